@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long CPU test")
+
+
+@pytest.fixture(scope="session")
+def oracle32():
+    from oracle.oracle import Oracle
+    import numpy as np
+    return Oracle(np.float32)
+
+
+@pytest.fixture(scope="session")
+def oracle64():
+    from oracle.oracle import Oracle
+    import numpy as np
+    return Oracle(np.float64)
