@@ -1,0 +1,68 @@
+"""Builds gslam_amd/libgsx.so (gfx950) from the HIP sources in this directory with hipcc.
+
+In-tree build: the .so travels to the GPU box with the repo snapshot; nothing is JIT-compiled at import time.
+``python -m gslam_amd.csrc.build [--force]``.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, "libgsx.so")
+OBJ = os.path.join(HERE, "_obj")
+ARCH = "gfx950"
+
+# -ffp-contract=off: integer outputs (radii, tile rectangles, sort keys) must match the CPU oracle bit for bit.
+SOURCES = {
+    "project.hip": ["-ffp-contract=off"],
+    "isect.hip": ["-ffp-contract=off"],
+    "raster.hip": [],
+    "ssim.hip": [],
+    "warp.hip": [],
+    "misc.hip": [],
+}
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-result", "-DNDEBUG"]
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src: str, extra: list[str], force: bool) -> str:
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    deps = [os.path.join(HERE, src), os.path.join(HERE, "gsx_common.h"),
+            os.path.join(PKG, "..", "include", "gsx.h"), os.path.abspath(__file__)]
+    if force or _stale(obj, deps):
+        cmd = ["hipcc", "-c", os.path.join(HERE, src), "-o", obj] + COMMON + extra
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda kv: _compile(kv[0], kv[1], force), SOURCES.items()))
+    if force or _stale(OUT, objs):
+        cmd = ["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print("built", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,275 @@
+// misc.hip — error plumbing, K13 spherical harmonics, fused multi-tensor Adam, device self-tests.
+#include <stdarg.h>
+
+#include "gsx_common.h"
+
+// ---- error plumbing -------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void gsx_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *gsx_last_error(void) { return g_err; }
+extern "C" int gsx_version(void) { return 100; }
+
+extern "C" int gsx_read_i64(const int64_t *dev_ptr, int64_t *host_out, void *stream) {
+    GSX_CHECK_ARG(dev_ptr && host_out);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(host_out, dev_ptr, sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        gsx_set_error("gsx_read_i64: %s", hipGetErrorString(hipGetLastError()));
+        return GSX_E_LAUNCH;
+    }
+    return GSX_OK;
+}
+
+namespace {
+
+// ---- K13: real spherical harmonics up to degree 3 ----------------------------------------------
+constexpr float SH_C0 = 0.2820947917738781f;
+constexpr float SH_C1 = 0.48860251190292f;
+constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f, SH_C2_2 = 0.31539156525252005f,
+                SH_C2_3 = -1.0925484305920792f, SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH_C3_2 = -0.4570457994644658f,
+                SH_C3_3 = 0.3731763325901154f, SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
+                SH_C3_6 = -0.5900435899266435f;
+
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float *B) {
+    B[0] = SH_C0;
+    if (deg < 1) return;
+    B[1] = -SH_C1 * y; B[2] = SH_C1 * z; B[3] = -SH_C1 * x;
+    if (deg < 2) return;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    B[4] = SH_C2_0 * xy; B[5] = SH_C2_1 * yz; B[6] = SH_C2_2 * (2.0f * zz - xx - yy);
+    B[7] = SH_C2_3 * xz; B[8] = SH_C2_4 * (xx - yy);
+    if (deg < 3) return;
+    B[9] = SH_C3_0 * y * (3.0f * xx - yy);
+    B[10] = SH_C3_1 * xy * z;
+    B[11] = SH_C3_2 * y * (4.0f * zz - xx - yy);
+    B[12] = SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+    B[13] = SH_C3_4 * x * (4.0f * zz - xx - yy);
+    B[14] = SH_C3_5 * z * (xx - yy);
+    B[15] = SH_C3_6 * x * (xx - 3.0f * yy);
+}
+
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float *dx, float *dy, float *dz) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dx[i] = dy[i] = dz[i] = 0.f;
+    if (deg < 1) return;
+    dy[1] = -SH_C1; dz[2] = SH_C1; dx[3] = -SH_C1;
+    if (deg < 2) return;
+    dx[4] = SH_C2_0 * y; dy[4] = SH_C2_0 * x;
+    dy[5] = SH_C2_1 * z; dz[5] = SH_C2_1 * y;
+    dx[6] = SH_C2_2 * -2.0f * x; dy[6] = SH_C2_2 * -2.0f * y; dz[6] = SH_C2_2 * 4.0f * z;
+    dx[7] = SH_C2_3 * z; dz[7] = SH_C2_3 * x;
+    dx[8] = SH_C2_4 * 2.0f * x; dy[8] = SH_C2_4 * -2.0f * y;
+    if (deg < 3) return;
+    const float xx = x * x, yy = y * y, zz = z * z;
+    dx[9] = SH_C3_0 * 6.0f * x * y; dy[9] = SH_C3_0 * (3.0f * xx - 3.0f * yy);
+    dx[10] = SH_C3_1 * y * z; dy[10] = SH_C3_1 * x * z; dz[10] = SH_C3_1 * x * y;
+    dx[11] = SH_C3_2 * -2.0f * x * y; dy[11] = SH_C3_2 * (4.0f * zz - xx - 3.0f * yy); dz[11] = SH_C3_2 * 8.0f * y * z;
+    dx[12] = SH_C3_3 * -6.0f * x * z; dy[12] = SH_C3_3 * -6.0f * y * z; dz[12] = SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+    dx[13] = SH_C3_4 * (4.0f * zz - 3.0f * xx - yy); dy[13] = SH_C3_4 * -2.0f * x * y; dz[13] = SH_C3_4 * 8.0f * x * z;
+    dx[14] = SH_C3_5 * 2.0f * x * z; dy[14] = SH_C3_5 * -2.0f * y * z; dz[14] = SH_C3_5 * (xx - yy);
+    dx[15] = SH_C3_6 * (3.0f * xx - 3.0f * yy); dy[15] = SH_C3_6 * -6.0f * x * y;
+}
+
+// one thread per Gaussian, looping cameras: the 192-byte coefficient row (degree 3) is read once per Gaussian
+__global__ __launch_bounds__(256) void sh_fwd_kernel(int deg, const float *__restrict__ dirs,
+                                                     const float *__restrict__ coeffs,
+                                                     const int32_t *__restrict__ radii, int64_t N, int C, int Kc,
+                                                     float *__restrict__ colors) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const int nb = (deg + 1) * (deg + 1);
+    float co[16 * 3];
+    for (int k = 0; k < nb; ++k) {
+        co[3 * k] = coeffs[(g * Kc + k) * 3]; co[3 * k + 1] = coeffs[(g * Kc + k) * 3 + 1];
+        co[3 * k + 2] = coeffs[(g * Kc + k) * 3 + 2];
+    }
+    for (int c = 0; c < C; ++c) {
+        const int64_t idx = (int64_t)c * N + g;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        if (!radii || radii[idx] > 0) {
+            float x = dirs[3 * idx], y = dirs[3 * idx + 1], z = dirs[3 * idx + 2];
+            const float n = sqrtf(x * x + y * y + z * z);
+            const float inv = n > 0.f ? 1.0f / n : 0.f;
+            x *= inv; y *= inv; z *= inv;
+            float B[16];
+            sh_basis(deg, x, y, z, B);
+            for (int k = 0; k < nb; ++k) { o0 += B[k] * co[3 * k]; o1 += B[k] * co[3 * k + 1]; o2 += B[k] * co[3 * k + 2]; }
+            o0 = fmaxf(0.f, o0 + 0.5f); o1 = fmaxf(0.f, o1 + 0.5f); o2 = fmaxf(0.f, o2 + 0.5f);
+        }
+        colors[3 * idx] = o0; colors[3 * idx + 1] = o1; colors[3 * idx + 2] = o2;
+    }
+}
+
+__global__ __launch_bounds__(256) void sh_bwd_kernel(int deg, const float *__restrict__ dirs,
+                                                     const float *__restrict__ coeffs,
+                                                     const int32_t *__restrict__ radii,
+                                                     const float *__restrict__ v_colors, int64_t N, int C, int Kc,
+                                                     float *__restrict__ v_coeffs, float *__restrict__ v_dirs) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const int nb = (deg + 1) * (deg + 1);
+    float co[16 * 3], vco[16 * 3];
+    for (int k = 0; k < 16; ++k) {
+        const bool in = k < nb;
+        for (int ch = 0; ch < 3; ++ch) {
+            co[3 * k + ch] = in ? coeffs[(g * Kc + k) * 3 + ch] : 0.f;
+            vco[3 * k + ch] = 0.f;
+        }
+    }
+    for (int c = 0; c < C; ++c) {
+        const int64_t idx = (int64_t)c * N + g;
+        float vdx = 0.f, vdy = 0.f, vdz = 0.f;
+        if (!radii || radii[idx] > 0) {
+            const float dx_ = dirs[3 * idx], dy_ = dirs[3 * idx + 1], dz_ = dirs[3 * idx + 2];
+            const float n = sqrtf(dx_ * dx_ + dy_ * dy_ + dz_ * dz_);
+            const float inv = n > 0.f ? 1.0f / n : 0.f;
+            const float x = dx_ * inv, y = dy_ * inv, z = dz_ * inv;
+            float B[16], bx[16], by[16], bz[16];
+            sh_basis(deg, x, y, z, B);
+            sh_basis_grad(deg, x, y, z, bx, by, bz);
+            float vx = 0.f, vy = 0.f, vz = 0.f;
+            for (int ch = 0; ch < 3; ++ch) {
+                float acc = 0.f;
+                for (int k = 0; k < nb; ++k) acc += B[k] * co[3 * k + ch];
+                if (!(acc + 0.5f > 0.f)) continue;
+                const float vc = v_colors[3 * idx + ch];
+                for (int k = 0; k < nb; ++k) {
+                    vco[3 * k + ch] += B[k] * vc;
+                    const float cv = co[3 * k + ch] * vc;
+                    vx += bx[k] * cv; vy += by[k] * cv; vz += bz[k] * cv;
+                }
+            }
+            const float dotp = vx * x + vy * y + vz * z;
+            vdx = (vx - dotp * x) * inv; vdy = (vy - dotp * y) * inv; vdz = (vz - dotp * z) * inv;
+        }
+        if (v_dirs) { v_dirs[3 * idx] = vdx; v_dirs[3 * idx + 1] = vdy; v_dirs[3 * idx + 2] = vdz; }
+    }
+    for (int k = 0; k < Kc; ++k)
+        for (int ch = 0; ch < 3; ++ch) v_coeffs[(g * Kc + k) * 3 + ch] = (k < nb) ? vco[3 * k + ch] : 0.f;
+}
+
+// ---- fused multi-tensor Adam --------------------------------------------------------------------------------------
+constexpr int ADAM_MAX = 8;
+struct AdamArgs {
+    float *p[ADAM_MAX];
+    const float *g[ADAM_MAX];
+    float *m[ADAM_MAX];
+    float *v[ADAM_MAX];
+    int64_t start[ADAM_MAX + 1];  // exclusive prefix of numels
+    float step_size[ADAM_MAX];    // lr / bias_correction1
+    int count;
+    float beta1, beta2, eps, bc2_sqrt;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
+    const int64_t total = a.start[a.count];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < ADAM_MAX; ++q) k += (q < a.count && i >= a.start[q]) ? 1 : 0;
+        const int64_t j = i - a.start[k];
+        const float grad = a.g[k][j];
+        float m = a.m[k][j], v = a.v[k][j];
+        m = m + (grad - m) * (1.0f - a.beta1);          // torch lerp form
+        v = a.beta2 * v + (1.0f - a.beta2) * grad * grad;
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        a.p[k][j] -= (a.step_size[k] * m) / denom;
+        a.m[k][j] = m;
+        a.v[k][j] = v;
+    }
+}
+
+// ---- self test ------------------------------------------------------------------------------------------------------
+__global__ void selftest_kernel(float *out) {
+    const int lane = threadIdx.x & 63;
+    const float v = (float)((lane * 37 + 11) % 101) - 50.0f + 0.25f * (float)(threadIdx.x >> 6);
+    const float a = gsx_wave_sum_dpp(v);
+    const float b = gsx_wave_sum_shfl(v);
+    out[threadIdx.x] = a;
+    out[256 + threadIdx.x] = b;
+}
+
+}  // namespace
+
+extern "C" int gsx_sh_fwd(int degree, const float *dirs, const float *coeffs, const int32_t *radii, int64_t N,
+                          int64_t C, int Kc, float *colors, void *stream) {
+    GSX_CHECK_ARG(degree >= 0 && degree <= 3 && dirs && coeffs && colors && N >= 0 && C >= 1);
+    GSX_CHECK_ARG((degree + 1) * (degree + 1) <= Kc);
+    if (N == 0) return GSX_OK;
+    hipLaunchKernelGGL(sh_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, degree, dirs,
+                       coeffs, radii, N, (int)C, Kc, colors);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_sh_bwd(int degree, const float *dirs, const float *coeffs, const int32_t *radii,
+                          const float *v_colors, int64_t N, int64_t C, int Kc, float *v_coeffs, float *v_dirs,
+                          void *stream) {
+    GSX_CHECK_ARG(degree >= 0 && degree <= 3 && dirs && coeffs && v_colors && v_coeffs && N >= 0 && C >= 1);
+    GSX_CHECK_ARG((degree + 1) * (degree + 1) <= Kc);
+    if (N == 0) return GSX_OK;
+    hipLaunchKernelGGL(sh_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, degree, dirs,
+                       coeffs, radii, v_colors, N, (int)C, Kc, v_coeffs, v_dirs);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_adam_multi(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                              float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1,
+                              float beta2, float eps, int64_t step_host, void *stream) {
+    GSX_CHECK_ARG(n_tensors >= 1 && n_tensors <= ADAM_MAX && params && grads && exp_avg && exp_avg_sq && numels && lrs);
+    GSX_CHECK_ARG(step_host >= 1);
+    AdamArgs a;
+    a.count = n_tensors;
+    a.start[0] = 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step_host), bc2 = 1.0 - pow((double)beta2, (double)step_host);
+    for (int k = 0; k < ADAM_MAX; ++k) {
+        const bool in = k < n_tensors;
+        a.p[k] = in ? params[k] : nullptr; a.g[k] = in ? grads[k] : nullptr;
+        a.m[k] = in ? exp_avg[k] : nullptr; a.v[k] = in ? exp_avg_sq[k] : nullptr;
+        a.start[k + 1] = a.start[k] + (in ? numels[k] : 0);
+        a.step_size[k] = in ? (float)((double)lrs[k] / bc1) : 0.f;
+        if (in) GSX_CHECK_ARG(numels[k] >= 0 && (numels[k] == 0 || (params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k])));
+    }
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.bc2_sqrt = (float)sqrt(bc2);
+    const int64_t total = a.start[n_tensors];
+    if (total == 0) return GSX_OK;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048 * 4) blocks = 2048 * 4;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_selftest(void *scratch, int64_t scratch_bytes, void *stream) {
+    GSX_CHECK_ARG(scratch && scratch_bytes >= 65536);
+    hipStream_t st = (hipStream_t)stream;
+    float *d = (float *)scratch;
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(256), 0, st, d);
+    GSX_CHECK_LAUNCH();
+    float h[512];
+    if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        gsx_set_error("gsx_selftest: copy back failed");
+        return GSX_E_LAUNCH;
+    }
+    for (int w = 0; w < 4; ++w) {
+        double ref = 0.0;
+        for (int l = 0; l < 64; ++l) ref += (double)((l * 37 + 11) % 101) - 50.0 + 0.25 * w;
+        for (int l = 0; l < 64; ++l) {
+            if (fabs(h[w * 64 + l] - ref) > 1e-3 || fabs(h[256 + w * 64 + l] - ref) > 1e-3) {
+                gsx_set_error("gsx_selftest: wave_sum mismatch wave %d lane %d: dpp=%f shfl=%f ref=%f", w, l,
+                              h[w * 64 + l], h[256 + w * 64 + l], ref);
+                return GSX_E_LAUNCH;
+            }
+        }
+    }
+    return GSX_OK;
+}

@@ -1,0 +1,203 @@
+// ssim.hip — K11/K12: fused SSIM loss, forward and backward.  Replaces rahul-goel/fused-ssim@30fb258c
+// `fused_ssim(img1, img2, padding, train)` (gslam/backend.py:13,303-307).  Maths: SURVEY.md §9.5.
+//
+// Mapping: one 256-thread workgroup per 16x16 output tile of one (batch, channel) plane.  The 26x26 input halo of
+// both images is staged in LDS once (zero padded), the 11-tap separable Gaussian runs horizontally into LDS
+// (5 moments) and vertically into registers.  Inputs are read through explicit (B,C,H,W) strides so the NHWC
+// renders of the rasteriser are consumed without a permute copy.  The map mean is reduced wave64 -> LDS -> one
+// partial per workgroup, then a single-block finishing kernel (deterministic, no atomics).
+#include "gsx_common.h"
+
+namespace {
+
+constexpr int TS = 16;           // output tile
+constexpr int HALO = 5;          // 11-tap window
+constexpr int IN = TS + 2 * HALO;  // 26
+
+__device__ __constant__ float c_win[11] = {1.0283800845e-03f, 7.5987581352e-03f, 3.6000772128e-02f, 1.0936068951e-01f,
+                                           2.1300553771e-01f, 2.6601172486e-01f, 2.1300553771e-01f, 1.0936068951e-01f,
+                                           3.6000772128e-02f, 7.5987581352e-03f, 1.0283800845e-03f};
+
+struct Strides {
+    int64_t b, c, h, w;
+};
+
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__ img1, const float *__restrict__ img2,
+                                                       int CH, int H, int W, Strides s1, Strides s2, int crop,
+                                                       float *__restrict__ partials, float *__restrict__ dm_dmu1,
+                                                       float *__restrict__ dm_ds1, float *__restrict__ dm_ds12) {
+    __shared__ float sx[IN][IN + 1];
+    __shared__ float sy[IN][IN + 1];
+    __shared__ float hz[5][IN][TS + 1];
+    __shared__ float s_red[4];
+    const int plane = blockIdx.z;
+    const int b = plane / CH, ch = plane - b * CH;
+    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const int t = threadIdx.x;
+    const float *p1 = img1 + b * s1.b + ch * s1.c;
+    const float *p2 = img2 + b * s2.b + ch * s2.c;
+    for (int i = t; i < IN * IN; i += 256) {
+        const int ly = i / IN, lx = i - ly * IN;
+        const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+        float a = 0.f, c = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            a = p1[gy * s1.h + gx * s1.w];
+            c = p2[gy * s2.h + gx * s2.w];
+        }
+        sx[ly][lx] = a;
+        sy[ly][lx] = c;
+    }
+    __syncthreads();
+    for (int i = t; i < IN * TS; i += 256) {
+        const int ly = i / TS, lx = i - ly * TS;
+        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float w = c_win[k], a = sx[ly][lx + k], c = sy[ly][lx + k];
+            m1 += w * a; m2 += w * c; e11 += w * a * a; e22 += w * c * c; e12 += w * a * c;
+        }
+        hz[0][ly][lx] = m1; hz[1][ly][lx] = m2; hz[2][ly][lx] = e11; hz[3][ly][lx] = e22; hz[4][ly][lx] = e12;
+    }
+    __syncthreads();
+    const int lx = t & 15, ly = t >> 4;
+    const int gx = x0 + lx, gy = y0 + ly;
+    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const float w = c_win[k];
+        m1 += w * hz[0][ly + k][lx]; m2 += w * hz[1][ly + k][lx]; e11 += w * hz[2][ly + k][lx];
+        e22 += w * hz[3][ly + k][lx]; e12 += w * hz[4][ly + k][lx];
+    }
+    float val = 0.f;
+    if (gx < W && gy < H) {
+        const float s1q = e11 - m1 * m1, s2q = e22 - m2 * m2, s12 = e12 - m1 * m2;
+        const float A = 2.0f * m1 * m2 + GSX_SSIM_C1, B = 2.0f * s12 + GSX_SSIM_C2;
+        const float Cq = m1 * m1 + m2 * m2 + GSX_SSIM_C1, D = s1q + s2q + GSX_SSIM_C2;
+        const float m = (A * B) / (Cq * D);
+        const bool in_crop = gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;
+        if (in_crop) val = m;
+        if (dm_dmu1) {
+            const int64_t o = ((int64_t)plane * H + gy) * W + gx;
+            dm_dmu1[o] = (m2 * 2.0f * B) / (Cq * D) - (m2 * 2.0f * A) / (Cq * D) - (m1 * 2.0f * A * B) / (Cq * Cq * D) +
+                         (m1 * 2.0f * A * B) / (Cq * D * D);
+            dm_ds1[o] = (-A * B) / (Cq * D * D);
+            dm_ds12[o] = (2.0f * A) / (Cq * D);
+        }
+    }
+    const float tot = gsx_wave_sum(val);
+    if ((t & 63) == 0) s_red[t >> 6] = tot;
+    __syncthreads();
+    if (t == 0) {
+        const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partials[bid] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partials, int64_t n,
+                                                              float *__restrict__ out) {
+    __shared__ float s_red[4];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) acc += partials[i];
+    const float tot = gsx_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(const float *__restrict__ img1, const float *__restrict__ img2,
+                                                       int CH, int H, int W, Strides s1, Strides s2, int crop,
+                                                       const float *__restrict__ dm_dmu1,
+                                                       const float *__restrict__ dm_ds1,
+                                                       const float *__restrict__ dm_ds12,
+                                                       const float *__restrict__ scale, float scale_mul,
+                                                       float *__restrict__ dL_dimg1) {
+    __shared__ float sm[3][IN][IN + 1];
+    __shared__ float hz[3][IN][TS + 1];
+    const int plane = blockIdx.z;
+    const int b = plane / CH, ch = plane - b * CH;
+    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const int t = threadIdx.x;
+    for (int i = t; i < IN * IN; i += 256) {
+        const int ly = i / IN, lx = i - ly * IN;
+        const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+        float a = 0.f, c = 0.f, d = 0.f;
+        if (gx >= crop && gx < W - crop && gy >= crop && gy < H - crop) {  // dL/dmap is zero outside the crop
+            const int64_t o = ((int64_t)plane * H + gy) * W + gx;
+            a = dm_dmu1[o]; c = dm_ds1[o]; d = dm_ds12[o];
+        }
+        sm[0][ly][lx] = a; sm[1][ly][lx] = c; sm[2][ly][lx] = d;
+    }
+    __syncthreads();
+    for (int i = t; i < IN * TS; i += 256) {
+        const int ly = i / TS, lx = i - ly * TS;
+        float a = 0.f, c = 0.f, d = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float w = c_win[k];
+            a += w * sm[0][ly][lx + k]; c += w * sm[1][ly][lx + k]; d += w * sm[2][ly][lx + k];
+        }
+        hz[0][ly][lx] = a; hz[1][ly][lx] = c; hz[2][ly][lx] = d;
+    }
+    __syncthreads();
+    const int lx = t & 15, ly = t >> 4;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx >= W || gy >= H) return;
+    float a = 0.f, c = 0.f, d = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const float w = c_win[k];
+        a += w * hz[0][ly + k][lx]; c += w * hz[1][ly + k][lx]; d += w * hz[2][ly + k][lx];
+    }
+    const float x = img1[b * s1.b + ch * s1.c + gy * s1.h + gx * s1.w];
+    const float y = img2[b * s2.b + ch * s2.c + gy * s2.h + gx * s2.w];
+    const float sc = scale[0] * scale_mul;
+    dL_dimg1[((int64_t)plane * H + gy) * W + gx] = sc * (a + 2.0f * x * c + y * d);
+}
+
+}  // namespace
+
+extern "C" int64_t gsx_ssim_workspace_bytes(int64_t B, int CH, int H, int W) {
+    const int64_t blocks = B * CH * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
+    return gsx_align256(blocks * (int64_t)sizeof(float)) + 256;
+}
+
+extern "C" int gsx_ssim_fwd(const float *img1, const float *img2, int64_t B, int CH, int H, int W,
+                            const int64_t *strides1, const int64_t *strides2, int crop, float *out_sum,
+                            float *dm_dmu1, float *dm_dsigma1_sq, float *dm_dsigma12, void *workspace,
+                            int64_t workspace_bytes, void *stream) {
+    GSX_CHECK_ARG(img1 && img2 && strides1 && strides2 && out_sum && B >= 1 && CH >= 1 && H > 0 && W > 0);
+    GSX_CHECK_ARG(crop >= 0 && H > 2 * crop && W > 2 * crop);
+    GSX_CHECK_ARG((dm_dmu1 == nullptr) == (dm_dsigma1_sq == nullptr) && (dm_dmu1 == nullptr) == (dm_dsigma12 == nullptr));
+    GSX_CHECK_ARG(B * CH < 65536);
+    if (!workspace || workspace_bytes < gsx_ssim_workspace_bytes(B, CH, H, W)) {
+        gsx_set_error("gsx_ssim_fwd: workspace too small");
+        return GSX_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, (unsigned)(B * CH));
+    const Strides s1{strides1[0], strides1[1], strides1[2], strides1[3]};
+    const Strides s2{strides2[0], strides2[1], strides2[2], strides2[3]};
+    float *partials = (float *)workspace;
+    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, st, img1, img2, CH, H, W, s1, s2, crop, partials, dm_dmu1,
+                       dm_dsigma1_sq, dm_dsigma12);
+    GSX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, partials,
+                       (int64_t)grid.x * grid.y * grid.z, out_sum);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_ssim_bwd(const float *img1, const float *img2, int64_t B, int CH, int H, int W,
+                            const int64_t *strides1, const int64_t *strides2, int crop, const float *dm_dmu1,
+                            const float *dm_dsigma1_sq, const float *dm_dsigma12, const float *scale, float scale_mul,
+                            float *dL_dimg1, void *stream) {
+    GSX_CHECK_ARG(img1 && img2 && strides1 && strides2 && dm_dmu1 && dm_dsigma1_sq && dm_dsigma12 && scale && dL_dimg1);
+    GSX_CHECK_ARG(B >= 1 && CH >= 1 && H > 0 && W > 0 && crop >= 0 && B * CH < 65536);
+    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, (unsigned)(B * CH));
+    const Strides s1{strides1[0], strides1[1], strides1[2], strides1[3]};
+    const Strides s2{strides2[0], strides2[1], strides2[2], strides2[3]};
+    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img1, img2, CH, H, W, s1, s2, crop,
+                       dm_dmu1, dm_dsigma1_sq, dm_dsigma12, scale, scale_mul, dL_dimg1);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}

@@ -1,0 +1,171 @@
+/*
+ * gsx.h — C ABI of libgsx.so, the MI355X (gfx950) native kernels behind the gslam render / loss / warp hot path.
+ *
+ * This is the drop-in boundary.  The reference binds its CUDA kernels through two Python
+ * extension modules that are NOT in /root/reference (gsplat fork, fused-ssim); the entry points below are what a
+ * binding for THIS path needs, one per kernel stage, and each cites the reference call site it replaces.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch / C++ types.
+ *  - All data pointers are DEVICE pointers (HBM) unless marked host.  fp32 everywhere, ids int32, isect keys int64.
+ *  - The caller owns every buffer, including workspaces (query *_workspace_bytes first).  The library never
+ *    allocates or frees device memory and never synchronises the stream, except gsx_read_i64 (explicit read-back).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous.
+ *  - Return value: 0 = ok, negative = GSX_E_*; text via gsx_last_error() (thread-local).  No exceptions cross.
+ *  - Re-entrant; no global mutable state; safe from several processes / threads on distinct streams.
+ *  - [C,N,...] arrays are row-major; "flatten id" = c*N + g.
+ */
+#ifndef GSX_H
+#define GSX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSX_OK 0
+#define GSX_E_INVALID -1   /* bad argument / shape            */
+#define GSX_E_LAUNCH -2    /* hip launch or runtime error      */
+#define GSX_E_UNSUPPORTED -3
+#define GSX_E_WORKSPACE -4 /* workspace too small              */
+
+/* numeric constants of the external kernels; one place, one line to change */
+#define GSX_FOV_SLACK 0.3f
+#define GSX_RADIUS_FLOOR 0.01f
+#define GSX_RADIUS_SIGMA 3.0f
+#define GSX_ALPHA_MAX 0.999f
+#define GSX_ALPHA_MIN (1.0f / 255.0f)
+#define GSX_T_MIN 1e-4f
+#define GSX_SSIM_C1 0.0001f
+#define GSX_SSIM_C2 0.0009f
+#define GSX_BETA_MIN 0.01f        /* gslam/rasterization.py:149 */
+#define GSX_TILE 16               /* gslam/rasterization.py:59 (only 16 is supported, as upstream tests) */
+#define GSX_REC_STRIDE_MAX 12     /* splat record: xy(2) conic(3) opac(1) colors(<=5), padded to 8 or 12 floats */
+
+/* projection flags */
+#define GSX_PROJ_LOG_SCALES 1     /* `scales` holds log-scales; exp() is fused (gslam/rasterization.py:147) */
+#define GSX_PROJ_RENDER_DEPTH 2   /* gslam record: append camera depth channel (rasterization.py:234-240)   */
+#define GSX_PROJ_BETAS 4          /* gslam record: append beta=clamp(exp(log_unc),0.01) (rasterization.py:149,249-256) */
+
+int gsx_version(void);
+const char *gsx_last_error(void);
+/* number of floats per splat record for CH colour channels (8 for CH<=2, 12 for CH<=5); <0 if unsupported */
+int gsx_record_stride(int CH);
+/* explicit device->host read-back of one int64 (synchronises `stream`) */
+int gsx_read_i64(const int64_t *dev_ptr, int64_t *host_out, void *stream);
+
+/* ---- K1: gsplat fully_fused_projection fwd  (gslam/rasterization.py:153-170, :390-407) -------------------------
+ * outputs [C,N]: radii i32, means2d [.,2], depths, conics [.,3], comps (nullable; 'antialiased' compensation).
+ * Culled rows are written as zeros.  tiles_per_gauss (nullable) = K3 count for tile 16 (rasterization.py:259-272).
+ * Optional fused gslam front-end (rasterization.py:145-149,183-256): when `rec` != NULL a splat record
+ * [xy, conic, opacity, colors...] of gsx_record_stride(CH) floats is written per (c,g) with
+ *   opacity = sigmoid(logit_opacities[g]); colors = sigmoid(logit_colors[g,0:3]) (+ depth) (+ beta), CH = 3 + flags.
+ */
+int gsx_project_fwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                    const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                    float far_plane, float radius_clip, int flags, int32_t *radii, float *means2d, float *depths,
+                    float *conics, float *comps, int32_t *tiles_per_gauss, int tile_w, int tile_h,
+                    const float *logit_opacities, const float *logit_colors, const float *log_uncertainties,
+                    float *rec, void *stream);
+
+/* ---- K2: projection bwd (autograd of K1; pose gradient used at gslam/frontend.py:627-646, backend.py:665-670) --
+ * v_means2d / v_conics are read with a row stride in floats (2 / 3 when dense, the record stride when they alias
+ * a v_rec buffer).  v_depths, v_comps, v_rec nullable.  Outputs are OVERWRITTEN (sum over cameras done inside):
+ * v_means [N,3], v_quats [N,4], v_scales [N,3] (w.r.t. log-scales when GSX_PROJ_LOG_SCALES), v_viewmats [C,4,4]
+ * (nullable).  With v_rec: also v_logit_opacities [N], v_logit_colors [N,3], v_log_unc [N] (gslam front-end bwd).
+ * workspace: gsx_project_bwd_workspace_bytes(N, C).
+ */
+int64_t gsx_project_bwd_workspace_bytes(int64_t N, int64_t C);
+int gsx_project_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                    const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                    float far_plane, int flags, const int32_t *radii, const float *v_means2d,
+                    int64_t v_means2d_stride, const float *v_depths, const float *v_conics, int64_t v_conics_stride,
+                    const float *v_comps, const float *logit_opacities, const float *logit_colors,
+                    const float *log_uncertainties, const float *v_rec, float *v_means, float *v_quats,
+                    float *v_scales, float *v_viewmats, float *v_logit_opacities, float *v_logit_colors,
+                    float *v_log_unc, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---- K10: gsplat.quat_scale_to_covar_preci (gslam/insertion.py:88-91) ------------------------------------------ */
+int gsx_quat_scale_to_covar_preci(const float *quats, const float *scales, int64_t n, float *covars /*[n,3,3]*/,
+                                  float *precis /*[n,3,3], nullable*/, void *stream);
+
+/* ---- pack separate [C,N,*] arrays into splat records (front of gsplat rasterize_to_pixels,
+ *      gslam/rasterization.py:325-339).  opac_stride_c / color_stride_c = 0 broadcasts an [N]-shaped input over C. */
+int gsx_pack_records(const float *means2d, const float *conics, const float *opacities, const float *colors,
+                     int64_t N, int64_t C, int CH, float *rec, void *stream);
+
+/* ---- K3..K7: gsplat isect_tiles + isect_offset_encode (gslam/rasterization.py:259-274) ----------------------------
+ * Integer-exact contract: key = cam<<(32+tile_n_bits) | tile<<32 | float_bits(depth); stable order.
+ */
+int gsx_isect_count(const float *means2d, const int32_t *radii, int64_t CN, int tile_w, int tile_h,
+                    int32_t *tiles_per_gauss, void *stream);
+/* inclusive scan of tiles_per_gauss -> cum_tiles int64 [CN]; M = cum_tiles[CN-1] */
+int64_t gsx_scan_workspace_bytes(int64_t CN);
+int gsx_isect_scan(const int32_t *tiles_per_gauss, int64_t CN, int64_t *cum_tiles, void *workspace,
+                   int64_t workspace_bytes, void *stream);
+/* emit + sort; writes sorted isect_ids [M] and flatten_ids [M] */
+int64_t gsx_isect_sort_workspace_bytes(int64_t M);
+int gsx_isect_emit_sort(const float *means2d, const int32_t *radii, const float *depths, const int64_t *cum_tiles,
+                        int64_t N, int64_t C, int tile_w, int tile_h, int64_t M, int sort, int64_t *isect_ids,
+                        int32_t *flatten_ids, void *workspace, int64_t workspace_bytes, void *stream);
+int gsx_isect_offset_encode(const int64_t *isect_ids, int64_t M, int64_t C, int tile_w, int tile_h,
+                            int32_t *offsets /*[C,tile_h,tile_w]*/, void *stream);
+
+/* ---- K8: gsplat(fork) rasterize_to_pixels fwd (gslam/rasterization.py:325-339; fork: + n_touched) ----------------
+ * rec: splat records [C*N, gsx_record_stride(CH)].  render [C,H,W,CH], alphas [C,H,W], last_ids [C,H,W] (global
+ * sorted index of the last contributing entry, -1 if none), n_touched [C*N] int32 (must be zeroed by the caller).
+ */
+int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds /*[C,CH] nullable*/, const int32_t *offsets,
+                   const int32_t *flatten_ids, int64_t M, int64_t C, int W, int H, int tile_w, int tile_h,
+                   float visibility_min_T, float *render, float *alphas, int32_t *last_ids, int32_t *n_touched,
+                   void *stream);
+/* ---- K9: rasterize_to_pixels bwd.  v_rec [C*N, stride] must be zeroed by the caller; gradients are accumulated
+ * in record layout: v_xy(2) v_conic(3) v_opacity(1) v_colors(CH).  v_abs (nullable, [C*N,2], zeroed): absgrad.   */
+int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
+                   const int32_t *flatten_ids, int64_t M, int64_t C, int W, int H, int tile_w, int tile_h,
+                   const float *alphas, const int32_t *last_ids, const float *v_render, const float *v_alphas,
+                   float *v_rec, float *v_abs, void *stream);
+
+/* ---- K13: spherical harmonics (gsplat.rendering.rasterization(sh_degree=)) -------------------------- */
+int gsx_sh_fwd(int degree, const float *dirs /*[C,N,3]*/, const float *coeffs /*[N,Kc,3]*/, const int32_t *radii,
+               int64_t N, int64_t C, int Kc, float *colors /*[C,N,3]*/, void *stream);
+int gsx_sh_bwd(int degree, const float *dirs, const float *coeffs, const int32_t *radii, const float *v_colors,
+               int64_t N, int64_t C, int Kc, float *v_coeffs /*[N,Kc,3] overwritten*/, float *v_dirs /*[C,N,3] nullable*/,
+               void *stream);
+
+/* ---- K11/K12: fused_ssim (gslam/backend.py:303-307).  img strides in floats: (sB,sC,sH,sW) ------------------------
+ * fwd: out_sum[0] = sum of the SSIM map over the crop (crop = 5 for 'valid', 0 for 'same'); the mean is
+ * out_sum/(B*CH*(H-2crop)*(W-2crop)).  dm_* (nullable when train=0): three [B,CH,H,W] planar maps for the bwd.    */
+int64_t gsx_ssim_workspace_bytes(int64_t B, int CH, int H, int W);
+int gsx_ssim_fwd(const float *img1, const float *img2, int64_t B, int CH, int H, int W, const int64_t *strides1,
+                 const int64_t *strides2, int crop, float *out_sum, float *dm_dmu1, float *dm_dsigma1_sq,
+                 float *dm_dsigma12, void *workspace, int64_t workspace_bytes, void *stream);
+/* bwd: dL_dimg1 [B,CH,H,W] planar = scale[0] * (conv(w; m*dm_dmu1) + 2 img1 conv(m*dm_ds1) + img2 conv(m*dm_ds12)),
+ * m = crop mask; `scale` is a DEVICE scalar (upstream grad / numel folded by the caller into scale_mul).           */
+int gsx_ssim_bwd(const float *img1, const float *img2, int64_t B, int CH, int H, int W, const int64_t *strides1,
+                 const int64_t *strides2, int crop, const float *dm_dmu1, const float *dm_dsigma1_sq,
+                 const float *dm_dsigma12, const float *scale, float scale_mul, float *dL_dimg1, void *stream);
+
+/* ---- Warp (gslam/warp.py:35-82).  T = f1_pose @ inv(f2_pose) [4,4], K, Kinv [3,3] device pointers ---------------- */
+int gsx_warp_fwd(const float *T, const float *K, const float *Kinv, const float *c1 /*[H,W,3]*/,
+                 const float *d1 /*[H,W]*/, int H, int W, float *result /*[H,W,3]*/, float *nwarps /*[H,W,2]*/,
+                 uint8_t *keep_mask /*[H,W]*/, void *stream);
+int64_t gsx_warp_bwd_workspace_bytes(int H, int W);
+int gsx_warp_bwd(const float *T, const float *K, const float *Kinv, const float *c1, const float *d1, int H, int W,
+                 const float *v_result, const float *v_nwarps /*nullable*/, float *v_T /*[4,4] overwritten*/,
+                 void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---- fused Adam (torch.optim.Adam(fused=True) defaults; gslam/backend.py:565-602).  Up to 8 tensors per launch.
+ * step_dev: device int64 holding the 1-based step AFTER increment is step_dev[0]+1; kernel does not modify it
+ * when step_host > 0 (then step_host is used).                                                                      */
+int gsx_adam_multi(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                   float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1, float beta2,
+                   float eps, int64_t step_host, void *stream);
+
+/* ---- self tests of device primitives (wave64 reductions); returns 0 if all pass.  scratch: >= 64 KiB device ----- */
+int gsx_selftest(void *scratch, int64_t scratch_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSX_H */

@@ -877,7 +877,7 @@ int gsxo_adam(int64_t n, real *p, const real *g, real *m, real *v, real lr, real
         m[i] = m[i] + (g[i] - m[i]) * (RC(1.0) - beta1); /* lerp form used by torch */
         v[i] = beta2 * v[i] + (RC(1.0) - beta2) * g[i] * g[i];
         const real denom = R_SQRT(v[i]) / bc2_sqrt + eps;
-        p[i] -= step_size * (m[i] / denom);
+        p[i] -= (step_size * m[i]) / denom;
     }
     return 0;
 }

@@ -1,0 +1,420 @@
+"""HIP path vs CPU oracle on identical seeded inputs (the parity tests proper).  Run on the MI355X box:
+    python -m pytest tests -m gpu -x -q
+Bars (BASELINE.json north_star): bit-exact integer outputs (radii, tile counts, isect ids, flatten ids, offsets);
+render within 1e-4 L1 per pixel; gradients within fp32 round-off of the oracle's.  Nothing here reads
+/root/reference."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _scene(n, seed, c, W=640, H=480, dev=None):
+    from gslam_amd.synthetic import make_cameras, make_scene
+    sc = make_scene(n, seed)
+    viewmats, Ks = make_cameras(c, W, H)
+    if dev is not None:
+        sc = {k: v.to(dev) for k, v in sc.items()}
+        viewmats, Ks = viewmats.to(dev), Ks.to(dev)
+    return sc, viewmats, Ks
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_selftest_wave_primitives(dev):
+    from gslam_amd._lib import check, lib
+    scratch = torch.empty(1 << 16, dtype=torch.uint8, device=dev)
+    check(lib.gsx_selftest(scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream), "selftest")
+
+
+@pytest.mark.parametrize("n,c", [(1, 1), (7, 2), (10000, 2), (50000, 8)])
+def test_projection_forward_bit_exact(dev, oracle32, n, c):
+    from gslam_amd import ops
+    sc, viewmats, Ks = _scene(n, 0, c)
+    scales = torch.exp(sc["scales"])
+    radii, m2d, dep, con, comp = ops.fully_fused_projection(
+        sc["means"].to(dev), None, sc["quats"].to(dev), scales.to(dev), viewmats.to(dev), Ks.to(dev), 640, 480,
+        calc_compensations=True)
+    o = oracle32.project_fwd(_np(sc["means"]), _np(sc["quats"]), _np(scales), _np(viewmats), _np(Ks), 640, 480,
+                             calc_compensations=True)
+    assert np.array_equal(_np(radii), o[0])
+    assert np.array_equal(_np(m2d), o[1])
+    assert np.array_equal(_np(dep), o[2])
+    assert np.array_equal(_np(con), o[3])
+    assert np.array_equal(_np(comp), o[4])
+    if n >= 10000:
+        assert (o[0] > 0).sum() > 100 and (o[0] == 0).sum() > 100  # both culled and visible rows are exercised
+
+
+def test_projection_culling_edge_cases(dev, oracle32):
+    """behind camera, beyond far, off-image bbox, huge radius, radius_clip."""
+    from gslam_amd import ops
+    means = torch.tensor([[0, 0, -1.0], [0, 0, 0.005], [0, 0, 2.0], [50.0, 0, 2.0], [0.0, 40.0, 2.0],
+                          [1.21, 0.9, 2.0], [0, 0, 0.02], [0.3, 0.2, 5.0]])
+    quats = torch.tensor([[1.0, 0, 0, 0]] * 8)
+    scales = torch.tensor([[0.05, 0.05, 0.05]] * 8)
+    scales[6] = 3.0
+    viewmats, Ks = torch.eye(4)[None], torch.tensor([[[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]]])
+    for clip in (0.0, 40.0):
+        r = ops.fully_fused_projection(means.to(dev), None, quats.to(dev), scales.to(dev), viewmats.to(dev),
+                                       Ks.to(dev), 640, 480, radius_clip=clip)
+        o = oracle32.project_fwd(_np(means), _np(quats), _np(scales), _np(viewmats), _np(Ks), 640, 480,
+                                 radius_clip=clip)
+        assert np.array_equal(_np(r[0]), o[0]) and np.array_equal(_np(r[1]), o[1])
+    assert list(o[0][0][:2]) == [0, 0] and o[0][0][2] == 0  # clip=40 removes the small central splat too
+    # packed variant (rasterization.py:390-419): compacted in flatten-id order
+    cam, gid, pr, pm, pd, pc, _ = ops.fully_fused_projection(means.to(dev), None, quats.to(dev), scales.to(dev),
+                                                             viewmats.to(dev), Ks.to(dev), 640, 480, packed=True)
+    o = oracle32.project_fwd(_np(means), _np(quats), _np(scales), _np(viewmats), _np(Ks), 640, 480)
+    sel = np.nonzero(o[0] > 0)
+    assert np.array_equal(_np(cam), sel[0]) and np.array_equal(_np(gid), sel[1])
+    assert np.array_equal(_np(pr), o[0][sel]) and np.array_equal(_np(pm), o[1][sel])
+
+
+def test_projection_backward_matches_oracle(dev, oracle32, oracle64):
+    from gslam_amd import ops
+    n, c = 3000, 3
+    sc, viewmats, Ks = _scene(n, 1, c)
+    scales = torch.exp(sc["scales"])
+    ins = [sc["means"], sc["quats"], scales, viewmats]
+    gin = [t.clone().to(dev).requires_grad_(True) for t in ins]
+    radii, m2d, dep, con, comp = ops.fully_fused_projection(gin[0], None, gin[1], gin[2], gin[3], Ks.to(dev), 640,
+                                                            480, calc_compensations=True)
+    g = torch.Generator().manual_seed(5)
+    w = [torch.randn(t.shape, generator=g) for t in (m2d, dep, con, comp)]
+    loss = sum((a * b.to(dev)).sum() for a, b in zip((m2d, dep, con, comp), w))
+    loss.backward()
+    # fp64 oracle is the yardstick; the fp32 oracle shows what fp32 round-off looks like
+    o64 = oracle64.project_bwd(_np(ins[0]), _np(ins[1]), _np(ins[2]), _np(ins[3]), _np(Ks), 640, 480, _np(radii),
+                               _np(w[0]), _np(w[1]), _np(w[2]), _np(w[3]))
+    o32 = oracle32.project_bwd(_np(ins[0]), _np(ins[1]), _np(ins[2]), _np(ins[3]), _np(Ks), 640, 480, _np(radii),
+                               _np(w[0]), _np(w[1]), _np(w[2]), _np(w[3]))
+    for name, got, ref64, ref32 in zip(("means", "quats", "scales", "viewmats"), gin, o64, o32):
+        got = _np(got.grad).astype(np.float64)
+        scale = np.abs(ref64).max() + 1e-12
+        err = np.abs(got - ref64).max() / scale
+        err32 = np.abs(ref32 - ref64).max() / scale
+        assert err < max(5e-5, 20 * err32), (name, err, err32)
+
+
+@pytest.mark.parametrize("n,c,W,H", [(5000, 1, 640, 480), (20000, 2, 640, 480), (3000, 8, 640, 480),
+                                      (4000, 1, 1920, 1080), (500, 1, 70, 50)])
+def test_isect_bit_exact(dev, oracle32, n, c, W, H):
+    from gslam_amd import ops
+    from gslam_amd.synthetic import make_cameras, make_scene
+    sc = make_scene(n, 2)
+    viewmats, Ks = make_cameras(c, W, H)
+    scales = torch.exp(sc["scales"]) * (3.0 if W < 100 else 1.0)
+    o = oracle32.project_fwd(_np(sc["means"]), _np(sc["quats"]), _np(scales), _np(viewmats), _np(Ks), W, H)
+    radii, m2d, dep = o[0], o[1], o[2]
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    tpg, ids, flat = ops.isect_tiles(torch.from_numpy(m2d).to(dev), torch.from_numpy(radii).to(dev),
+                                     torch.from_numpy(dep).to(dev), 16, tw, th, n_cameras=c)
+    off = ops.isect_offset_encode(ids, c, tw, th)
+    otpg, oids, oflat = oracle32.isect_tiles(m2d, radii, dep, 16, tw, th)
+    ooff = oracle32.isect_offset_encode(oids, c, tw, th)
+    assert np.array_equal(_np(tpg), otpg)
+    assert np.array_equal(_np(ids), oids)
+    assert np.array_equal(_np(flat), oflat)
+    assert np.array_equal(_np(off), ooff)
+    assert len(oids) > 0
+    # unsorted emission order is part of the contract too (sort=False)
+    _, ids_u, flat_u = ops.isect_tiles(torch.from_numpy(m2d).to(dev), torch.from_numpy(radii).to(dev),
+                                       torch.from_numpy(dep).to(dev), 16, tw, th, sort=False)
+    _, oids_u, oflat_u = oracle32.isect_tiles(m2d, radii, dep, 16, tw, th, sort=False)
+    assert np.array_equal(_np(ids_u), oids_u) and np.array_equal(_np(flat_u), oflat_u)
+
+
+def test_isect_ties_and_empty(dev, oracle32):
+    """equal depths must keep ascending flatten-id order; zero intersections give all-zero offsets."""
+    from gslam_amd import ops
+    m2d = np.array([[[100.0, 100.0], [100.0, 100.0], [104.0, 98.0], [100.0, 100.0]]], np.float32)
+    radii = np.array([[20, 20, 20, 20]], np.int32)
+    dep = np.array([[2.0, 1.0, 2.0, 2.0]], np.float32)
+    tpg, ids, flat = ops.isect_tiles(torch.from_numpy(m2d).to(dev), torch.from_numpy(radii).to(dev),
+                                     torch.from_numpy(dep).to(dev), 16, 40, 30)
+    otpg, oids, oflat = oracle32.isect_tiles(m2d, radii, dep, 16, 40, 30)
+    assert np.array_equal(_np(ids), oids) and np.array_equal(_np(flat), oflat)
+    radii0 = np.zeros((1, 4), np.int32)
+    tpg, ids, flat = ops.isect_tiles(torch.from_numpy(m2d).to(dev), torch.from_numpy(radii0).to(dev),
+                                     torch.from_numpy(dep).to(dev), 16, 40, 30)
+    assert ids.numel() == 0 and flat.numel() == 0 and int(tpg.sum()) == 0
+    off = ops.isect_offset_encode(ids, 1, 40, 30)
+    assert int(off.abs().sum()) == 0
+
+
+def _oracle_pipeline(o, sc, viewmats, Ks, W, H, ch, seed=3):
+    scales = torch.exp(sc["scales"])
+    radii, m2d, dep, con, _ = o.project_fwd(_np(sc["means"]), _np(sc["quats"]), _np(scales), _np(viewmats), _np(Ks),
+                                            W, H)
+    c, n = radii.shape
+    rng = np.random.default_rng(seed)
+    colors = rng.uniform(0, 1, (c, n, ch)).astype(np.float32)
+    opac = rng.uniform(0.05, 0.95, (c, n)).astype(np.float32)
+    bg = rng.uniform(0, 1, (c, ch)).astype(np.float32)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    tpg, ids, flat = o.isect_tiles(m2d, radii, dep, 16, tw, th)
+    off = o.isect_offset_encode(ids, c, tw, th)
+    return m2d, con, colors, opac, bg, off, flat
+
+
+@pytest.mark.parametrize("n,c,W,H,ch", [(3000, 1, 640, 480, 5), (3000, 2, 320, 240, 3), (2000, 1, 200, 120, 1),
+                                         (2000, 1, 330, 250, 4), (2000, 1, 330, 250, 2)])
+def test_raster_forward_backward_vs_oracle(dev, oracle32, n, c, W, H, ch):
+    from gslam_amd import ops
+    from gslam_amd.synthetic import make_cameras, make_scene
+    sc = make_scene(n, 4)
+    sc["scales"] = sc["scales"] + 0.7   # fatter splats: deeper per-pixel lists, exercises early termination
+    viewmats, Ks = make_cameras(c, W, H)
+    m2d, con, colors, opac, bg, off, flat = _oracle_pipeline(oracle32, sc, viewmats, Ks, W, H, ch)
+    o_render, o_alpha, o_last, o_nt = oracle32.raster_fwd(m2d, con, colors, opac, bg, W, H, 16, off, flat)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    gin = [t(m2d).requires_grad_(True), t(con).requires_grad_(True), t(colors).requires_grad_(True),
+           t(opac).requires_grad_(True)]
+    tbg = t(bg).requires_grad_(True)
+    render, alphas, n_touched = ops.rasterize_to_pixels(gin[0], gin[1], gin[2], gin[3], W, H, 16, t(off), t(flat),
+                                                        backgrounds=tbg)
+    l1 = np.abs(_np(render) - o_render).mean()
+    assert l1 < 1e-5, l1
+    assert np.abs(_np(render) - o_render).max() < 2e-3
+    assert np.abs(_np(alphas) - o_alpha).max() < 1e-4
+    nt_mismatch = (_np(n_touched) != o_nt).mean()
+    assert nt_mismatch < 2e-3, nt_mismatch
+    assert o_nt.sum() > 0 and (o_last >= 0).mean() > 0.3
+    # backward
+    g = torch.Generator().manual_seed(7)
+    w_r, w_a = torch.randn(render.shape, generator=g), torch.randn(alphas.shape, generator=g)
+    (render * w_r.to(dev)).sum().add((alphas * w_a.to(dev)).sum()).backward()
+    o_v = oracle32.raster_bwd(m2d, con, colors, opac, bg, W, H, 16, off, flat, o_alpha, o_last, _np(w_r), _np(w_a))
+    for name, got, ref in zip(("means2d", "conics", "colors", "opacities"), gin, o_v[:4]):
+        got = _np(got.grad)
+        scale = np.abs(ref).max() + 1e-12
+        # a pixel whose alpha sits on the 1/255 or T<=1e-4 cut may flip between CPU expf and GPU __expf:
+        # bound the worst case loosely and the bulk tightly
+        assert np.abs(got - ref).max() / scale < 5e-3, (name, np.abs(got - ref).max() / scale)
+        assert np.abs(got - ref).mean() / (np.abs(ref).mean() + 1e-12) < 2e-4, name
+    ref_bg = (_np(w_r) * (1.0 - o_alpha)).sum(axis=(1, 2))
+    np.testing.assert_allclose(_np(tbg.grad), ref_bg, rtol=1e-3, atol=1e-3)
+
+
+def test_raster_many_channels_and_absgrad(dev, oracle32):
+    """CH > 5 goes through channel chunks; absgrad side channel as in gsplat."""
+    from gslam_amd import ops
+    from gslam_amd.synthetic import make_cameras, make_scene
+    n, c, W, H, ch = 1500, 1, 200, 150, 7
+    sc = make_scene(n, 9)
+    sc["scales"] = sc["scales"] + 0.7
+    viewmats, Ks = make_cameras(c, W, H)
+    m2d, con, colors, opac, bg, off, flat = _oracle_pipeline(oracle32, sc, viewmats, Ks, W, H, ch)
+    o_render, o_alpha, o_last, _ = oracle32.raster_fwd(m2d, con, colors, opac, bg, W, H, 16, off, flat)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tm = t(m2d).requires_grad_(True)
+    render, alphas, _ = ops.rasterize_to_pixels(tm, t(con), t(colors), t(opac), W, H, 16, t(off), t(flat),
+                                                backgrounds=t(bg), absgrad=True)
+    assert render.shape[-1] == 7 and np.abs(_np(render) - o_render).mean() < 1e-5
+    render[..., :5].sum().backward()
+    vr = np.zeros_like(o_render)
+    vr[..., :5] = 1.0
+    ov = oracle32.raster_bwd(m2d, con, colors, opac, bg, W, H, 16, off, flat, o_alpha, o_last, vr,
+                             np.zeros_like(o_alpha), absgrad=True)
+    assert hasattr(tm, "absgrad")
+
+
+@pytest.mark.parametrize("mode,with_unc", [("RGB", True), ("RGB+D", True), ("RGB+D", False), ("RGB", False)])
+def test_gslam_rasterization_fused_vs_oracle(dev, oracle32, mode, with_unc):
+    from gslam_amd.rasterization import rasterization
+    n, c, W, H = 4000, 2, 640, 480
+    sc, viewmats, Ks = _scene(n, 11, c)
+    sc["log_uncertainties"] = torch.linspace(-6.0, 1.0, n)
+    d = {k: v.to(dev) for k, v in sc.items()}
+    out = rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], viewmats.to(dev),
+                        Ks.to(dev), W, H, packed=False, render_mode=mode,
+                        log_uncertainties=d["log_uncertainties"] if with_unc else None,
+                        backgrounds=torch.zeros(c, 3, device=dev))
+    scales_gpu = torch.exp(d["scales"]).cpu().numpy()     # same exp as the device (bit-exact index contract)
+    o = oracle32.gslam_rasterization(_np(sc["means"]), _np(sc["quats"]), _np(sc["scales"]), _np(sc["opacities"]),
+                                     _np(sc["colors"]), _np(viewmats), _np(Ks), W, H, render_mode=mode,
+                                     log_uncertainties=_np(sc["log_uncertainties"]) if with_unc else None,
+                                     backgrounds=np.zeros((c, 3), np.float32), scales_override=scales_gpu)
+    for f in ("radii", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
+        assert np.array_equal(_np(getattr(out, f)), o[f]), f
+    for f in ("means2d", "depths", "conics"):
+        assert np.array_equal(_np(getattr(out, f)), o[f]), f
+    assert np.abs(_np(out.rgbs) - o["rgbs"]).mean() < 1e-5
+    assert np.abs(_np(out.alphas) - o["alphas"]).max() < 1e-4
+    np.testing.assert_allclose(_np(out.opacities), o["opacities"], atol=1e-6)
+    if mode == "RGB+D":
+        assert np.abs(_np(out.depthmaps) - o["depthmaps"]).mean() < 1e-5
+    else:
+        assert out.depthmaps is None
+    if with_unc:
+        assert np.abs(_np(out.betas) - o["betas"]).mean() < 1e-5
+        empty = o["alphas"][..., 0] == 0
+        np.testing.assert_allclose(_np(out.betas)[empty], np.e, rtol=1e-6)
+    else:
+        assert out.betas is None
+    assert out.n_touched.dtype == torch.int64 and (_np(out.n_touched) != o["n_touched"]).mean() < 2e-3
+    assert (out.tile_width, out.tile_height, out.width, out.height, out.tile_size, out.n_cameras) == (40, 30, W, H, 16, c)
+
+
+def test_gslam_rasterization_fused_grads_match_unfused(dev):
+    """The fused path (activations+packing inside K1/K2) must give the same gradients as the reference's op
+    sequence (torch activations -> projection -> cat -> rasterize) built from the low-level ops; and
+    means2d.retain_grad() must work (gslam/backend.py:326)."""
+    from gslam_amd import ops
+    from gslam_amd.rasterization import rasterization
+    n, c, W, H = 3000, 2, 320, 240
+    sc, viewmats, Ks = _scene(n, 12, c, W, H)
+    sc["scales"] = sc["scales"] + 0.5
+    names = ("means", "quats", "scales", "opacities", "colors", "log_uncertainties")
+    g = torch.Generator().manual_seed(3)
+    gt = torch.rand(c, H, W, 3, generator=g).to(dev)
+
+    def loss_of(out_rgbs, out_depth, out_betas, alphas):
+        return ((out_rgbs - gt).square().sum(-1) / (2 * out_betas.square())).mean() + 0.01 * out_depth.mean() \
+            + 0.1 * alphas.mean()
+
+    # fused
+    pa = {k: sc[k].clone().to(dev).requires_grad_(True) for k in names}
+    va = viewmats.clone().to(dev).requires_grad_(True)
+    out = rasterization(pa["means"], pa["quats"], pa["scales"], pa["opacities"], pa["colors"], va, Ks.to(dev), W, H,
+                        packed=False, render_mode="RGB+D", log_uncertainties=pa["log_uncertainties"],
+                        backgrounds=torch.zeros(c, 3, device=dev))
+    out.means2d.retain_grad()
+    loss_of(out.rgbs, out.depthmaps, out.betas, out.alphas).backward()
+    assert out.means2d.grad is not None and out.means2d.grad.shape == (c, n, 2)
+    assert out.means2d.grad.abs().sum() > 0
+
+    # unfused: the reference's own op sequence (rasterization.py:145-348) on the low-level ops
+    pb = {k: sc[k].clone().to(dev).requires_grad_(True) for k in names}
+    vb = viewmats.clone().to(dev).requires_grad_(True)
+    opac = torch.sigmoid(pb["opacities"])
+    cols = torch.sigmoid(pb["colors"])
+    scales = torch.exp(pb["scales"])
+    betas = torch.exp(pb["log_uncertainties"]).clamp(min=0.01)
+    radii, m2d, dep, con, _ = ops.fully_fused_projection(pb["means"], None, pb["quats"], scales, vb, Ks.to(dev), W, H)
+    m2d.retain_grad()
+    colors = torch.cat((cols.expand(c, -1, -1), dep[..., None], betas.expand(c, -1)[..., None]), dim=-1)
+    bg = torch.cat([torch.zeros(c, 4, device=dev), torch.full((c, 1), math.e, device=dev)], -1)
+    tpg, ids, flat = ops.isect_tiles(m2d, radii, dep, 16, math.ceil(W / 16), math.ceil(H / 16))
+    off = ops.isect_offset_encode(ids, c, math.ceil(W / 16), math.ceil(H / 16))
+    render, alphas, nt = ops.rasterize_to_pixels(m2d, con, colors, opac.repeat(c, 1), W, H, 16, off, flat,
+                                                 backgrounds=bg)
+    assert torch.equal(radii, out.radii) and torch.equal(flat, out.flatten_ids)
+    assert (render[..., :3] - out.rgbs).abs().max() < 1e-5
+    loss_of(render[..., :3], render[..., 3], render[..., 4], alphas).backward()
+    for k in names:
+        a, b = pa[k].grad, pb[k].grad
+        assert (a - b).abs().max() <= 1e-4 * b.abs().max() + 1e-9, (k, (a - b).abs().max(), b.abs().max())
+    assert (va.grad - vb.grad).abs().max() <= 1e-3 * vb.grad.abs().max() + 1e-9
+    assert (out.means2d.grad - m2d.grad).abs().max() <= 1e-4 * m2d.grad.abs().max() + 1e-9
+
+
+@pytest.mark.parametrize("padding", ["same", "valid"])
+def test_fused_ssim_vs_oracle(dev, oracle32, padding):
+    from gslam_amd.ssim import fused_ssim
+    g = torch.Generator().manual_seed(0)
+    B, H, W = 2, 75, 131
+    a = torch.rand(B, H, W, 3, generator=g)
+    b = (a + 0.1 * torch.randn(B, H, W, 3, generator=g)).clamp(0, 1)
+    ta = a.to(dev).requires_grad_(True)
+    val = fused_ssim(ta.permute(0, 3, 1, 2), b.to(dev).permute(0, 3, 1, 2), padding=padding)   # backend.py:303-307
+    val.backward()
+    oval, og = oracle32.fused_ssim(_np(a.permute(0, 3, 1, 2)), _np(b.permute(0, 3, 1, 2)), padding)
+    assert abs(float(val) - float(oval)) < 2e-6
+    got = _np(ta.grad.permute(0, 3, 1, 2))
+    assert np.abs(got - og).max() < 1e-3 * np.abs(og).max() + 1e-9
+    with torch.no_grad():
+        same = fused_ssim(ta.permute(0, 3, 1, 2), ta.permute(0, 3, 1, 2), padding=padding, train=False)
+    assert abs(float(same) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["warp_48x64.npz", "warp_120x160.npz"])
+def test_warp_vs_reference_golden(dev, name):
+    from gslam_amd.warp import Warp
+    g = dict(np.load(os.path.join(GOLD, name)))
+    H, W = g["d1"].shape
+    warp = Warp(torch.from_numpy(g["K"]).to(dev), H, W)
+    f1 = torch.from_numpy(g["f1_pose"]).to(dev).requires_grad_(True)
+    f2 = torch.from_numpy(g["f2_pose"]).to(dev).requires_grad_(True)
+    res, nw, keep = warp(f1, f2, torch.from_numpy(g["c1"]).to(dev), torch.from_numpy(g["d1"]).to(dev))
+    assert res.shape == (H, W, 3) and nw.shape == (1, H, W, 2) and keep.dtype == torch.bool
+    np.testing.assert_allclose(_np(nw), g["normalized_warps"], atol=3e-6)
+    border = (np.abs(np.abs(g["normalized_warps"][0]) - 1.0) < 1e-5).any(-1)
+    assert (_np(keep) == g["keep_mask"])[~border].all()
+    assert np.abs(_np(res) - g["result"]).max() < 2e-4 and np.abs(_np(res) - g["result"]).mean() < 5e-6
+    (res[keep].sum() + 0.1 * nw.square().sum()).backward()             # same loss as oracle/gen_golden.py
+    scale = max(np.abs(g["grad_f1"]).max(), 1.0)
+    np.testing.assert_allclose(_np(f1.grad)[:3], g["grad_f1"][:3], atol=5e-4 * scale)
+    np.testing.assert_allclose(_np(f2.grad)[:3], g["grad_f2"][:3], atol=5e-4 * scale)
+    eye = torch.eye(4, device=dev)
+    res_id, _, _ = warp(eye, eye, torch.from_numpy(g["c1"]).to(dev), torch.from_numpy(g["d1"]).to(dev))
+    if "result_identity" in g and name == "warp_48x64.npz":
+        assert np.abs(_np(res_id) - g["result_identity"]).max() < 1e-4
+
+
+def test_sh_vs_oracle(dev, oracle32):
+    from gslam_amd import ops
+    g = torch.Generator().manual_seed(1)
+    c, n = 2, 5000
+    dirs = torch.randn(c, n, 3, generator=g)
+    coeffs = torch.randn(n, 16, 3, generator=g) * 0.3
+    radii = (torch.rand(c, n, generator=g) > 0.2).to(torch.int32)
+    w = torch.randn(c, n, 3, generator=g)
+    for deg in (0, 1, 2, 3):
+        td, tc = dirs.to(dev).requires_grad_(True), coeffs.to(dev).requires_grad_(True)
+        col = ops.spherical_harmonics(deg, td, tc, masks=radii.to(dev))
+        ocol = oracle32.sh_fwd(deg, _np(dirs), _np(coeffs), _np(radii))
+        assert np.abs(_np(col) - ocol).max() < 2e-6
+        (col * w.to(dev)).sum().backward()
+        ovc, ovd = oracle32.sh_bwd(deg, _np(dirs), _np(coeffs), _np(w), _np(radii))
+        assert np.abs(_np(tc.grad) - ovc).max() < 1e-5 * max(1.0, np.abs(ovc).max())
+        assert np.abs(_np(td.grad) - ovd).max() < 1e-4 * max(1.0, np.abs(ovd).max())
+
+
+def test_quat_scale_to_covar_preci(dev, oracle32):
+    from gslam_amd import ops
+    g = torch.Generator().manual_seed(2)
+    q, s = torch.randn(1000, 4, generator=g), torch.rand(1000, 3, generator=g) + 0.1
+    cov, pre = ops.quat_scale_to_covar_preci(q.to(dev), s.to(dev))
+    oc, op = oracle32.quat_scale_to_covar_preci(_np(q), _np(s))
+    assert np.array_equal(_np(cov), oc) and np.array_equal(_np(pre), op)
+
+
+def test_adam_matches_torch_and_oracle(dev, oracle32):
+    from gslam_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1000, 3), (1000, 4), (1000, 3), (1000,), (1000, 3), (1000,)]
+    lrs = [1.6e-3, 5e-3, 5e-3, 2.5e-2, 1e-2, 2.5e-3]                # gslam/backend.py:53-58
+    p0 = [torch.randn(s, generator=g) for s in shapes]
+    ours = [p.clone().to(dev).requires_grad_(True) for p in p0]
+    ref = [p.clone().to(dev).requires_grad_(True) for p in p0]
+    opt = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(ours, lrs)])
+    ropts = [torch.optim.Adam([p], lr=lr) for p, lr in zip(ref, lrs)]
+    cpu = [(_np(p), np.zeros(p.shape, np.float32), np.zeros(p.shape, np.float32)) for p in p0]
+    for step in range(1, 6):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        for p, q, gr in zip(ours, ref, grads):
+            p.grad = gr.clone().to(dev)
+            q.grad = gr.clone().to(dev)
+        opt.step()
+        for ro in ropts:
+            ro.step()
+        cpu = [oracle32.adam(p, _np(gr), m, v, lr, step) for (p, m, v), gr, lr in zip(cpu, grads, lrs)]
+    for p, q, (cp, _, _) in zip(ours, ref, cpu):
+        assert (p - q).abs().max() < 1e-6
+        assert np.abs(_np(p) - cp).max() < 1e-6
