@@ -1,0 +1,173 @@
+"""Keyframe bundle adjustment ("mapping") loop: the loss block, optimiser plumbing and iteration of
+``Backend.optimize_map`` (gslam/backend.py:249-407, 554-602), without the process / viewer / rerun shell.
+
+Multi-GPU: the window's keyframes are sharded over ranks (gslam_amd.dist.KeyframeShard); every rank holds a replica
+of the map, renders its own cameras and the per-Gaussian gradients are summed with one RCCL all-reduce of a single
+[N,15] bucket.  With world_size == 1 the code path is identical minus the collective.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import dist as gdist
+from .map import GaussianSplattingData
+from .optim import FusedAdam
+from .primitives import Frame
+from .rasterization import RasterizationOutput
+from .ssim import fused_ssim
+from .utils import StopOnPlateau, create_batch, edge_aware_tv
+
+
+@dataclass
+class MapConfig:
+    """Subset of gslam/backend.py:43-107 that the loss / optimiser path reads (same names, same defaults)."""
+    isotropic_regularization_weight: float = 0.0005
+    depth_regularization_weight: float = 0.000001
+    pose_optim_lr: float = 0.003
+    means_lr: float = 0.0016
+    opacity_lr: float = 0.025
+    scale_lr: float = 0.005
+    color_lr: float = 0.01
+    quat_lr: float = 0.005
+    log_uncertainty_lr: float = 0.0025
+    opacity_decay: float = 0.995
+    optim_window_last_n_keyframes: int = 8
+    num_iters_mapping: int = 15
+    num_iters_initialization: int = 400
+    ssim_weight: float = 0.2
+    active_gs: bool = True
+    device: str = 'cuda'
+
+
+SPLAT_LRS = (('means', 'means_lr'), ('quats', 'quat_lr'), ('scales', 'scale_lr'), ('opacities', 'opacity_lr'),
+             ('colors', 'color_lr'), ('log_uncertainties', 'log_uncertainty_lr'))
+
+
+def mapping_loss(splats: GaussianSplattingData, outputs: RasterizationOutput, gt_imgs: torch.Tensor,
+                 exposure_params: torch.Tensor, conf: MapConfig, regularize: bool = True, c_total: Optional[int] = None,
+                 visible_gaussians: Optional[torch.Tensor] = None, iso_scale: float = 1.0):
+    """gslam/backend.py:273-318.  ``c_total`` (cameras in the whole window) rescales the per-camera means when this
+    rank holds only a shard: mean over C = sum over shards of (C_local / C) * local mean."""
+    C_local = gt_imgs.shape[0]
+    shard = 1.0 if c_total is None else C_local / float(c_total)
+    rendered = outputs.rgbs * exposure_params[..., 0].view(-1, 1, 1, 1).exp() + exposure_params[..., 1].view(-1, 1, 1, 1)
+    if conf.active_gs:
+        photometric = (rendered - gt_imgs).square().sum(dim=-1)
+        photometric = (photometric / (2 * outputs.betas.square())).mean()
+        photometric = photometric + (outputs.betas.log().square() * 0.5).mean()
+    else:
+        photometric = (outputs.rgbs - gt_imgs).square().mean()
+    if visible_gaussians is None:
+        visible_gaussians = outputs.radii.sum(dim=0) > 0
+    # same value as indexing with the boolean mask (backend.py:287-296) but without the nonzero() host sync
+    mean_scales = splats.scales.mean(dim=1, keepdim=True).exp().detach()
+    isotropic = ((splats.scales.exp() - mean_scales).abs() * visible_gaussians[:, None]).sum()
+    depth_reg = edge_aware_tv(outputs.depthmaps, outputs.rgbs, outputs.alphas[..., 0] > 0.4)
+    ssim_loss = 1.0 - fused_ssim(outputs.rgbs.permute(0, 3, 1, 2), gt_imgs.permute(0, 3, 1, 2), padding='valid')
+    total = shard * ((1.0 - conf.ssim_weight) * photometric + conf.ssim_weight * ssim_loss) \
+        + iso_scale * conf.isotropic_regularization_weight * isotropic
+    if regularize:
+        total = total + conf.depth_regularization_weight * depth_reg     # a SUM: no shard scaling
+    return total, photometric
+
+
+class MapOptimizers:
+    """The six splat Adams + the pose Adam of backend.py:554-602,665-670 as two multi-tensor launches."""
+
+    def __init__(self, splats: GaussianSplattingData, conf: MapConfig):
+        self.conf = conf
+        self.splat_opt = FusedAdam([{"params": [getattr(splats, name)], "lr": getattr(conf, lr)}
+                                    for name, lr in SPLAT_LRS])
+        self.pose_opt: Optional[FusedAdam] = None
+        self._pose_ids = set()
+
+    def add_pose(self, pose: torch.nn.Module, lr: Optional[float] = None):
+        params = [p for p in pose.parameters() if p.requires_grad and id(p) not in self._pose_ids]
+        if not params:
+            return
+        self._pose_ids.update(id(p) for p in params)
+        group = {"params": params, "lr": self.conf.pose_optim_lr if lr is None else lr}
+        if self.pose_opt is None:
+            self.pose_opt = FusedAdam([group])
+        else:
+            self.pose_opt.add_param_group(group)
+
+    def zero_grad(self):
+        self.splat_opt.zero_grad(set_to_none=True)
+        if self.pose_opt is not None:
+            self.pose_opt.zero_grad(set_to_none=True)
+
+    def step(self):
+        self.splat_opt.step()
+        if self.pose_opt is not None:
+            self.pose_opt.step()
+
+
+class BundleAdjuster:
+    """One object per process/GPU.  ``step(window)`` is one iteration of the loop at backend.py:260-359."""
+
+    def __init__(self, splats: GaussianSplattingData, conf: Optional[MapConfig] = None):
+        self.splats = splats
+        self.conf = conf or MapConfig()
+        self.optimizers = MapOptimizers(splats, self.conf)
+        self.shard = gdist.KeyframeShard()
+        self.bucket = gdist.GradBucket(splats) if self.shard.world_size > 1 else None
+        self.total_step = 0
+        self.last_outputs: Optional[RasterizationOutput] = None
+
+    def step(self, window: List[Frame], regularize: bool = True, decay_opacity: bool = True):
+        """window = ALL keyframes of the BA window (every rank passes the same list); this rank renders its shard."""
+        conf = self.conf
+        self.total_step += 1
+        mine = self.shard.select(window)
+        for f in mine:
+            self.optimizers.add_pose(f.pose)
+        self.optimizers.zero_grad()
+        if self.bucket is not None:
+            self.bucket.attach_zeroed()
+        cameras = [f.camera for f in mine]
+        poses = [f.pose for f in mine]
+        gt_imgs = create_batch(mine, lambda f: f.img)
+        exposure = create_batch(mine, lambda f: f.exposure_params)
+        outputs = self.splats(cameras, poses, render_depth=True)
+        vis_count = (outputs.radii > 0).sum(dim=0).to(torch.int32)
+        if self.shard.world_size > 1:
+            vis_count = self.shard.all_reduce_sum(vis_count)
+        total, photometric = mapping_loss(self.splats, outputs, gt_imgs, exposure, conf, regularize,
+                                          c_total=len(window), visible_gaussians=vis_count > 0,
+                                          iso_scale=1.0 / self.shard.world_size)
+        outputs.means2d.retain_grad()                                   # backend.py:326
+        total.backward()
+        if self.bucket is not None:
+            self.bucket.all_reduce()
+        self.optimizers.step()
+        if decay_opacity:
+            with torch.no_grad():                                       # backend.py:356-359
+                self.splats.opacities.data.mul_(torch.where(vis_count > 1, conf.opacity_decay, 1.0))
+        self.last_outputs = outputs
+        return total.detach(), photometric.detach()
+
+    def optimize_map(self, window: List[Frame], n_iters: Optional[int] = None, regularize: bool = True,
+                     early_stop: bool = True):
+        """backend.py:249-362 without pruning/insertion."""
+        n_iters = self.conf.num_iters_mapping if n_iters is None else n_iters
+        stopper = StopOnPlateau(3, 0.012)
+        last = None
+        for _ in range(n_iters):
+            total, photometric = self.step(window, regularize)
+            last = (total, photometric)
+            if early_stop:
+                pm = photometric
+                if self.shard.world_size > 1:
+                    pm = self.shard.all_reduce_sum(pm * (len(self.shard.select(window)) / len(window)))
+                if stopper.stop(pm.item()):
+                    break
+        outputs = self.last_outputs
+        if outputs is not None:
+            for f, d in zip(self.shard.select(window), outputs.depthmaps):
+                f.est_depths = d.detach().clone()
+        return last

@@ -1,0 +1,94 @@
+"""PoseZhou / Camera / Frame of gslam/primitives.py (the parts on the hot path).
+
+PoseZhou = fixed ``Rt`` times a learnable delta (6D rotation by Gram-Schmidt + translation), 9 scalars per pose;
+this is the SE(3) parametrisation the v_viewmats gradient of K2 flows into (primitives.py:15-36,40-92)."""
+from __future__ import annotations
+
+from copy import deepcopy
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+
+def rotation_6d_to_matrix(d6: torch.Tensor) -> torch.Tensor:
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = F.normalize(a1, dim=-1)
+    b2 = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
+    b2 = F.normalize(b2, dim=-1)
+    b3 = torch.cross(b1, b2, dim=-1)
+    return torch.stack((b1, b2, b3), dim=-2)
+
+
+class PoseZhou(torch.nn.Module):
+    def __init__(self, _pose: Optional[torch.Tensor] = None, is_learnable: bool = True):
+        super().__init__()
+        self.is_learnable = is_learnable
+        self.register_buffer("Rt", torch.eye(4) if _pose is None else _pose)
+        self.dt = torch.nn.Parameter(torch.zeros(3, dtype=torch.float32, device=self.Rt.device),
+                                     requires_grad=is_learnable)
+        self.dR = torch.nn.Parameter(torch.zeros(6, dtype=torch.float32, device=self.Rt.device),
+                                     requires_grad=is_learnable)
+        self.register_buffer("id", torch.tensor([1, 0, 0, 0, 1, 0], device=self.Rt.device, dtype=torch.float32))
+        self.register_buffer("eye4_row4", torch.tensor([0, 0, 0, 1], device=self.Rt.device, dtype=self.Rt.dtype))
+
+    def forward(self) -> torch.Tensor:
+        if not self.is_learnable:
+            return self.Rt
+        rot = rotation_6d_to_matrix(self.dR + self.id)
+        dRt = torch.cat([torch.cat([rot, self.dt.view(3, 1)], dim=-1), self.eye4_row4.view(1, 4)])
+        return torch.matmul(self.Rt, dRt)
+
+
+Pose = PoseZhou  # gslam/map.py:5 imports the pose type under this name
+
+
+@dataclass
+class Camera:
+    intrinsics: torch.Tensor
+    height: int
+    width: int
+
+    def to(self, device):
+        self.intrinsics = self.intrinsics.to(device)
+        return self
+
+    def clone(self):
+        return Camera(self.intrinsics.detach(), self.height, self.width)
+
+    @torch.no_grad()
+    def backproject(self, depth_map: torch.Tensor) -> torch.Tensor:
+        """[H,W] depth -> [H*W,3] camera-space points (gslam/primitives.py:369-395)."""
+        fx, fy = self.intrinsics[0, 0], self.intrinsics[1, 1]
+        cx, cy = self.intrinsics[0, 2], self.intrinsics[1, 2]
+        H, W = depth_map.shape
+        vs, us = torch.meshgrid(torch.arange(H, device=depth_map.device), torch.arange(W, device=depth_map.device),
+                                indexing='ij')
+        xs = (us - cx) * (depth_map / fx)
+        ys = (vs - cy) * (depth_map / fy)
+        return torch.stack([xs, ys, depth_map], dim=-1).reshape(-1, 3)
+
+
+@dataclass
+class Frame:
+    img: torch.Tensor
+    timestamp: float
+    camera: Camera
+    pose: PoseZhou
+    gt_pose: torch.Tensor
+    index: int
+    gt_depth: torch.Tensor = None
+    img_file: str = None
+    visible_gaussians: torch.Tensor = None
+    est_depths: torch.Tensor = None
+    exposure_params: torch.Tensor = None
+
+    def to(self, device):
+        attrs = {k: (v.to(device) if hasattr(v, 'to') else v) for k, v in vars(self).items()}
+        return type(self)(**attrs)
+
+    @torch.no_grad()
+    def strip(self):
+        return type(self)(None, self.timestamp, self.camera, deepcopy(self.pose), self.gt_pose, self.index, None,
+                          self.img_file, None, None, self.exposure_params.detach().clone()).to(self.img.device)

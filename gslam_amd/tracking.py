@@ -1,0 +1,114 @@
+"""Per-frame camera tracking: ``Frontend.tracking_loss`` / ``igs_track_lbfgs`` / ``warp_track`` of
+gslam/frontend.py:113-138, 604-662, 521-569 without the process / logging shell.  C = 1: tracking does not shard
+("replicas only") - spare GPUs run bundle adjustment while one tracks."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .map import GaussianSplattingData
+from .primitives import Frame
+from .warp import Warp
+
+
+@dataclass
+class TrackingConfig:
+    """Subset of gslam/frontend.py:44-61 (same names / defaults)."""
+    device: str = 'cuda'
+    num_tracking_iters: int = 200          # warp tracker iterations (frontend.py:47-51)
+    photometric_loss: str = 'active-nerf'
+    pose_optim_lr: float = 0.002
+    pose_optim_lr_decay: float = 0.99
+    learn_exposure_params: bool = True
+    use_gt_depths: bool = False
+    n_adam_warmup: int = 10                # frontend.py:651
+    lbfgs_history: int = 5                 # frontend.py:613-619
+
+
+def tracking_loss(conf: TrackingConfig, gt_img, rendered_img, betas=None, rendered_depth=None, gt_depth=None):
+    """gslam/frontend.py:113-138."""
+    error = rendered_img - gt_img
+    if conf.photometric_loss == 'l1':
+        loss = error.abs().mean()
+    elif conf.photometric_loss == 'mse':
+        loss = error.square().mean()
+    elif conf.photometric_loss == 'active-nerf':
+        loss = (error.square().sum(dim=-1) * betas.pow(-2.0)).mean()
+    elif conf.photometric_loss == 'none':
+        loss = error
+    else:
+        raise ValueError(conf.photometric_loss)
+    if conf.use_gt_depths:
+        depth_error = (rendered_depth - gt_depth)[gt_depth > 0.0]
+        loss = loss + depth_error.abs().mean() * 0.01
+    return loss
+
+
+def igs_track_lbfgs(splats: GaussianSplattingData, new_frame: Frame, conf: Optional[TrackingConfig] = None,
+                    prev_exposure: Optional[torch.Tensor] = None, max_eval: Optional[int] = None):
+    """Default tracker (gslam/frontend.py:604-662): 10 Adam steps then one L-BFGS(strong Wolfe) step on the pose
+    delta (+ exposure).  Every closure is one C=1 render forward+backward.  Returns (last_loss, n_closures)."""
+    conf = conf or TrackingConfig()
+    n_evals = 0
+    params = list(new_frame.pose.parameters())
+    if conf.learn_exposure_params:
+        if prev_exposure is not None:
+            new_frame.exposure_params.data = prev_exposure.clone().detach()
+        params.append(new_frame.exposure_params)
+    kw = {} if max_eval is None else {"max_eval": max_eval}
+    optimizer = torch.optim.LBFGS(params, history_size=conf.lbfgs_history, line_search_fn='strong_wolfe',
+                                  tolerance_change=1e-9, lr=conf.pose_optim_lr, **kw)
+    last_loss = None
+
+    def closure():
+        nonlocal n_evals, last_loss
+        n_evals += 1
+        if torch.is_grad_enabled():
+            optimizer.zero_grad()
+        outputs = splats([new_frame.camera], [new_frame.pose], render_depth=True)
+        rendered_rgb = outputs.rgbs[0]
+        if conf.learn_exposure_params:
+            rendered_rgb = rendered_rgb * new_frame.exposure_params[0].exp() + new_frame.exposure_params[1]
+        loss = tracking_loss(conf, rendered_rgb, new_frame.img, outputs.betas[0], outputs.depthmaps[0],
+                             new_frame.gt_depth)
+        if loss.requires_grad:
+            loss.backward()
+        last_loss = loss.item()
+        return loss
+
+    warm = torch.optim.Adam(params, conf.pose_optim_lr)
+    for _ in range(conf.n_adam_warmup):
+        closure()
+        warm.step()
+        warm.zero_grad()
+    optimizer.step(closure)
+    return last_loss, n_evals
+
+
+def warp_track(new_frame: Frame, ref_frame: Frame, ref_img: torch.Tensor, ref_depth: torch.Tensor,
+               conf: Optional[TrackingConfig] = None, n_iters: Optional[int] = None):
+    """Alternative tracker (gslam/frontend.py:521-569): SGD-Nesterov on the pose through the depth-based warp of the
+    last keyframe; masked L1 with exposure affine."""
+    conf = conf or TrackingConfig()
+    n_iters = conf.num_tracking_iters if n_iters is None else n_iters
+    K = new_frame.camera.intrinsics
+    warp = Warp(K, new_frame.camera.height, new_frame.camera.width).to(K.device)
+    params = list(new_frame.pose.parameters())
+    if conf.learn_exposure_params:
+        params.append(new_frame.exposure_params)
+    opt = torch.optim.SGD(params, lr=conf.pose_optim_lr, momentum=0.8, nesterov=True)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=conf.pose_optim_lr_decay)
+    loss = None
+    ref_pose = ref_frame.pose().detach()
+    for _ in range(n_iters):
+        opt.zero_grad()
+        result, _, keep = warp(ref_pose, new_frame.pose(), ref_img, ref_depth)
+        if conf.learn_exposure_params:
+            result = result * new_frame.exposure_params[0].exp() + new_frame.exposure_params[1]
+        loss = ((result - new_frame.img).abs() * keep[..., None]).sum() / keep.sum().clamp(min=1) / 3.0
+        loss.backward()
+        opt.step()
+        sched.step()
+    return loss
