@@ -49,6 +49,23 @@ __device__ __forceinline__ float gsx_wave_sum_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Interleaved partial reduction of N independent values: after the call, lanes 15/31/47/63 hold the sums of their
+// 16-lane DPP rows.  The N chains are advanced step by step so that consecutive DPP instructions are independent
+// (no s_nop wait states between a VALU write and the DPP read of the same register).
+template <int N>
+__device__ __forceinline__ void gsx_row16_sum(float (&v)[N]) {
+#define GSX_ROW_STEP(ctrl)                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < N; ++k) {                                                          \
+        const int x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k]), ctrl, 0xf, 0xf, true);   \
+        v[k] += __builtin_bit_cast(float, x);                                                                \
+    }
+    GSX_ROW_STEP(0x111)
+    GSX_ROW_STEP(0x112)
+    GSX_ROW_STEP(0x114)
+    GSX_ROW_STEP(0x118)
+#undef GSX_ROW_STEP
+}
+
 __device__ __forceinline__ float gsx_wave_sum_shfl(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -60,6 +77,26 @@ __device__ __forceinline__ float gsx_wave_sum_shfl(float v) {
 #else
 #define gsx_wave_sum gsx_wave_sum_shfl
 #endif
+
+// LDS float add without return value (ds_add_f32).  Written as inline asm so that the AMDGPU atomic optimizer does not
+// wrap it in its own wave-wide DPP reduction: the callers have already reduced to a handful of active lanes.
+__device__ __forceinline__ void gsx_lds_fadd(float *lds_ptr, float v) {
+    const unsigned addr = (unsigned)(uintptr_t)lds_ptr;  // LDS pointers are 32-bit offsets in the generic->local cast
+    asm volatile("ds_add_f32 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+
+template <int BYTE_OFF>
+__device__ __forceinline__ void gsx_lds_fadd_off(unsigned lds_addr, float v) {
+    asm volatile("ds_add_f32 %0, %1 offset:%2" : : "v"(lds_addr), "v"(v), "n"(BYTE_OFF) : "memory");
+}
+
+template <int N, int K = 0>
+__device__ __forceinline__ void gsx_lds_fadd_row(unsigned lds_addr, const float (&v)[N]) {
+    if constexpr (K < N) {
+        gsx_lds_fadd_off<4 * K>(lds_addr, v[K]);
+        gsx_lds_fadd_row<N, K + 1>(lds_addr, v);
+    }
+}
 
 __device__ __forceinline__ int gsx_lane() { return threadIdx.x & 63; }
 

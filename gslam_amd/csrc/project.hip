@@ -433,16 +433,24 @@ __global__ __launch_bounds__(PBWD_THREADS) void project_bwd_kernel(
     }
 }
 
-__global__ void project_bwd_finish_kernel(const float *__restrict__ partials, int n_blocks, int C,
-                                          float *__restrict__ v_viewmats) {
-    // one block per camera, 64 threads: thread k<12 sums column k over all blocks (coalesced-ish 48 B rows)
+__global__ __launch_bounds__(256) void project_bwd_finish_kernel(const float *__restrict__ partials, int n_blocks,
+                                                                 int C, float *__restrict__ v_viewmats) {
+    // one workgroup per camera: 21 row-strided accumulators x 12 columns, then a 21-term fold per column
+    __shared__ float s_acc[21][12];
     const int c = blockIdx.x;
-    const int k = threadIdx.x;
-    if (k >= 16) return;
-    float acc = 0.f;
-    if (k < 12)
-        for (int b = 0; b < n_blocks; ++b) acc += partials[((int64_t)b * C + c) * 12 + k];
-    v_viewmats[c * 16 + k] = acc;  // row 3 (k = 12..15) stays zero
+    const int k = threadIdx.x % 12, r = threadIdx.x / 12;
+    if (r < 21) {
+        float acc = 0.f;
+        for (int b = r; b < n_blocks; b += 21) acc += partials[((int64_t)b * C + c) * 12 + k];
+        s_acc[r][k] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float acc = 0.f;
+        if (threadIdx.x < 12)
+            for (int rr = 0; rr < 21; ++rr) acc += s_acc[rr][threadIdx.x];
+        v_viewmats[c * 16 + threadIdx.x] = acc;  // row 3 (entries 12..15) stays zero
+    }
 }
 
 __global__ void qs2cp_kernel(const float *__restrict__ quats, const float *__restrict__ scales, int64_t n,
@@ -567,7 +575,7 @@ extern "C" int gsx_project_bwd(const float *means, const float *quats, const flo
                        v_logit_colors, v_log_unc);
     GSX_CHECK_LAUNCH();
     if (v_viewmats) {
-        hipLaunchKernelGGL(project_bwd_finish_kernel, dim3((unsigned)C), dim3(64), 0, st, partials, (int)blocks,
+        hipLaunchKernelGGL(project_bwd_finish_kernel, dim3((unsigned)C), dim3(256), 0, st, partials, (int)blocks,
                            (int)C, v_viewmats);
         GSX_CHECK_LAUNCH();
     }

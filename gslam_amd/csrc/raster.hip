@@ -2,239 +2,281 @@
 // Replaces the gsplat fork's `rasterize_to_pixels` (gslam/rasterization.py:325-339; 3-tuple return with n_touched).
 // Maths: SURVEY.md §9.3 / §9.4.
 //
-// Mapping (MI355X, wave64): one 256-thread workgroup per 16x16 tile = 4 wavefronts, each wavefront owns a
-// 16x4-pixel strip.  The tile's depth-sorted list is staged through LDS 256 records at a time (one coalesced
-// id load + one 48-byte record gather per thread); the compositing loop reads each record as an LDS broadcast
-// (3 x ds_read_b128, same address in all lanes -> conflict free).  Termination is voted per wavefront
-// (64-bit ballot) inside a batch and per workgroup between batches.  n_touched is counted with a wave ballot +
-// popcount into an LDS counter and flushed with one global atomic per staged Gaussian.  The backward replays the
-// list back to front, reduces each Gaussian's gradient over the 64 lanes with DPP row/bcast adds, merges the four
-// wavefronts in LDS and issues one record-shaped (48-byte contiguous) atomic add per (tile, Gaussian).
+// wave64-native mapping (v2).  A workgroup is still one 16x16 tile, but each of its four wavefronts owns an
+// 8x8-pixel quadrant and walks the tile's depth-sorted list in chunks of 64 entries with the LANES MAPPED TO
+// ENTRIES first:
+//   1. lane i loads entry i of the chunk (coalesced id load + one 48-byte record gather),
+//   2. lane i decides - exactly and conservatively - whether its Gaussian can reach alpha >= 1/255 anywhere in
+//      the wavefront's 8x8 quadrant (minimum of the conic quadratic over the quadrant rectangle),
+//   3. a 64-bit ballot compacts the survivors; the wavefront then visits only the set bits, broadcasting the
+//      surviving record from its lane's VGPRs to SGPRs with v_readlane (no LDS, no barrier, no wait),
+//   4. now LANES = PIXELS: the usual compositing step with scalar (SGPR) Gaussian operands.
+// Entries that cannot touch the quadrant cost ~1 instruction per 64 instead of a full loop trip, termination is
+// voted per wavefront, and the forward needs no LDS or barriers at all.  The backward keeps one LDS accumulator
+// row per staged entry so that the four quadrants merge before a single record-shaped (48 B contiguous) atomic
+// flush per (tile, Gaussian); per-Gaussian sums over the 64 lanes use DPP row/bcast adds.
+#include <stdlib.h>
+
 #include "gsx_common.h"
+
+#include "raster_v1.inc"
 
 namespace {
 
-constexpr int BLOCK = 256;
+constexpr int QUAD = 8;  // a wavefront renders an 8x8 pixel quadrant of the 16x16 tile
 
 template <int RS>
-__device__ __forceinline__ void stage_record(float *s_rec, int t, const float *__restrict__ rec, int g) {
+struct Rec {
+    float v[RS];
+};
+
+template <int RS>
+__device__ __forceinline__ Rec<RS> load_record(const float *__restrict__ rec, int g) {
+    Rec<RS> r;
     const float4 *src = reinterpret_cast<const float4 *>(rec + (int64_t)g * RS);
-    float4 *dst = reinterpret_cast<float4 *>(s_rec + t * RS);
 #pragma unroll
-    for (int k = 0; k < RS / 4; ++k) dst[k] = src[k];
+    for (int k = 0; k < RS / 4; ++k) {
+        const float4 q = src[k];
+        r.v[4 * k] = q.x; r.v[4 * k + 1] = q.y; r.v[4 * k + 2] = q.z; r.v[4 * k + 3] = q.w;
+    }
+    return r;
+}
+
+__device__ __forceinline__ float bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// Can this Gaussian reach alpha >= 1/255 at ANY point of the rectangle [x0,x1]x[y0,y1] (pixel-centre coords)?
+// alpha >= 1/255  <=>  sigma <= log(255*opac).  sigma is a convex quadratic (PD conic): its minimum over the
+// rectangle is 0 if the mean is inside, otherwise it lies on one of the four edges, where it is a clamped 1-D
+// parabola.  A small slack keeps the test conservative under fp32 rounding; anything uncertain is kept (the exact
+// per-pixel predicate runs afterwards), so results are identical to visiting every entry.
+__device__ __forceinline__ bool may_touch(float mx, float my, float a, float b, float c, float opac, float x0,
+                                          float y0, float x1, float y1) {
+    if (!(opac * 255.0f >= 1.0f)) return false;           // alpha < 1/255 everywhere (also NaN-safe)
+    if (!(a > 0.0f && c > 0.0f)) return true;               // not a PD conic: keep, let the exact test decide
+    const float tau = __logf(opac * 255.0f);
+    const float u0 = x0 - mx, u1 = x1 - mx, v0 = y0 - my, v1 = y1 - my;
+    if (u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f) return true;
+    const float inv_a = 1.0f / a, inv_c = 1.0f / c;
+    float smin;
+    {   // edges u = u0 / u = u1, v free in [v0,v1]
+        float v = fminf(fmaxf(-b * u0 * inv_c, v0), v1);
+        smin = 0.5f * (a * u0 * u0 + c * v * v) + b * u0 * v;
+        v = fminf(fmaxf(-b * u1 * inv_c, v0), v1);
+        smin = fminf(smin, 0.5f * (a * u1 * u1 + c * v * v) + b * u1 * v);
+    }
+    {   // edges v = v0 / v = v1, u free in [u0,u1]
+        float u = fminf(fmaxf(-b * v0 * inv_a, u0), u1);
+        smin = fminf(smin, 0.5f * (a * u * u + c * v0 * v0) + b * u * v0);
+        u = fminf(fmaxf(-b * v1 * inv_a, u0), u1);
+        smin = fminf(smin, 0.5f * (a * u * u + c * v1 * v1) + b * u * v1);
+    }
+    return !(smin > tau * 1.001f + 1e-3f);
+}
+
+struct Quad {
+    int tile, c, px, py, wave, lane;
+    bool inside;
+    float fx, fy, x0, y0, x1, y1;
+};
+
+__device__ __forceinline__ Quad make_quad(int tile_w, int tile_h, int W, int H) {
+    Quad q;
+    const int tiles_per_cam = tile_w * tile_h;
+    q.tile = blockIdx.x;
+    q.c = q.tile / tiles_per_cam;
+    const int tl = q.tile - q.c * tiles_per_cam;
+    const int ty = tl / tile_w, tx = tl - ty * tile_w;
+    q.wave = threadIdx.x >> 6;
+    q.lane = threadIdx.x & 63;
+    const int bx = tx * GSX_TILE + (q.wave & 1) * QUAD, by = ty * GSX_TILE + (q.wave >> 1) * QUAD;
+    q.px = bx + (q.lane & 7);
+    q.py = by + (q.lane >> 3);
+    q.inside = (q.px < W) && (q.py < H);
+    q.fx = (float)q.px + 0.5f;
+    q.fy = (float)q.py + 0.5f;
+    q.x0 = (float)bx + 0.5f; q.y0 = (float)by + 0.5f;
+    q.x1 = (float)(bx + QUAD - 1) + 0.5f; q.y1 = (float)(by + QUAD - 1) + 0.5f;
+    return q;
 }
 
 template <int CH, int RS>
-__global__ __launch_bounds__(BLOCK) void raster_fwd_kernel(const float *__restrict__ rec, const float *__restrict__ bg,
-                                                           const int32_t *__restrict__ offsets,
-                                                           const int32_t *__restrict__ flatten_ids, int64_t M, int W,
-                                                           int H, int tile_w, int tile_h, float vis_min_T,
-                                                           float *__restrict__ render, float *__restrict__ alphas,
-                                                           int32_t *__restrict__ last_ids,
-                                                           int32_t *__restrict__ n_touched) {
-    __shared__ __attribute__((aligned(16))) float s_rec[BLOCK * RS];
-    __shared__ int s_id[BLOCK];
-    __shared__ int s_cnt[BLOCK];
-
-    const int tiles_per_cam = tile_w * tile_h;
-    const int tile = blockIdx.x;
+__global__ __launch_bounds__(256) void raster_fwd_kernel(const float *__restrict__ rec, const float *__restrict__ bg,
+                                                         const int32_t *__restrict__ offsets,
+                                                         const int32_t *__restrict__ flatten_ids, int64_t M, int W,
+                                                         int H, int tile_w, int tile_h, float vis_min_T,
+                                                         float *__restrict__ render, float *__restrict__ alphas,
+                                                         int32_t *__restrict__ last_ids,
+                                                         int32_t *__restrict__ n_touched) {
+    const Quad q = make_quad(tile_w, tile_h, W, H);
     const int n_tiles_total = gridDim.x;
-    const int c = tile / tiles_per_cam;
-    const int tl = tile - c * tiles_per_cam;
-    const int ty = tl / tile_w, tx = tl - ty * tile_w;
-    const int t = threadIdx.x;
-    const int px = tx * GSX_TILE + (t & 15), py = ty * GSX_TILE + (t >> 4);
-    const bool inside = (px < W) && (py < H);
-    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-
-    const int start = offsets[tile];
-    const int end = (tile + 1 < n_tiles_total) ? offsets[tile + 1] : (int)M;
-    const int n_batches = (end - start + BLOCK - 1) / BLOCK;
+    const int start = offsets[q.tile];
+    const int end = (q.tile + 1 < n_tiles_total) ? offsets[q.tile + 1] : (int)M;
 
     float T = 1.0f;
     float pix[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) pix[k] = 0.f;
     int last = -1;
-    bool done = !inside;
+    bool done = !q.inside;
 
-    for (int b = 0; b < n_batches; ++b) {
-        // all four wavefronts finished -> stop staging (also protects the LDS buffers of the previous batch)
-        if (__syncthreads_and(done)) break;
-        const int batch_start = start + b * BLOCK;
-        const int bsize = min(BLOCK, end - batch_start);
-        if (t < bsize) {
-            const int g = flatten_ids[batch_start + t];
-            s_id[t] = g;
-            stage_record<RS>(s_rec, t, rec, g);
-        }
-        s_cnt[t] = 0;
-        __syncthreads();
-        for (int j = 0; j < bsize; ++j) {
-            if (__all(done)) break;  // wave-uniform
-            const float4 r0 = reinterpret_cast<const float4 *>(s_rec + j * RS)[0];
-            const float4 r1 = reinterpret_cast<const float4 *>(s_rec + j * RS)[1];
-            const float dx = r0.x - fx, dy = r0.y - fy;
-            const float sigma = 0.5f * (r0.z * dx * dx + r1.x * dy * dy) + r0.w * dx * dy;
-            const float alpha = fminf(GSX_ALPHA_MAX, r1.y * __expf(-sigma));
+    for (int base = start; base < end; base += 64) {
+        if (__all(done)) break;  // wave-uniform: every pixel of the quadrant is saturated
+        const int e = base + q.lane;
+        const bool have = e < end;
+        const int g = have ? flatten_ids[e] : 0;
+        Rec<RS> r = load_record<RS>(rec, have ? g : 0);
+        const bool maybe = have && may_touch(r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5], q.x0, q.y0, q.x1, q.y1);
+        unsigned long long mask = __ballot(maybe);
+        while (mask != 0ull) {
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            // LANES = PIXELS from here on; the Gaussian's record is broadcast into scalar registers
+            const float mx = bcast(r.v[0], j), my = bcast(r.v[1], j);
+            const float ca = bcast(r.v[2], j), cb = bcast(r.v[3], j), cc = bcast(r.v[4], j);
+            const float opac = bcast(r.v[5], j);
+            const float dx = mx - q.fx, dy = my - q.fy;
+            const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+            const float alpha = fminf(GSX_ALPHA_MAX, opac * __expf(-sigma));
             bool valid = !done && (sigma >= 0.0f) && (alpha >= GSX_ALPHA_MIN);
             const float nT = T * (1.0f - alpha);
             if (valid && nT <= GSX_T_MIN) { done = true; valid = false; }
-            bool touched = false;
-            if (valid) {
-                const float vis = alpha * T;
-                float col[6];
-                col[0] = r1.z; col[1] = r1.w;
-                if (RS > 8) {
-                    const float4 r2 = reinterpret_cast<const float4 *>(s_rec + j * RS)[RS > 8 ? 2 : 0];
-                    col[2] = r2.x; col[3] = r2.y; col[4] = r2.z; col[5] = r2.w;
-                }
-#pragma unroll
-                for (int k = 0; k < CH; ++k) pix[k] += col[k] * vis;
-                touched = nT > vis_min_T;
-                last = batch_start + j;
-                T = nT;
+            if (!__any(valid)) {
+                if (__all(done)) break;
+                continue;
             }
-            const unsigned long long m = __ballot(touched);
-            if (m != 0ull && (t & 63) == 0) atomicAdd(&s_cnt[j], __popcll(m));
-        }
-        __syncthreads();
-        if (t < bsize) {
-            const int cnt = s_cnt[t];
-            if (cnt > 0) atomicAdd(&n_touched[s_id[t]], cnt);
+            const float vis = valid ? alpha * T : 0.0f;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) pix[k] += bcast(r.v[6 + k], j) * vis;
+            const bool touched = valid && (nT > vis_min_T);
+            if (valid) { last = base + j; T = nT; }
+            const unsigned long long tm = __ballot(touched);
+            if (tm != 0ull && q.lane == 0) atomicAdd(&n_touched[__builtin_amdgcn_readlane(g, j)], __popcll(tm));
         }
     }
-    if (inside) {
-        const int64_t p = ((int64_t)c * H + py) * W + px;
+    if (q.inside) {
+        const int64_t p = ((int64_t)q.c * H + q.py) * W + q.px;
 #pragma unroll
-        for (int k = 0; k < CH; ++k) render[p * CH + k] = pix[k] + (bg ? T * bg[c * CH + k] : 0.f);
+        for (int k = 0; k < CH; ++k) render[p * CH + k] = pix[k] + (bg ? T * bg[q.c * CH + k] : 0.f);
         alphas[p] = 1.0f - T;
         last_ids[p] = last;
     }
 }
 
 template <int CH, int RS, bool ABS>
-__global__ __launch_bounds__(BLOCK) void raster_bwd_kernel(
+__global__ __launch_bounds__(256) void raster_bwd_kernel(
     const float *__restrict__ rec, const float *__restrict__ bg, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ flatten_ids, int64_t M, int W, int H, int tile_w, int tile_h,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_rec, float *__restrict__ v_abs) {
-    __shared__ __attribute__((aligned(16))) float s_rec[BLOCK * RS];
-    __shared__ __attribute__((aligned(16))) float s_grad[BLOCK * RS];
-    __shared__ float s_abs[ABS ? BLOCK * 2 : 2];
-    __shared__ int s_id[BLOCK];
-    __shared__ int s_wmax[BLOCK / GSX_WAVE];
     constexpr int NG = 6 + CH;  // gradient entries per record: xy(2) conic(3) opacity(1) colors(CH)
+    __shared__ __attribute__((aligned(16))) float s_grad[256 * RS];
+    __shared__ float s_abs[ABS ? 512 : 2];
+    __shared__ int s_id[256];
+    __shared__ int s_wmax[4];
 
-    const int tiles_per_cam = tile_w * tile_h;
-    const int tile = blockIdx.x;
-    const int c = tile / tiles_per_cam;
-    const int tl = tile - c * tiles_per_cam;
-    const int ty = tl / tile_w, tx = tl - ty * tile_w;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int px = tx * GSX_TILE + (t & 15), py = ty * GSX_TILE + (t >> 4);
-    const bool inside = (px < W) && (py < H);
-    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-    const int64_t p = ((int64_t)c * H + min(py, H - 1)) * W + min(px, W - 1);
-
-    const int start = offsets[tile];
-    const int last = inside ? last_ids[p] : -1;
-    // workgroup max of `last`
+    const Quad q = make_quad(tile_w, tile_h, W, H);
+    const int t = threadIdx.x;
+    const int64_t p = ((int64_t)q.c * H + min(q.py, H - 1)) * W + min(q.px, W - 1);
+    const int start = offsets[q.tile];
+    const int last = q.inside ? last_ids[p] : -1;
     int wmax = last;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
-    if (lane == 0) s_wmax[wave] = wmax;
+    if (q.lane == 0) s_wmax[q.wave] = wmax;
     __syncthreads();
-    int bmax = s_wmax[0];
-#pragma unroll
-    for (int w = 1; w < BLOCK / GSX_WAVE; ++w) bmax = max(bmax, s_wmax[w]);
-    if (bmax < start) return;  // nothing composited in this tile (uniform)
+    const int bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    if (bmax < start) return;  // nothing composited in this tile (uniform over the workgroup)
 
-    const float T_final = inside ? 1.0f - alphas[p] : 1.0f;
+    const float T_final = q.inside ? 1.0f - alphas[p] : 1.0f;
     float T = T_final;
     float vo[CH], buf[CH];
     float bg_dot = 0.f;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
-        vo[k] = inside ? v_render[p * CH + k] : 0.f;
+        vo[k] = q.inside ? v_render[p * CH + k] : 0.f;
         buf[k] = 0.f;
-        if (bg) bg_dot += bg[c * CH + k] * vo[k];
+        if (bg) bg_dot += bg[q.c * CH + k] * vo[k];
     }
-    const float va_out = inside ? v_alphas[p] : 0.f;
+    const float va_out = q.inside ? v_alphas[p] : 0.f;
 
     const int n = bmax - start + 1;
-    const int n_batches = (n + BLOCK - 1) / BLOCK;
+    const int n_batches = (n + 255) / 256;
     for (int b = n_batches - 1; b >= 0; --b) {
-        const int batch_start = start + b * BLOCK;
-        const int bsize = min(BLOCK, start + n - batch_start);
+        const int batch_start = start + b * 256;
+        const int bsize = min(256, start + n - batch_start);
+        __syncthreads();  // the previous batch's flush has finished reading s_grad / s_id
+        if (t < bsize) s_id[t] = flatten_ids[batch_start + t];
+#pragma unroll
+        for (int k = 0; k < RS; ++k) s_grad[k * 256 + t] = 0.f;
+        if (ABS) { s_abs[t] = 0.f; s_abs[256 + t] = 0.f; }
         __syncthreads();
-        if (t < bsize) {
-            const int g = flatten_ids[batch_start + t];
-            s_id[t] = g;
-            stage_record<RS>(s_rec, t, rec, g);
-        }
+        for (int sub = 3; sub >= 0; --sub) {
+            const int cbase = batch_start + sub * 64;
+            if (cbase >= batch_start + bsize || cbase > wmax) continue;  // wave-uniform
+            const int e = cbase + q.lane;
+            const bool have = (e < batch_start + bsize) && (e <= wmax);
+            const int g = have ? s_id[sub * 64 + q.lane] : 0;
+            Rec<RS> r = load_record<RS>(rec, g);
+            const bool maybe = have && may_touch(r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5], q.x0, q.y0, q.x1, q.y1);
+            unsigned long long mask = __ballot(maybe);
+            while (mask != 0ull) {
+                const int j = 63 - __clzll((long long)mask);  // back to front
+                mask &= ~(1ull << j);
+                const float mx = bcast(r.v[0], j), my = bcast(r.v[1], j);
+                const float a = bcast(r.v[2], j), bq = bcast(r.v[3], j), cq = bcast(r.v[4], j);
+                const float opac = bcast(r.v[5], j);
+                const float dx = mx - q.fx, dy = my - q.fy;
+                const float sigma = 0.5f * (a * dx * dx + cq * dy * dy) + bq * dx * dy;
+                const float vis = __expf(-sigma);
+                const float alpha = fminf(GSX_ALPHA_MAX, opac * vis);
+                const bool valid = (cbase + j <= last) && (sigma >= 0.0f) && (alpha >= GSX_ALPHA_MIN);
+                if (!__any(valid)) continue;
+                float gr[NG];
 #pragma unroll
-        for (int k = 0; k < RS; ++k) s_grad[k * BLOCK + t] = 0.f;  // zero the whole [BLOCK*RS] buffer, conflict-free
-        if (ABS) { s_abs[t] = 0.f; s_abs[BLOCK + t] = 0.f; }
-        __syncthreads();
-        for (int j = bsize - 1; j >= 0; --j) {
-            const int e = batch_start + j;
-            const float4 r0 = reinterpret_cast<const float4 *>(s_rec + j * RS)[0];
-            const float4 r1 = reinterpret_cast<const float4 *>(s_rec + j * RS)[1];
-            const float dx = r0.x - fx, dy = r0.y - fy;
-            const float a = r0.z, bq = r0.w, cq = r1.x, opac = r1.y;
-            const float sigma = 0.5f * (a * dx * dx + cq * dy * dy) + bq * dx * dy;
-            const float vis = __expf(-sigma);
-            const float alpha = fminf(GSX_ALPHA_MAX, opac * vis);
-            const bool valid = (e <= last) && (sigma >= 0.0f) && (alpha >= GSX_ALPHA_MIN);
-            if (!__any(valid)) continue;  // wave-uniform skip
-            float gr[NG];
+                for (int k = 0; k < NG; ++k) gr[k] = 0.f;
+                float gax = 0.f, gay = 0.f;
+                if (valid) {
+                    const float ra = 1.0f / (1.0f - alpha);
+                    T *= ra;
+                    const float fac = alpha * T;
+                    float v_alpha = 0.f;
 #pragma unroll
-            for (int k = 0; k < NG; ++k) gr[k] = 0.f;
-            float gax = 0.f, gay = 0.f;
-            if (valid) {
-                float col[6];
-                col[0] = r1.z; col[1] = r1.w;
-                if (RS > 8) {
-                    const float4 r2 = reinterpret_cast<const float4 *>(s_rec + j * RS)[RS > 8 ? 2 : 0];
-                    col[2] = r2.x; col[3] = r2.y; col[4] = r2.z; col[5] = r2.w;
+                    for (int k = 0; k < CH; ++k) {
+                        const float ck = bcast(r.v[6 + k], j);
+                        gr[6 + k] = fac * vo[k];
+                        v_alpha += (ck * T - buf[k] * ra) * vo[k];
+                        buf[k] += ck * fac;
+                    }
+                    v_alpha += T_final * ra * va_out;
+                    v_alpha -= T_final * ra * bg_dot;
+                    if (opac * vis <= GSX_ALPHA_MAX) {
+                        const float v_sigma = -opac * vis * v_alpha;
+                        gr[2] = 0.5f * v_sigma * dx * dx;
+                        gr[3] = v_sigma * dx * dy;
+                        gr[4] = 0.5f * v_sigma * dy * dy;
+                        gr[0] = v_sigma * (a * dx + bq * dy);
+                        gr[1] = v_sigma * (bq * dx + cq * dy);
+                        gr[5] = vis * v_alpha;
+                        if (ABS) { gax = fabsf(gr[0]); gay = fabsf(gr[1]); }
+                    }
                 }
-                const float ra = 1.0f / (1.0f - alpha);
-                T *= ra;
-                const float fac = alpha * T;
-                float v_alpha = 0.f;
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    gr[6 + k] = fac * vo[k];
-                    v_alpha += (col[k] * T - buf[k] * ra) * vo[k];
-                    buf[k] += col[k] * fac;
+                // 16-lane row sums of all NG entries, interleaved (DPP), then the four row leaders add into the
+                // entry's LDS accumulator row: one exec-mask change, NG ds_add_f32 with 4 active lanes each
+                const int slot = sub * 64 + j;
+                gsx_row16_sum<NG>(gr);
+                float ab[2] = {gax, gay};
+                if (ABS) gsx_row16_sum<2>(ab);
+                if ((q.lane & 15) == 15) {
+                    gsx_lds_fadd_row<NG>((unsigned)(uintptr_t)&s_grad[slot * RS], gr);
+                    if (ABS) { gsx_lds_fadd(&s_abs[2 * slot], ab[0]); gsx_lds_fadd(&s_abs[2 * slot + 1], ab[1]); }
                 }
-                v_alpha += T_final * ra * va_out;
-                v_alpha -= T_final * ra * bg_dot;
-                if (opac * vis <= GSX_ALPHA_MAX) {
-                    const float v_sigma = -opac * vis * v_alpha;
-                    gr[2] = 0.5f * v_sigma * dx * dx;
-                    gr[3] = v_sigma * dx * dy;
-                    gr[4] = 0.5f * v_sigma * dy * dy;
-                    gr[0] = v_sigma * (a * dx + bq * dy);
-                    gr[1] = v_sigma * (bq * dx + cq * dy);
-                    gr[5] = vis * v_alpha;
-                    if (ABS) { gax = fabsf(gr[0]); gay = fabsf(gr[1]); }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NG; ++k) {
-                const float tot = gsx_wave_sum(gr[k]);
-                if (lane == 0) atomicAdd(&s_grad[j * RS + k], tot);
-            }
-            if (ABS) {
-                const float tx_ = gsx_wave_sum(gax), ty_ = gsx_wave_sum(gay);
-                if (lane == 0) { atomicAdd(&s_abs[2 * j], tx_); atomicAdd(&s_abs[2 * j + 1], ty_); }
             }
         }
         __syncthreads();
         // record-shaped flush: consecutive lanes -> consecutive floats of one 48-byte record row
-        for (int i = t; i < bsize * RS; i += BLOCK) {
+        for (int i = t; i < bsize * RS; i += 256) {
             const int j = i / RS, k = i - j * RS;
             if (k < NG) {
                 const float v = s_grad[i];
@@ -242,12 +284,17 @@ __global__ __launch_bounds__(BLOCK) void raster_bwd_kernel(
             }
         }
         if (ABS) {
-            for (int i = t; i < bsize * 2; i += BLOCK) {
+            for (int i = t; i < bsize * 2; i += 256) {
                 const float v = s_abs[i];
                 if (v != 0.f) atomicAdd(&v_abs[(int64_t)s_id[i >> 1] * 2 + (i & 1)], v);
             }
         }
     }
+}
+
+bool use_v1() {
+    const char *e = getenv("GSX_RASTER_V1");
+    return e && e[0] == '1';
 }
 
 }  // namespace
@@ -263,10 +310,18 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
     const int64_t T = C * tile_w * tile_h;
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(ch, rs)                                                                                             \
-    hipLaunchKernelGGL((raster_fwd_kernel<ch, rs>), dim3((unsigned)T), dim3(BLOCK), 0, st, rec, backgrounds,      \
-                       offsets, flatten_ids, M, W, H, tile_w, tile_h, visibility_min_T, render, alphas, last_ids, \
-                       n_touched)
+    const bool v1 = use_v1();
+#define LAUNCH(ch, rs)                                                                                              \
+    do {                                                                                                            \
+        if (v1)                                                                                                     \
+            hipLaunchKernelGGL((raster_fwd_kernel_v1<ch, rs>), dim3((unsigned)T), dim3(256), 0, st, rec,           \
+                               backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, visibility_min_T,       \
+                               render, alphas, last_ids, n_touched);                                                \
+        else                                                                                                        \
+            hipLaunchKernelGGL((raster_fwd_kernel<ch, rs>), dim3((unsigned)T), dim3(256), 0, st, rec, backgrounds, \
+                               offsets, flatten_ids, M, W, H, tile_w, tile_h, visibility_min_T, render, alphas,    \
+                               last_ids, n_touched);                                                                \
+    } while (0)
     switch (CH) {
         case 1: LAUNCH(1, 8); break;
         case 2: LAUNCH(2, 8); break;
@@ -291,16 +346,17 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     GSX_CHECK_ARG(rec && flatten_ids && v_rec);
     const int64_t T = C * tile_w * tile_h;
     hipStream_t st = (hipStream_t)stream;
+    const bool v1 = use_v1();
+#define ARGS rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
-        if (v_abs)                                                                                                  \
-            hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, true>), dim3((unsigned)T), dim3(BLOCK), 0, st, rec,      \
-                               backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids,       \
-                               v_render, v_alphas, v_rec, v_abs);                                                   \
-        else                                                                                                        \
-            hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, false>), dim3((unsigned)T), dim3(BLOCK), 0, st, rec,     \
-                               backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids,       \
-                               v_render, v_alphas, v_rec, v_abs);                                                   \
+        if (v1) {                                                                                                   \
+            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS); \
+            else hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS);      \
+        } else {                                                                                                    \
+            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS);    \
+            else hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS);         \
+        }                                                                                                           \
     } while (0)
     switch (CH) {
         case 1: LAUNCH(1, 8); break;
@@ -311,6 +367,7 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
         default: gsx_set_error("gsx_raster_bwd: CH=%d unsupported (1..5)", CH); return GSX_E_UNSUPPORTED;
     }
 #undef LAUNCH
+#undef ARGS
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }
