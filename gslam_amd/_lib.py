@@ -22,7 +22,7 @@ PROTOTYPES = {
     "gsx_record_stride": (i32, [i32]),
     "gsx_read_i64": (i32, [vp, C.POINTER(i64), vp]),
     "gsx_project_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp,
-                              i32, i32, vp, vp, vp, vp, vp]),
+                              i32, i32, vp, vp, vp, vp, vp, vp]),
     "gsx_project_bwd_workspace_bytes": (i64, [i64, i64]),
     "gsx_project_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, vp, i64, vp, vp, i64, vp,
                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
@@ -41,6 +41,12 @@ PROTOTYPES = {
     "gsx_ssim_workspace_bytes": (i64, [i64, i32, i32, i32]),
     "gsx_ssim_fwd": (i32, [vp, vp, i64, i32, i32, i32, C.POINTER(i64), C.POINTER(i64), i32, vp, vp, vp, vp, vp, i64, vp]),
     "gsx_ssim_bwd": (i32, [vp, vp, i64, i32, i32, i32, C.POINTER(i64), C.POINTER(i64), i32, vp, vp, vp, vp, f32, vp, vp]),
+    "gsx_map_loss_workspace_bytes": (i64, [i64, i32, i32]),
+    "gsx_map_loss": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp, vp, i64, vp]),
+    "gsx_isotropic_workspace_bytes": (i64, [i64]),
+    "gsx_isotropic_loss": (i32, [vp, vp, i64, f32, vp, vp, vp, i64, vp]),
+    "gsx_combine_terms": (i32, [i32, C.POINTER(vp), C.POINTER(f32), C.POINTER(f32), f32, f32, vp, vp]),
+    "gsx_opacity_decay": (i32, [vp, vp, i64, i32, f32, vp]),
     "gsx_warp_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
     "gsx_warp_bwd_workspace_bytes": (i64, [i32, i32]),
     "gsx_warp_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),

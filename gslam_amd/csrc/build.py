@@ -22,6 +22,7 @@ SOURCES = {
     "isect.hip": ["-ffp-contract=off"],
     "raster.hip": [],
     "ssim.hip": [],
+    "loss.hip": [],
     "warp.hip": [],
     "misc.hip": [],
 }

@@ -1,0 +1,301 @@
+// loss.hip — the mapping / tracking loss block fused into single passes with analytic gradients.
+// Replaces the dozens of torch elementwise + reduction kernels of gslam/backend.py:273-318 (exposure affine,
+// active-NeRF photometric + 0.5 log^2 beta, edge_aware_tv of gslam/utils.py:136-161, isotropic regulariser) and of
+// gslam/frontend.py:113-138,632-646 (tracking loss), reading the render and the target once (~80 B/pixel) and
+// writing the gradient of the render once (20 B/pixel).  The loss is always followed by its backward in the
+// reference loops, so value and gradient are produced together; the autograd wrapper only scales by the upstream
+// gradient.  All reductions are wave64 DPP -> LDS -> one partial row per workgroup -> finishing kernel
+// (deterministic, no atomics).
+#include "gsx_common.h"
+
+namespace {
+
+constexpr int LB = 256;
+constexpr int NPART = 6;  // per-workgroup partials: S-term, log-beta term, tv, v_a, v_b, (spare)
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+struct LossArgs {
+    const float *render;   // [C,H,W,CH]
+    const float *alphas;   // [C,H,W]
+    const float *gt;       // [C,H,W,3]
+    const float *exposure; // [C,2] (a, b): rendered = rgb * exp(a) + b
+    const float *ssim_grad; // [C,3,H,W] planar, already scaled; nullable
+    float *v_render;       // [C,H,W,CH]
+    float *partials;       // [C][blocks_per_cam][NPART]
+    int H, W, CH, depth_index, beta_index;
+    int mode;              // 0: active-gs mapping (backend.py:277-283), 1: plain mse on un-exposed rgb (backend.py:285),
+                           // 2: active-nerf tracking (frontend.py:127: err^2 * beta^-2, no log term)
+    float w_photo;         // weight / (C*H*W) (mode 1: / (C*H*W*3))
+    float w_tv;            // weight of the edge-aware depth TV SUM (0 disables)
+    float mask_thresh;     // alphas > thresh (backend.py:301: 0.4)
+};
+
+__global__ __launch_bounds__(LB) void map_loss_kernel(LossArgs A) {
+    __shared__ float s_part[LB / GSX_WAVE][NPART];
+    const int c = blockIdx.y;
+    const int HW = A.H * A.W;
+    const int i = blockIdx.x * LB + threadIdx.x;
+    float part[NPART] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < HW) {
+        const int y = i / A.W, x = i - y * A.W;
+        const int64_t p = (int64_t)c * HW + i;
+        const int CH = A.CH;
+        const float *rp = A.render + p * CH;
+        const float r0 = rp[0], r1 = rp[1], r2 = rp[2];
+        const float ea = __expf(A.exposure[2 * c]), eb = A.exposure[2 * c + 1];
+        const float g0 = A.gt[p * 3], g1 = A.gt[p * 3 + 1], g2 = A.gt[p * 3 + 2];
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, vdepth = 0.f, vbeta = 0.f;
+        if (A.mode == 1) {
+            const float d0 = r0 - g0, d1 = r1 - g1, d2 = r2 - g2;
+            part[0] = d0 * d0 + d1 * d1 + d2 * d2;
+            v0 = 2.f * A.w_photo * d0; v1 = 2.f * A.w_photo * d1; v2 = 2.f * A.w_photo * d2;
+        } else {
+            const float d0 = r0 * ea + eb - g0, d1 = r1 * ea + eb - g1, d2 = r2 * ea + eb - g2;
+            const float S = d0 * d0 + d1 * d1 + d2 * d2;
+            const float beta = rp[A.beta_index];
+            const float ib = 1.0f / beta, ib2 = ib * ib;
+            if (A.mode == 0) {
+                const float lb = __logf(beta);
+                part[0] = 0.5f * S * ib2;
+                part[1] = 0.5f * lb * lb;
+                const float w = A.w_photo;
+                v0 = w * d0 * ea * ib2; v1 = w * d1 * ea * ib2; v2 = w * d2 * ea * ib2;
+                vbeta = w * (-S * ib2 * ib + lb * ib);
+                part[3] = w * (d0 * r0 + d1 * r1 + d2 * r2) * ea * ib2;
+                part[4] = w * (d0 + d1 + d2) * ib2;
+            } else {
+                part[0] = S * ib2;
+                const float w = 2.f * A.w_photo;
+                v0 = w * d0 * ea * ib2; v1 = w * d1 * ea * ib2; v2 = w * d2 * ea * ib2;
+                vbeta = -w * S * ib2 * ib;
+                part[3] = w * (d0 * r0 + d1 * r1 + d2 * r2) * ea * ib2;
+                part[4] = w * (d0 + d1 + d2) * ib2;
+            }
+        }
+        if (A.w_tv != 0.f && A.depth_index >= 0) {
+            // edge_aware_tv: pairs (p,right) and (p,down) are owned by p and masked by p's alpha; gather the four
+            // incident pairs so that every gradient entry is written exactly once.
+            const float dp = rp[A.depth_index];
+            const bool mp = A.alphas[p] > A.mask_thresh;
+            float tv = 0.f;
+            auto pair = [&](int64_t q_, bool owner_is_p, bool mask_owner) {
+                // returns contribution to (v_depth[p], v_rgb[p]) from the pair {p, q_}; owner = left/upper pixel
+                const float *rq = A.render + q_ * CH;
+                const float dq = rq[A.depth_index];
+                const float a0 = r0 - rq[0], a1 = r1 - rq[1], a2 = r2 - rq[2];   // p - q
+                const float gi = (fabsf(a0) + fabsf(a1) + fabsf(a2)) * (1.0f / 3.0f);
+                const float e = __expf(-gi);
+                const float gd = fabsf(dp - dq);
+                if (!mask_owner) return;
+                if (owner_is_p) tv += gd * e;
+                // d/d depth_p |dp - dq| = sgn(dp - dq) regardless of who owns the pair
+                vdepth += A.w_tv * sgn(dp - dq) * e;
+                const float k = -A.w_tv * gd * e * (1.0f / 3.0f);
+                v0 += k * sgn(a0); v1 += k * sgn(a1); v2 += k * sgn(a2);
+            };
+            if (x + 1 < A.W) pair(p + 1, true, mp);
+            if (x > 0) pair(p - 1, false, A.alphas[p - 1] > A.mask_thresh);
+            if (y + 1 < A.H) pair(p + A.W, true, mp);
+            if (y > 0) pair(p - A.W, false, A.alphas[p - A.W] > A.mask_thresh);
+            part[2] = tv;
+        }
+        if (A.ssim_grad) {
+            const int64_t o = (int64_t)c * 3 * HW + i;
+            v0 += A.ssim_grad[o]; v1 += A.ssim_grad[o + HW]; v2 += A.ssim_grad[o + 2 * HW];
+        }
+        float *vp = A.v_render + p * CH;
+        vp[0] = v0; vp[1] = v1; vp[2] = v2;
+        for (int k = 3; k < CH; ++k) vp[k] = (k == A.depth_index) ? vdepth : ((k == A.beta_index) ? vbeta : 0.f);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) {
+        const float tot = gsx_wave_sum(part[k]);
+        if (lane == 0) s_part[wave][k] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < NPART) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < LB / GSX_WAVE; ++w) acc += s_part[w][threadIdx.x];
+        A.partials[((int64_t)c * gridDim.x + blockIdx.x) * NPART + threadIdx.x] = acc;
+    }
+}
+
+// one workgroup: sums[0..2] = total S-term, log-beta term, tv over all cameras; v_exposure[c] = (v_a, v_b)
+__global__ __launch_bounds__(LB) void map_loss_finish_kernel(const float *__restrict__ partials, int C, int blocks_per_cam,
+                                                             float *__restrict__ sums, float *__restrict__ v_exposure) {
+    __shared__ float s_red[LB / GSX_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto block_sum = [&](float v) -> float {
+        const float tot = gsx_wave_sum(v);
+        __syncthreads();
+        if (lane == 0) s_red[wave] = tot;
+        __syncthreads();
+        return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    };
+    for (int k = 0; k < 3; ++k) {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < C * blocks_per_cam; i += LB) acc += partials[(int64_t)i * NPART + k];
+        const float tot = block_sum(acc);
+        if (threadIdx.x == 0) sums[k] = tot;
+    }
+    for (int c = 0; c < C; ++c)
+        for (int k = 3; k < 5; ++k) {
+            float acc = 0.f;
+            for (int i = threadIdx.x; i < blocks_per_cam; i += LB)
+                acc += partials[((int64_t)c * blocks_per_cam + i) * NPART + k];
+            const float tot = block_sum(acc);
+            if (threadIdx.x == 0 && v_exposure) v_exposure[2 * c + (k - 3)] = tot;
+        }
+}
+
+// isotropic regulariser (backend.py:287-296): sum over visible Gaussians of sum_j |exp(s_j) - exp(mean(s))|, mean detached
+__global__ __launch_bounds__(LB) void isotropic_kernel(const float *__restrict__ log_scales,
+                                                       const int32_t *__restrict__ vis_count, int64_t N, float weight,
+                                                       float *__restrict__ partials, float *__restrict__ v_log_scales) {
+    __shared__ float s_red[LB / GSX_WAVE];
+    const int64_t g = (int64_t)blockIdx.x * LB + threadIdx.x;
+    float term = 0.f;
+    if (g < N) {
+        const float s0 = log_scales[3 * g], s1 = log_scales[3 * g + 1], s2 = log_scales[3 * g + 2];
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (vis_count[g] > 0) {
+            const float m = expf((s0 + s1 + s2) * (1.0f / 3.0f));
+            const float e0 = expf(s0), e1 = expf(s1), e2 = expf(s2);
+            term = fabsf(e0 - m) + fabsf(e1 - m) + fabsf(e2 - m);
+            v0 = weight * sgn(e0 - m) * e0; v1 = weight * sgn(e1 - m) * e1; v2 = weight * sgn(e2 - m) * e2;
+        }
+        v_log_scales[3 * g] = v0; v_log_scales[3 * g + 1] = v1; v_log_scales[3 * g + 2] = v2;
+    }
+    const float tot = gsx_wave_sum(term);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(LB) void sum_partials_kernel(const float *__restrict__ partials, int64_t n,
+                                                          float *__restrict__ out) {
+    __shared__ float s_red[LB / GSX_WAVE];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += LB) acc += partials[i];
+    const float tot = gsx_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// out[0] = sum_k coef[k] * (*terms[k]) + bias ; out[1] = second linear form (the reference also reports the
+// photometric term on its own: backend.py:340-354)
+struct CombineArgs {
+    const float *t[6];
+    float c0[6], c1[6];
+    float bias0, bias1;
+    int n;
+};
+__global__ void combine_kernel(CombineArgs a, float *out) {
+    if (threadIdx.x != 0) return;
+    float o0 = a.bias0, o1 = a.bias1;
+    for (int k = 0; k < a.n; ++k) {
+        const float v = a.t[k][0];
+        o0 += a.c0[k] * v;
+        o1 += a.c1[k] * v;
+    }
+    out[0] = o0;
+    out[1] = o1;
+}
+
+__global__ __launch_bounds__(LB) void opacity_decay_kernel(float *__restrict__ logit_opac,
+                                                           const int32_t *__restrict__ vis_count, int64_t N,
+                                                           int min_count, float decay) {
+    const int64_t g = (int64_t)blockIdx.x * LB + threadIdx.x;
+    if (g < N && vis_count[g] > min_count) logit_opac[g] *= decay;
+}
+
+}  // namespace
+
+extern "C" int64_t gsx_map_loss_workspace_bytes(int64_t C, int H, int W) {
+    const int64_t blocks = ((int64_t)H * W + LB - 1) / LB;
+    return gsx_align256(C * blocks * NPART * (int64_t)sizeof(float)) + 256;
+}
+
+extern "C" int gsx_map_loss(const float *render, const float *alphas, const float *gt, const float *exposure, int64_t C,
+                            int H, int W, int CH, int depth_index, int beta_index, int mode, float w_photo, float w_tv,
+                            float mask_thresh, const float *ssim_grad, float *sums, float *v_render, float *v_exposure,
+                            void *workspace, int64_t workspace_bytes, void *stream) {
+    GSX_CHECK_ARG(render && gt && exposure && sums && v_render && C >= 1 && H > 0 && W > 0 && CH >= 3);
+    GSX_CHECK_ARG(mode >= 0 && mode <= 2);
+    GSX_CHECK_ARG(mode == 1 || (beta_index >= 3 && beta_index < CH));
+    GSX_CHECK_ARG(w_tv == 0.f || (alphas && depth_index >= 3 && depth_index < CH));
+    GSX_CHECK_ARG(C < 65536);
+    if (!workspace || workspace_bytes < gsx_map_loss_workspace_bytes(C, H, W)) {
+        gsx_set_error("gsx_map_loss: workspace too small");
+        return GSX_E_WORKSPACE;
+    }
+    LossArgs A;
+    A.render = render; A.alphas = alphas; A.gt = gt; A.exposure = exposure; A.ssim_grad = ssim_grad;
+    A.v_render = v_render; A.partials = (float *)workspace;
+    A.H = H; A.W = W; A.CH = CH; A.depth_index = depth_index; A.beta_index = beta_index; A.mode = mode;
+    A.w_photo = w_photo; A.w_tv = w_tv; A.mask_thresh = mask_thresh;
+    const unsigned blocks = (unsigned)(((int64_t)H * W + LB - 1) / LB);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(map_loss_kernel, dim3(blocks, (unsigned)C), dim3(LB), 0, st, A);
+    GSX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(map_loss_finish_kernel, dim3(1), dim3(LB), 0, st, (const float *)workspace, (int)C, (int)blocks,
+                       sums, v_exposure);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int64_t gsx_isotropic_workspace_bytes(int64_t N) {
+    return gsx_align256(((N + LB - 1) / LB) * (int64_t)sizeof(float)) + 256;
+}
+
+extern "C" int gsx_isotropic_loss(const float *log_scales, const int32_t *vis_count, int64_t N, float weight,
+                                  float *sum_out, float *v_log_scales, void *workspace, int64_t workspace_bytes,
+                                  void *stream) {
+    GSX_CHECK_ARG(log_scales && vis_count && sum_out && v_log_scales && N >= 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0) {
+        if (hipMemsetAsync(sum_out, 0, sizeof(float), st) != hipSuccess) return GSX_E_LAUNCH;
+        return GSX_OK;
+    }
+    if (!workspace || workspace_bytes < gsx_isotropic_workspace_bytes(N)) {
+        gsx_set_error("gsx_isotropic_loss: workspace too small");
+        return GSX_E_WORKSPACE;
+    }
+    const unsigned blocks = (unsigned)((N + LB - 1) / LB);
+    hipLaunchKernelGGL(isotropic_kernel, dim3(blocks), dim3(LB), 0, st, log_scales, vis_count, N, weight,
+                       (float *)workspace, v_log_scales);
+    GSX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(LB), 0, st, (const float *)workspace, (int64_t)blocks, sum_out);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_combine_terms(int n, const float *const *terms, const float *coef0, const float *coef1, float bias0,
+                                 float bias1, float *out2, void *stream) {
+    GSX_CHECK_ARG(n >= 1 && n <= 6 && terms && coef0 && coef1 && out2);
+    CombineArgs a;
+    a.n = n; a.bias0 = bias0; a.bias1 = bias1;
+    for (int k = 0; k < 6; ++k) {
+        a.t[k] = k < n ? terms[k] : nullptr;
+        a.c0[k] = k < n ? coef0[k] : 0.f;
+        a.c1[k] = k < n ? coef1[k] : 0.f;
+        if (k < n) GSX_CHECK_ARG(terms[k] != nullptr);
+    }
+    hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out2);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_opacity_decay(float *logit_opacities, const int32_t *vis_count, int64_t N, int min_count,
+                                 float decay, void *stream) {
+    GSX_CHECK_ARG(logit_opacities && vis_count && N >= 0);
+    if (N == 0) return GSX_OK;
+    hipLaunchKernelGGL(opacity_decay_kernel, dim3((unsigned)((N + LB - 1) / LB)), dim3(LB), 0, (hipStream_t)stream,
+                       logit_opacities, vis_count, N, min_count, decay);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}

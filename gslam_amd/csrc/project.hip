@@ -173,9 +173,11 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     float near_p, float far_p, float radius_clip, int flags, int32_t *__restrict__ radii,
     float *__restrict__ means2d, float *__restrict__ depths, float *__restrict__ conics, float *__restrict__ comps,
     int32_t *__restrict__ tiles_per_gauss, int tile_w, int tile_h, const float *__restrict__ logit_opacities,
-    const float *__restrict__ logit_colors, const float *__restrict__ log_unc, float *__restrict__ rec) {
+    const float *__restrict__ logit_colors, const float *__restrict__ log_unc, float *__restrict__ rec,
+    int32_t *__restrict__ vis_count) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
+    int n_vis = 0;
     const float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
     const float q[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
     float s[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             }
         }
         radii[idx] = radius_i;
+        n_vis += radius_i > 0 ? 1 : 0;
         means2d[2 * idx] = mx; means2d[2 * idx + 1] = my;
         depths[idx] = depth;
         conics[3 * idx] = con0; conics[3 * idx + 1] = con1; conics[3 * idx + 2] = con2;
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             reinterpret_cast<float4 *>(r)[2] = c4;
         }
     }
+    if (vis_count) vis_count[g] = n_vis;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -508,7 +512,7 @@ extern "C" int gsx_project_fwd(const float *means, const float *quats, const flo
                                float far_plane, float radius_clip, int flags, int32_t *radii, float *means2d,
                                float *depths, float *conics, float *comps, int32_t *tiles_per_gauss, int tile_w,
                                int tile_h, const float *logit_opacities, const float *logit_colors,
-                               const float *log_uncertainties, float *rec, void *stream) {
+                               const float *log_uncertainties, float *rec, int32_t *vis_count, void *stream) {
     GSX_CHECK_ARG(N >= 0 && C >= 1 && W > 0 && H > 0);
     GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && radii && means2d && depths && conics);
     if (rec) {
@@ -524,12 +528,12 @@ extern "C" int gsx_project_fwd(const float *means, const float *quats, const flo
         hipLaunchKernelGGL((project_fwd_kernel<12>), dim3(blocks), dim3(threads), 0, st, means, quats, scales,
                            viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, radius_clip, flags, radii,
                            means2d, depths, conics, comps, tiles_per_gauss, tile_w, tile_h, logit_opacities,
-                           logit_colors, log_uncertainties, rec);
+                           logit_colors, log_uncertainties, rec, vis_count);
     else
         hipLaunchKernelGGL((project_fwd_kernel<0>), dim3(blocks), dim3(threads), 0, st, means, quats, scales,
                            viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, radius_clip, flags, radii,
                            means2d, depths, conics, comps, tiles_per_gauss, tile_w, tile_h, logit_opacities,
-                           logit_colors, log_uncertainties, rec);
+                           logit_colors, log_uncertainties, rec, vis_count);
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }

@@ -1,0 +1,123 @@
+"""Fused loss blocks on libgsx.so: value + analytic gradient in one pass over the render (csrc/loss.hip).
+
+``fused_mapping_loss`` computes exactly what ``mapping_loss`` (gslam/backend.py:273-318) computes with ~60 torch
+kernels: exposure affine, active-NeRF photometric term + 0.5 log^2(beta), 1 - fused_ssim('valid') on the un-exposed
+rgb, the isotropic regulariser and the edge-aware depth TV, and hands autograd a ready gradient for the render tensor,
+the exposure parameters and the log-scales.  ``fused_tracking_loss`` is the active-nerf tracking loss of
+gslam/frontend.py:113-138,632-646.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from ._lib import check, lib, ptr, stream_ptr
+from .ops import workspace
+from .ssim import _strides
+
+
+class _FusedMappingLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo, w_ssim,
+                w_iso, w_tv, mode):
+        """returns (total, photometric) as 0-dim tensors.
+        total = w_photo * photometric + w_ssim * (1 - ssim) + w_iso * isotropic + w_tv * tv"""
+        render, gt = render.contiguous(), gt.contiguous()
+        exposure = exposure.contiguous()
+        Cn, H, W, CH = render.shape
+        dev = render.device
+        st = stream_ptr(dev)
+        n_px = Cn * H * W
+        sums = torch.empty(3, dtype=torch.float32, device=dev)
+        ssim_sum = torch.empty(1, dtype=torch.float32, device=dev)
+        iso_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        v_render = torch.empty_like(render)
+        v_exposure = torch.empty_like(exposure)
+        ssim_grad = None
+        numel_ssim = Cn * 3 * (H - 10) * (W - 10)
+        if w_ssim != 0.0:
+            # fused_ssim(outputs.rgbs NCHW-view, gt NCHW-view, 'valid') straight on the NHWC buffers (backend.py:303-307)
+            s_r = (C.c_int64 * 4)(H * W * CH, 1, W * CH, CH)
+            s_g = (C.c_int64 * 4)(H * W * 3, 1, W * 3, 3)
+            dm = torch.empty(3, Cn, 3, H, W, dtype=torch.float32, device=dev)
+            ws = workspace(lib.gsx_ssim_workspace_bytes(Cn, 3, H, W), dev, "ssim")
+            check(lib.gsx_ssim_fwd(ptr(render), ptr(gt), Cn, 3, H, W, s_r, s_g, 5, ptr(ssim_sum), ptr(dm[0]), ptr(dm[1]),
+                                   ptr(dm[2]), ptr(ws), ws.numel(), st), "gsx_ssim_fwd")
+            ssim_grad = torch.empty(Cn, 3, H, W, dtype=torch.float32, device=dev)
+            one = _ones(dev)
+            check(lib.gsx_ssim_bwd(ptr(render), ptr(gt), Cn, 3, H, W, s_r, s_g, 5, ptr(dm[0]), ptr(dm[1]), ptr(dm[2]),
+                                   ptr(one), -w_ssim / numel_ssim, ptr(ssim_grad), st), "gsx_ssim_bwd")
+        else:
+            ssim_sum.zero_()
+        denom = n_px * (3 if mode == 1 else 1)
+        ws = workspace(lib.gsx_map_loss_workspace_bytes(Cn, H, W), dev, "map_loss")
+        check(lib.gsx_map_loss(ptr(render), ptr(alphas.contiguous()) if alphas is not None else None, ptr(gt),
+                               ptr(exposure), Cn, H, W, CH, depth_index, beta_index, mode, w_photo / denom, w_tv, 0.4,
+                               ptr(ssim_grad), ptr(sums), ptr(v_render), ptr(v_exposure), ptr(ws), ws.numel(), st),
+              "gsx_map_loss")
+        v_scales = None
+        if w_iso != 0.0 and log_scales is not None:
+            log_scales = log_scales.contiguous()
+            v_scales = torch.empty_like(log_scales)
+            N = log_scales.shape[0]
+            ws = workspace(lib.gsx_isotropic_workspace_bytes(N), dev, "iso")
+            check(lib.gsx_isotropic_loss(ptr(log_scales), ptr(vis_count.contiguous()), N, w_iso, ptr(iso_sum),
+                                         ptr(v_scales), ptr(ws), ws.numel(), st), "gsx_isotropic_loss")
+        # total / photometric from the raw sums, on device
+        out2 = torch.empty(2, dtype=torch.float32, device=dev)
+        terms = (C.c_void_p * 5)(sums[0:1].data_ptr(), sums[1:2].data_ptr(), sums[2:3].data_ptr(), ssim_sum.data_ptr(),
+                                 iso_sum.data_ptr())
+        pm = 1.0 / denom
+        c0 = (C.c_float * 5)(w_photo * pm, w_photo * pm, w_tv, -w_ssim / numel_ssim, w_iso)
+        c1 = (C.c_float * 5)(pm, pm, 0.0, 0.0, 0.0)
+        check(lib.gsx_combine_terms(5, terms, c0, c1, w_ssim, 0.0, ptr(out2), st), "gsx_combine_terms")
+        ctx.save_for_backward(v_render, v_exposure, v_scales)
+        total, photo = out2[0].clone(), out2[1].clone()
+        ctx.mark_non_differentiable(photo)
+        return total, photo
+
+    @staticmethod
+    def backward(ctx, g_total, _g_photo):
+        v_render, v_exposure, v_scales = ctx.saved_tensors
+        return (v_render * g_total, None, None, v_exposure * g_total, None if v_scales is None else v_scales * g_total,
+                None, None, None, None, None, None, None, None)
+
+
+_ONES: dict = {}
+
+
+def _ones(dev) -> Tensor:
+    t = _ONES.get(dev)
+    if t is None:
+        t = torch.ones(1, dtype=torch.float32, device=dev)
+        _ONES[dev] = t
+    return t
+
+
+def fused_mapping_loss(outputs, gt_imgs: Tensor, exposure_params: Tensor, log_scales: Tensor, *, ssim_weight: float,
+                       iso_weight: float, tv_weight: float, active_gs: bool = True, shard: float = 1.0,
+                       iso_scale: float = 1.0, vis_count: Optional[Tensor] = None):
+    """(total, photometric) of gslam/backend.py:273-318 for a RasterizationOutput produced by
+    gslam_amd.rasterization (needs its private un-split render).  ``shard`` = C_local / C_window for keyframe-sharded
+    BA, ``iso_scale`` = 1 / world_size (SURVEY.md §8e loss-scaling rules)."""
+    render = outputs._render
+    if vis_count is None:
+        vis_count = outputs._vis_count
+    return _FusedMappingLoss.apply(render, outputs.alphas, gt_imgs, exposure_params, log_scales, vis_count,
+                                   -1 if outputs._depth_index is None else outputs._depth_index,
+                                   -1 if outputs._betas_index is None else outputs._betas_index,
+                                   shard * (1.0 - ssim_weight), shard * ssim_weight, iso_scale * iso_weight, tv_weight,
+                                   0 if active_gs else 1)
+
+
+def fused_tracking_loss(outputs, gt_img: Tensor, exposure_params: Tensor):
+    """active-nerf tracking loss of gslam/frontend.py:127 with the exposure affine of :632-636, C = 1."""
+    render = outputs._render
+    total, _ = _FusedMappingLoss.apply(render, None, gt_img[None] if gt_img.dim() == 3 else gt_img,
+                                       exposure_params.reshape(1, 2), None, None,
+                                       -1 if outputs._depth_index is None else outputs._depth_index,
+                                       outputs._betas_index, 1.0, 0.0, 0.0, 0.0, 2)
+    return total

@@ -14,6 +14,8 @@ from typing import List, Optional
 import torch
 
 from . import dist as gdist
+from ._lib import check, lib, ptr, stream_ptr
+from .losses import fused_mapping_loss
 from .map import GaussianSplattingData
 from .optim import FusedAdam
 from .primitives import Frame
@@ -110,9 +112,10 @@ class MapOptimizers:
 class BundleAdjuster:
     """One object per process/GPU.  ``step(window)`` is one iteration of the loop at backend.py:260-359."""
 
-    def __init__(self, splats: GaussianSplattingData, conf: Optional[MapConfig] = None):
+    def __init__(self, splats: GaussianSplattingData, conf: Optional[MapConfig] = None, fused_loss: bool = True):
         self.splats = splats
         self.conf = conf or MapConfig()
+        self.fused_loss = fused_loss
         self.optimizers = MapOptimizers(splats, self.conf)
         self.shard = gdist.KeyframeShard()
         self.bucket = gdist.GradBucket(splats) if self.shard.world_size > 1 else None
@@ -134,12 +137,19 @@ class BundleAdjuster:
         gt_imgs = create_batch(mine, lambda f: f.img)
         exposure = create_batch(mine, lambda f: f.exposure_params)
         outputs = self.splats(cameras, poses, render_depth=True)
-        vis_count = (outputs.radii > 0).sum(dim=0).to(torch.int32)
+        vis_count = outputs._vis_count                                  # = (radii > 0).sum(0), from K1
         if self.shard.world_size > 1:
-            vis_count = self.shard.all_reduce_sum(vis_count)
-        total, photometric = mapping_loss(self.splats, outputs, gt_imgs, exposure, conf, regularize,
-                                          c_total=len(window), visible_gaussians=vis_count > 0,
-                                          iso_scale=1.0 / self.shard.world_size)
+            vis_count = self.shard.all_reduce_sum(vis_count.clone())
+        if self.fused_loss:
+            total, photometric = fused_mapping_loss(
+                outputs, gt_imgs, exposure, self.splats.scales, ssim_weight=conf.ssim_weight,
+                iso_weight=conf.isotropic_regularization_weight,
+                tv_weight=conf.depth_regularization_weight if regularize else 0.0, active_gs=conf.active_gs,
+                shard=len(mine) / float(len(window)), iso_scale=1.0 / self.shard.world_size, vis_count=vis_count)
+        else:
+            total, photometric = mapping_loss(self.splats, outputs, gt_imgs, exposure, conf, regularize,
+                                              c_total=len(window), visible_gaussians=vis_count > 0,
+                                              iso_scale=1.0 / self.shard.world_size)
         outputs.means2d.retain_grad()                                   # backend.py:326
         total.backward()
         if self.bucket is not None:
@@ -147,7 +157,9 @@ class BundleAdjuster:
         self.optimizers.step()
         if decay_opacity:
             with torch.no_grad():                                       # backend.py:356-359
-                self.splats.opacities.data.mul_(torch.where(vis_count > 1, conf.opacity_decay, 1.0))
+                op = self.splats.opacities
+                check(lib.gsx_opacity_decay(ptr(op.data), ptr(vis_count), op.shape[0], 1, conf.opacity_decay,
+                                            stream_ptr(op.device)), "gsx_opacity_decay")
         self.last_outputs = outputs
         return total.detach(), photometric.detach()
 

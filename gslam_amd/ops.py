@@ -59,7 +59,7 @@ class _Projection(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, viewmats, Ks, logit_opac, logit_colors, log_unc, width, height, eps2d,
-                near_plane, far_plane, radius_clip, calc_comp, flags, want_rec, want_tiles):
+                near_plane, far_plane, radius_clip, calc_comp, flags, want_rec, want_tiles, want_vis=False):
         means, quats, scales = _f32c(means, "means"), _f32c(quats, "quats"), _f32c(scales, "scales")
         viewmats, Ks = _f32c(viewmats, "viewmats"), _f32c(Ks, "Ks")
         N, Cn = means.shape[0], viewmats.shape[0]
@@ -71,6 +71,7 @@ class _Projection(torch.autograd.Function):
         comps = torch.empty(Cn, N, dtype=torch.float32, device=dev) if calc_comp else None
         tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
         tiles = torch.empty(Cn, N, dtype=torch.int32, device=dev) if want_tiles else None
+        vis = torch.empty(N, dtype=torch.int32, device=dev) if want_vis else None
         rec = None
         if want_rec:
             logit_opac, logit_colors = _f32c(logit_opac, "logit_opacities"), _f32c(logit_colors, "logit_colors")
@@ -80,7 +81,7 @@ class _Projection(torch.autograd.Function):
         check(lib.gsx_project_fwd(ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), N, Cn, width, height,
                                   eps2d, near_plane, far_plane, radius_clip, flags, ptr(radii), ptr(means2d),
                                   ptr(depths), ptr(conics), ptr(comps), ptr(tiles), tile_w, tile_h, ptr(logit_opac),
-                                  ptr(logit_colors), ptr(log_unc), ptr(rec), stream_ptr(dev)), "gsx_project_fwd")
+                                  ptr(logit_colors), ptr(log_unc), ptr(rec), ptr(vis), stream_ptr(dev)), "gsx_project_fwd")
         ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii,
                               logit_opac if want_rec else None, logit_colors if want_rec else None,
                               log_unc if want_rec else None)
@@ -88,10 +89,12 @@ class _Projection(torch.autograd.Function):
         ctx.mark_non_differentiable(radii)
         if tiles is not None:
             ctx.mark_non_differentiable(tiles)
-        return radii, means2d, depths, conics, comps, rec, tiles
+        if vis is not None:
+            ctx.mark_non_differentiable(vis)
+        return radii, means2d, depths, conics, comps, rec, tiles, vis
 
     @staticmethod
-    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, v_rec, _v_tiles):
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, v_rec, _v_tiles, _v_vis):
         means, quats, scales, viewmats, Ks, radii, logit_opac, logit_colors, log_unc = ctx.saved_tensors
         width, height, eps2d, near_plane, far_plane, flags, want_rec, calc_comp = ctx.cfg
         N, Cn = means.shape[0], viewmats.shape[0]
@@ -132,7 +135,7 @@ class _Projection(torch.autograd.Function):
                                   ptr(logit_colors), ptr(log_unc), ptr(v_rec) if want_rec else None, ptr(v_means),
                                   ptr(v_quats), ptr(v_scales), ptr(v_view), ptr(v_lo), ptr(v_lc), ptr(v_lu), ptr(ws),
                                   ws.numel(), stream_ptr(dev)), "gsx_project_bwd")
-        return (v_means, v_quats, v_scales, v_view, None, v_lo, v_lc, v_lu) + (None,) * 10
+        return (v_means, v_quats, v_scales, v_view, None, v_lo, v_lc, v_lu) + (None,) * 11
 
 
 def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optional[Tensor], scales: Optional[Tensor],
@@ -151,7 +154,7 @@ def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optio
         raise NotImplementedError("only the pinhole camera model is on the gslam hot path")
     if sparse_grad:
         raise NotImplementedError("sparse_grad is never enabled by the reference (rasterization.py:62)")
-    radii, means2d, depths, conics, comps, _, _ = _Projection.apply(
+    radii, means2d, depths, conics, comps, _, _, _ = _Projection.apply(
         means, quats, scales, viewmats, Ks, None, None, None, int(width), int(height), float(eps2d),
         float(near_plane), float(far_plane), float(radius_clip), bool(calc_compensations), 0, False, False)
     if not packed:

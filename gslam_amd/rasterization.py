@@ -113,9 +113,9 @@ def rasterization(
         betas_index = ch
         ch += 1
 
-    radii, means2d, depths, conics, _comps, rec, tiles_per_gauss = ops._Projection.apply(
+    radii, means2d, depths, conics, _comps, rec, tiles_per_gauss, vis_count = ops._Projection.apply(
         means, quats, log_scales, viewmats, Ks, logit_opacities, logit_colors, log_uncertainties, int(width),
-        int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), False, flags, True, True)
+        int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), False, flags, True, True, True)
 
     # backgrounds: [C,3] + 0 for depth + e^1 for beta (rasterization.py:236-239,251-255)
     bg = None
@@ -151,6 +151,8 @@ def rasterization(
             out.depthmaps = out.depthmaps / alphas[..., 0].clamp(min=1e-10)
     if betas_index is not None:
         out.betas = render[..., betas_index]
+    # private extras for the fused loss (gslam_amd.losses): the un-split render and per-Gaussian visibility counts
+    out._render, out._depth_index, out._betas_index, out._vis_count = render, depth_index, betas_index, vis_count
     return out
 
 

@@ -66,7 +66,8 @@ int gsx_project_fwd(const float *means, const float *quats, const float *scales,
                     float far_plane, float radius_clip, int flags, int32_t *radii, float *means2d, float *depths,
                     float *conics, float *comps, int32_t *tiles_per_gauss, int tile_w, int tile_h,
                     const float *logit_opacities, const float *logit_colors, const float *log_uncertainties,
-                    float *rec, void *stream);
+                    float *rec, int32_t *vis_count /*[N] nullable: number of cameras with radii>0 (backend.py:287,357)*/,
+                    void *stream);
 
 /* ---- K2: projection bwd (autograd of K1; pose gradient used at gslam/frontend.py:627-646, backend.py:665-670) --
  * v_means2d / v_conics are read with a row stride in floats (2 / 3 when dense, the record stride when they alias
@@ -133,7 +134,7 @@ int gsx_sh_bwd(int degree, const float *dirs, const float *coeffs, const int32_t
                int64_t N, int64_t C, int Kc, float *v_coeffs /*[N,Kc,3] overwritten*/, float *v_dirs /*[C,N,3] nullable*/,
                void *stream);
 
-/* ---- K11/K12: fused_ssim (gslam/backend.py:303-307).  img strides in floats: (sB,sC,sH,sW) ------------------------
+/* ---- K11/K12: fused_ssim (gslam/backend.py:303-307).  strides: HOST int64[4] in floats (sB,sC,sH,sW) ------------------------
  * fwd: out_sum[0] = sum of the SSIM map over the crop (crop = 5 for 'valid', 0 for 'same'); the mean is
  * out_sum/(B*CH*(H-2crop)*(W-2crop)).  dm_* (nullable when train=0): three [B,CH,H,W] planar maps for the bwd.    */
 int64_t gsx_ssim_workspace_bytes(int64_t B, int CH, int H, int W);
@@ -145,6 +146,32 @@ int gsx_ssim_fwd(const float *img1, const float *img2, int64_t B, int CH, int H,
 int gsx_ssim_bwd(const float *img1, const float *img2, int64_t B, int CH, int H, int W, const int64_t *strides1,
                  const int64_t *strides2, int crop, const float *dm_dmu1, const float *dm_dsigma1_sq,
                  const float *dm_dsigma12, const float *scale, float scale_mul, float *dL_dimg1, void *stream);
+
+/* ---- fused loss block (gslam/backend.py:273-318 mapping; gslam/frontend.py:113-138 tracking) -----------------------
+ * One pass over the render: value partial sums AND the analytic gradient w.r.t. the render / exposure.
+ *  mode 0: active-gs mapping loss   sum_px [ S/(2 b^2) + 0.5 log^2 b ],  S = sum_k (rgb_k e^a + b_c - gt_k)^2
+ *  mode 1: plain mse on the un-exposed rgb (backend.py:285)
+ *  mode 2: active-nerf tracking     sum_px S / b^2                        (frontend.py:127)
+ * w_photo multiplies the per-pixel photometric gradient (caller folds weight / (C*H*W) into it); w_tv multiplies the
+ * edge-aware depth TV SUM of gslam/utils.py:136-161 (mask = alphas > mask_thresh, owned by the left / upper pixel).
+ * ssim_grad (nullable, planar [C,3,H,W], already scaled) is added to the rgb gradient.
+ * out: sums[0..2] = raw sums of (photometric term, 0.5 log^2 beta term, tv); v_render [C,H,W,CH]; v_exposure [C,2]. */
+int64_t gsx_map_loss_workspace_bytes(int64_t C, int H, int W);
+int gsx_map_loss(const float *render, const float *alphas, const float *gt, const float *exposure, int64_t C, int H,
+                 int W, int CH, int depth_index, int beta_index, int mode, float w_photo, float w_tv,
+                 float mask_thresh, const float *ssim_grad, float *sums, float *v_render, float *v_exposure,
+                 void *workspace, int64_t workspace_bytes, void *stream);
+/* isotropic regulariser (backend.py:287-296): sum_out[0] = sum over visible g of sum_j |exp(s_j) - exp(mean s)|;
+ * v_log_scales [N,3] = weight * d/ds (mean detached), zero rows for invisible Gaussians. */
+int64_t gsx_isotropic_workspace_bytes(int64_t N);
+int gsx_isotropic_loss(const float *log_scales, const int32_t *vis_count, int64_t N, float weight, float *sum_out,
+                       float *v_log_scales, void *workspace, int64_t workspace_bytes, void *stream);
+/* out2[i] = bias_i + sum_k coef_i[k] * terms[k][0]  (device scalars in, device scalars out; host arrays of pointers) */
+int gsx_combine_terms(int n, const float *const *terms, const float *coef0, const float *coef1, float bias0,
+                      float bias1, float *out2, void *stream);
+/* logit_opacities[g] *= decay where vis_count[g] > min_count (backend.py:356-359) */
+int gsx_opacity_decay(float *logit_opacities, const int32_t *vis_count, int64_t N, int min_count, float decay,
+                      void *stream);
 
 /* ---- Warp (gslam/warp.py:35-82).  T = f1_pose @ inv(f2_pose) [4,4], K, Kinv [3,3] device pointers ---------------- */
 int gsx_warp_fwd(const float *T, const float *K, const float *Kinv, const float *c1 /*[H,W,3]*/,

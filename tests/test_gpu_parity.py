@@ -418,3 +418,78 @@ def test_adam_matches_torch_and_oracle(dev, oracle32):
     for p, q, (cp, _, _) in zip(ours, ref, cpu):
         assert (p - q).abs().max() < 1e-6
         assert np.abs(_np(p) - cp).max() < 1e-6
+
+
+@pytest.mark.parametrize("regularize", [True, False])
+def test_fused_mapping_loss_matches_reference_formulation(dev, regularize):
+    """csrc/loss.hip (one pass, analytic gradient) vs the reference's own torch formulation of
+    gslam/backend.py:273-318 (gslam_amd.mapping.mapping_loss) - values and every gradient."""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.mapping import MapConfig, mapping_loss
+    from gslam_amd.losses import fused_mapping_loss
+    from gslam_amd.primitives import Camera, PoseZhou
+    from gslam_amd.synthetic import make_cameras, make_scene
+    n, c, W, H = 3000, 2, 200, 152
+    sc = make_scene(n, 21)
+    sc["scales"] = sc["scales"] + 0.6
+    viewmats, Ks = make_cameras(c, W, H)
+    g = torch.Generator().manual_seed(2)
+    gt = torch.rand(c, H, W, 3, generator=g).to(dev)
+    conf = MapConfig()
+    res = []
+    for fused in (False, True):
+        splats = GaussianSplattingData.from_dict(sc, dev)
+        cams = [Camera(Ks[i].to(dev), H, W) for i in range(c)]
+        poses = [PoseZhou(viewmats[i].to(dev)).to(dev) for i in range(c)]
+        exposure = torch.tensor([[0.1, -0.05], [-0.2, 0.03]], device=dev).requires_grad_(True)
+        out = splats(cams, poses, render_depth=True)
+        if fused:
+            total, pm = fused_mapping_loss(out, gt, exposure, splats.scales, ssim_weight=conf.ssim_weight,
+                                           iso_weight=conf.isotropic_regularization_weight * 50,
+                                           tv_weight=(conf.depth_regularization_weight * 1e3) if regularize else 0.0)
+        else:
+            conf2 = MapConfig(isotropic_regularization_weight=conf.isotropic_regularization_weight * 50,
+                              depth_regularization_weight=conf.depth_regularization_weight * 1e3)
+            total, pm = mapping_loss(splats, out, gt, exposure, conf2, regularize)
+        total.backward()
+        grads = {k: getattr(splats, k).grad.clone() for k in ("means", "quats", "scales", "opacities", "colors",
+                                                              "log_uncertainties")}
+        grads["exposure"] = exposure.grad.clone()
+        grads["dR"] = torch.stack([p.dR.grad for p in poses])
+        grads["dt"] = torch.stack([p.dt.grad for p in poses])
+        res.append((float(total), float(pm), grads))
+    (t0, p0, g0), (t1, p1, g1) = res
+    assert abs(t0 - t1) < 1e-5 * max(1.0, abs(t0)) and abs(p0 - p1) < 1e-5 * max(1.0, abs(p0)), (t0, t1, p0, p1)
+    for k in g0:
+        scale = g0[k].abs().max().item() + 1e-12
+        assert (g0[k] - g1[k]).abs().max().item() < 2e-3 * scale, (k, (g0[k] - g1[k]).abs().max().item(), scale)
+        assert (g0[k] - g1[k]).abs().mean().item() < 1e-4 * scale, k
+
+
+def test_fused_tracking_loss_matches_reference_formulation(dev):
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.losses import fused_tracking_loss
+    from gslam_amd.primitives import Camera, PoseZhou
+    from gslam_amd.synthetic import make_cameras, make_scene
+    from gslam_amd.tracking import TrackingConfig, tracking_loss
+    n, W, H = 3000, 200, 152
+    sc = make_scene(n, 22)
+    sc["scales"] = sc["scales"] + 0.6
+    viewmats, Ks = make_cameras(1, W, H)
+    gt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+    splats = GaussianSplattingData.from_dict(sc, dev)
+    res = []
+    for fused in (False, True):
+        pose = PoseZhou(viewmats[0].to(dev)).to(dev)
+        exposure = torch.tensor([0.1, -0.05], device=dev).requires_grad_(True)
+        out = splats([Camera(Ks[0].to(dev), H, W)], [pose], render_depth=True)
+        if fused:
+            loss = fused_tracking_loss(out, gt, exposure)
+        else:
+            rgb = out.rgbs[0] * exposure[0].exp() + exposure[1]
+            loss = tracking_loss(TrackingConfig(), rgb, gt, out.betas[0], out.depthmaps[0], None)
+        loss.backward()
+        res.append((float(loss), pose.dR.grad.clone(), pose.dt.grad.clone(), exposure.grad.clone()))
+    assert abs(res[0][0] - res[1][0]) < 1e-5 * abs(res[0][0])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert (a - b).abs().max() < 2e-3 * a.abs().max() + 1e-9

@@ -47,7 +47,7 @@ def main():
         # direct stage calls
         from gslam_amd._lib import check, lib, ptr, stream_ptr
         rec = torch.empty(C, N, 12, device=dev)
-        radii, m2d, dep, con, _, rec, tiles = ops._Projection.apply(
+        radii, m2d, dep, con, _, rec, tiles, _ = ops._Projection.apply(
             sc["means"].detach(), sc["quats"].detach(), sc["scales"].detach(), viewmats, Ks, sc["opacities"].detach(),
             sc["colors"].detach(), sc["log_uncertainties"].detach(), W, H, 0.3, 0.01, 1e10, 0.0, False, 1 | 2 | 4, True,
             True)
