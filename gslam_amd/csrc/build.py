@@ -20,6 +20,7 @@ ARCH = "gfx950"
 SOURCES = {
     "project.hip": ["-ffp-contract=off"],
     "isect.hip": ["-ffp-contract=off"],
+    "isect_bin.hip": ["-ffp-contract=off"],
     "raster.hip": [],
     "ssim.hip": [],
     "loss.hip": [],

@@ -1,0 +1,350 @@
+// isect_bin.hip — K3..K7 v2: tile-binned depth sort ("per-tile radix depth sort" of the north star, done as
+// bin-by-tile + per-tile LDS sort).  Same integer-exact contract as isect.hip (gsplat isect_tiles +
+// isect_offset_encode, gslam/rasterization.py:259-274): within a (camera, tile) the order is ascending
+// (float_bits(depth), flatten id), which is exactly what a stable sort of gsplat's 64-bit keys gives.
+//
+// Why not a device-wide radix sort: the key's high bits are the tile id, which is known when an intersection is
+// emitted.  Binning by tile costs ONE 8-byte scattered write per intersection, the per-tile offsets fall out of
+// the binning for free (no offset-encode pass), the residual sort is tile-local and runs out of LDS, and nothing
+// needs the host: every size lives in device memory, so the whole render is sync-free (the M read-back of the
+// reference's isect_tiles is gone).  HBM traffic per intersection: 8 B written + 8 B read + 4 B written (+8 B if
+// isect_ids are materialised) against >= 24 B x 6 digit passes for the 44-47 live key bits of the global sort.
+//
+//   1. tile_diff     : each Gaussian adds +-1 at the 4 corners of its tile rectangle in an LDS 2-D difference grid
+//                      (O(1) per Gaussian whatever its size), flushed with coalesced int atomics
+//   2. tile_offsets  : 2-D prefix sum -> per-tile counts -> exclusive scan -> offsets[T+1], cursors, M (one block)
+//   3. emit_binned   : per workgroup: LDS per-tile counts, ONE global atomic per touched tile to reserve a range,
+//                      LDS cursors to place 8-byte entries (depth_bits<<32 | flatten_id); rectangles larger than 16
+//                      tiles are walked cooperatively by the whole wavefront
+//   4. tile_sort     : one workgroup per tile, all-ascending ("mirrored") bitonic network on 64-bit keys in LDS
+//                      (<= 4096 entries) or in place in global memory (larger tiles); writes flatten_ids / isect_ids
+#include "gsx_common.h"
+
+namespace {
+
+constexpr int BIN_THREADS = 256;
+constexpr int BIN_ITEMS = 4;          // Gaussians per thread in tile_diff / emit_binned
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_LDS_CAP = 4096;    // keys sorted out of LDS (32 KiB); larger tiles sort in global memory
+constexpr int COOP_AREA = 16;         // rectangles with more tiles than this are walked by the whole wavefront
+
+__device__ __forceinline__ uint32_t sat_u32(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+
+struct Rect {
+    int x0, y0, x1, y1;
+};
+
+__device__ __forceinline__ Rect tile_rect(float mx, float my, int32_t radius, int tile_w, int tile_h) {
+    const float ts = (float)GSX_TILE;
+    const float tr = (float)radius / ts, tx = mx / ts, ty = my / ts;
+    Rect r;
+    r.x0 = (int)min(sat_u32(floorf(tx - tr)), (uint32_t)tile_w);
+    r.y0 = (int)min(sat_u32(floorf(ty - tr)), (uint32_t)tile_h);
+    r.x1 = (int)min(sat_u32(ceilf(tx + tr)), (uint32_t)tile_w);
+    r.y1 = (int)min(sat_u32(ceilf(ty + tr)), (uint32_t)tile_h);
+    return r;
+}
+
+__device__ __forceinline__ Rect load_rect(const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                                          int64_t idx, int tile_w, int tile_h, bool in_range) {
+    Rect r = {0, 0, 0, 0};
+    if (in_range) {
+        const int32_t rad = radii[idx];
+        if (rad > 0) r = tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rad, tile_w, tile_h);
+    }
+    return r;
+}
+
+// ---- 1. 2-D difference grid ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BIN_THREADS) void tile_diff_kernel(const float *__restrict__ means2d,
+                                                                const int32_t *__restrict__ radii, int64_t N,
+                                                                int tile_w, int tile_h, int *__restrict__ diff) {
+    extern __shared__ int s_diff[];
+    const int c = blockIdx.y;
+    const int gw = tile_w + 1;
+    const int G = gw * (tile_h + 1);
+    for (int i = threadIdx.x; i < G; i += BIN_THREADS) s_diff[i] = 0;
+    __syncthreads();
+    for (int it = 0; it < BIN_ITEMS; ++it) {
+        const int64_t g = ((int64_t)blockIdx.x * BIN_ITEMS + it) * BIN_THREADS + threadIdx.x;
+        const Rect r = load_rect(means2d, radii, (int64_t)c * N + g, tile_w, tile_h, g < N);
+        if (r.x1 > r.x0 && r.y1 > r.y0) {
+            atomicAdd(&s_diff[r.y0 * gw + r.x0], 1);
+            atomicAdd(&s_diff[r.y0 * gw + r.x1], -1);
+            atomicAdd(&s_diff[r.y1 * gw + r.x0], -1);
+            atomicAdd(&s_diff[r.y1 * gw + r.x1], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < G; i += BIN_THREADS) {
+        const int v = s_diff[i];
+        if (v != 0) atomicAdd(&diff[(int64_t)c * G + i], v);
+    }
+}
+
+// ---- 2. counts -> offsets ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void tile_offsets_kernel(const int *__restrict__ diff, int C, int tile_w, int tile_h,
+                                                            int64_t M_cap, int32_t *__restrict__ offsets /*[T+1]*/,
+                                                            int32_t *__restrict__ cursor /*[T]*/,
+                                                            int64_t *__restrict__ M_dev, int32_t *__restrict__ status) {
+    extern __shared__ int s_g[];           // (tile_h+1)*(tile_w+1) grid, then reused as the 1024-entry scan buffer
+    __shared__ long long s_scan[1024];
+    const int t = threadIdx.x;
+    const int gw = tile_w + 1, gh = tile_h + 1;
+    const int G = gw * gh;
+    const int n_tiles = tile_w * tile_h;
+    const int T = C * n_tiles;
+    for (int c = 0; c < C; ++c) {
+        for (int i = t; i < G; i += 1024) s_g[i] = diff[(int64_t)c * G + i];
+        __syncthreads();
+        if (t < gh) {  // prefix along x
+            int run = 0;
+            for (int x = 0; x < gw; ++x) { run += s_g[t * gw + x]; s_g[t * gw + x] = run; }
+        }
+        __syncthreads();
+        if (t < gw) {  // prefix along y
+            int run = 0;
+            for (int y = 0; y < gh; ++y) { run += s_g[y * gw + t]; s_g[y * gw + t] = run; }
+        }
+        __syncthreads();
+        for (int i = t; i < n_tiles; i += 1024) {
+            const int y = i / tile_w, x = i - y * tile_w;
+            offsets[(int64_t)c * n_tiles + i] = s_g[y * gw + x];  // per-tile count, scanned in place below
+        }
+        __syncthreads();
+    }
+    // exclusive scan of the T counts: contiguous chunk per thread + block scan of the chunk sums
+    const int per = (T + 1023) / 1024;
+    const int lo = min(T, t * per), hi = min(T, lo + per);
+    long long sum = 0;
+    for (int i = lo; i < hi; ++i) sum += offsets[i];
+    s_scan[t] = sum;
+    for (int off = 1; off < 1024; off <<= 1) {
+        __syncthreads();
+        const long long add = (t >= off) ? s_scan[t - off] : 0;
+        __syncthreads();
+        s_scan[t] += add;
+    }
+    __syncthreads();
+    long long run = s_scan[t] - sum;  // exclusive base of this thread's chunk
+    const long long total = s_scan[1023];
+    for (int i = lo; i < hi; ++i) {
+        const int cnt = offsets[i];
+        const int32_t o = (int32_t)min(run, (long long)0x7fffffff);
+        offsets[i] = o;
+        cursor[i] = o;
+        run += cnt;
+    }
+    if (t == 0) {
+        offsets[T] = (int32_t)min(total, (long long)0x7fffffff);
+        M_dev[0] = total;
+        if (total > M_cap || total > 0x7fffffffLL) atomicOr(status, 1);
+    }
+}
+
+// ---- 3. binning ---------------------------------------------------------------------------------------------------
+// walks every tile of every rectangle held by the wavefront's lanes and calls op(tile_local_index, lo, hi) with the
+// owning lane's 64-bit payload; small rectangles are walked by their own lane, large ones by all 64 lanes together
+// (payload broadcast once per large rectangle).  Must be called by all lanes of the wavefront.
+template <typename Op>
+__device__ __forceinline__ void walk_rects(const Rect &r, int tile_w, unsigned int lo, unsigned int hi, Op op) {
+    const int w = r.x1 - r.x0, h = r.y1 - r.y0;
+    const int area = (w > 0 && h > 0) ? w * h : 0;
+    const int lane = threadIdx.x & 63;
+    if (area > 0 && area <= COOP_AREA) {
+        for (int y = r.y0; y < r.y1; ++y)
+            for (int x = r.x0; x < r.x1; ++x) op(y * tile_w + x, lo, hi);
+    }
+    unsigned long long big = __ballot(area > COOP_AREA);
+    while (big != 0ull) {
+        const int l = __ffsll((long long)big) - 1;
+        big &= big - 1ull;
+        const int bx0 = __builtin_amdgcn_readlane(r.x0, l), by0 = __builtin_amdgcn_readlane(r.y0, l);
+        const int bw = __builtin_amdgcn_readlane(w, l), ba = __builtin_amdgcn_readlane(area, l);
+        const unsigned int blo = (unsigned int)__builtin_amdgcn_readlane((int)lo, l);
+        const unsigned int bhi = (unsigned int)__builtin_amdgcn_readlane((int)hi, l);
+        for (int k = lane; k < ba; k += 64) {
+            const int yy = k / bw, xx = k - yy * bw;
+            op((by0 + yy) * tile_w + bx0 + xx, blo, bhi);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void emit_binned_kernel(const float *__restrict__ means2d,
+                                                                  const int32_t *__restrict__ radii,
+                                                                  const float *__restrict__ depths, int64_t N,
+                                                                  int tile_w, int tile_h, int64_t M_cap,
+                                                                  int32_t *__restrict__ cursor,
+                                                                  unsigned long long *__restrict__ entries) {
+    extern __shared__ int s_cnt[];  // [n_tiles]
+    const int c = blockIdx.y;
+    const int n_tiles = tile_w * tile_h;
+    for (int i = threadIdx.x; i < n_tiles; i += BIN_THREADS) s_cnt[i] = 0;
+    __syncthreads();
+    Rect rects[BIN_ITEMS];
+#pragma unroll
+    for (int it = 0; it < BIN_ITEMS; ++it) {
+        const int64_t g = ((int64_t)blockIdx.x * BIN_ITEMS + it) * BIN_THREADS + threadIdx.x;
+        rects[it] = load_rect(means2d, radii, (int64_t)c * N + g, tile_w, tile_h, g < N);
+        walk_rects(rects[it], tile_w, 0u, 0u, [&](int tile, unsigned int, unsigned int) { atomicAdd(&s_cnt[tile], 1); });
+    }
+    __syncthreads();
+    // reserve one contiguous range per touched tile; s_cnt becomes the workgroup's absolute write cursor
+    for (int i = threadIdx.x; i < n_tiles; i += BIN_THREADS) {
+        const int n = s_cnt[i];
+        s_cnt[i] = (n > 0) ? atomicAdd(&cursor[(int64_t)c * n_tiles + i], n) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < BIN_ITEMS; ++it) {
+        const int64_t g = ((int64_t)blockIdx.x * BIN_ITEMS + it) * BIN_THREADS + threadIdx.x;
+        const int64_t idx = (int64_t)c * N + g;
+        const bool has = (rects[it].x1 > rects[it].x0) && (rects[it].y1 > rects[it].y0);
+        const unsigned int klo = (unsigned int)idx, khi = has ? __float_as_uint(depths[idx]) : 0u;
+        walk_rects(rects[it], tile_w, klo, khi, [&](int tile, unsigned int lo, unsigned int hi) {
+            const int pos = atomicAdd(&s_cnt[tile], 1);
+            if ((int64_t)pos < M_cap) entries[pos] = ((unsigned long long)hi << 32) | lo;
+        });
+    }
+}
+
+// ---- 4. per-tile sort -----------------------------------------------------------------------------------------------
+template <typename Ptr>
+__device__ __forceinline__ void cmp_exchange(Ptr k, int a, int b) {
+    const unsigned long long ka = k[a], kb = k[b];
+    if (ka > kb) { k[a] = kb; k[b] = ka; }
+}
+
+// all-ascending bitonic network over the first n slots of k (virtual +inf padding up to the next power of two)
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_sort(Ptr k, int n) {
+    int P = 1;
+    while (P < n) P <<= 1;
+    const int half = P >> 1;
+    for (int size = 2; size <= P; size <<= 1) {
+        const int hs = size >> 1;
+        for (int i = threadIdx.x; i < half; i += SORT_THREADS) {  // mirror step
+            const int blk = i / hs, off = i - blk * hs;
+            const int a = blk * size + off, b = blk * size + size - 1 - off;
+            if (b < n) cmp_exchange(k, a, b);
+        }
+        __syncthreads();
+        for (int j = hs >> 1; j >= 1; j >>= 1) {  // half cleaners
+            for (int i = threadIdx.x; i < half; i += SORT_THREADS) {
+                const int blk = i / j, off = i - blk * j;
+                const int a = blk * 2 * j + off, b = a + j;
+                if (b < n) cmp_exchange(k, a, b);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long long *__restrict__ entries,
+                                                                 const int32_t *__restrict__ offsets, int n_tiles,
+                                                                 int tile_n_bits, int64_t M_cap,
+                                                                 int64_t *__restrict__ isect_ids,
+                                                                 int32_t *__restrict__ flatten_ids) {
+    __shared__ unsigned long long s_keys[SORT_LDS_CAP];
+    const int tile = blockIdx.x;
+    const int64_t start = min((int64_t)offsets[tile], M_cap);
+    const int64_t end = min((int64_t)offsets[tile + 1], M_cap);
+    const int n = (int)(end - start);
+    if (n <= 0) return;
+    const int c = tile / n_tiles, tl = tile - c * n_tiles;
+    const long long hi_part = ((long long)c << (32 + tile_n_bits)) | ((long long)tl << 32);
+    unsigned long long *seg = entries + start;
+    if (n <= SORT_LDS_CAP) {
+        for (int i = threadIdx.x; i < n; i += SORT_THREADS) s_keys[i] = seg[i];
+        __syncthreads();
+        if (n > 1) bitonic_sort(s_keys, n);
+        for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
+            const unsigned long long k = s_keys[i];
+            flatten_ids[start + i] = (int32_t)(uint32_t)k;
+            if (isect_ids) isect_ids[start + i] = hi_part | (long long)(k >> 32);
+        }
+    } else {
+        __syncthreads();
+        bitonic_sort(seg, n);  // in place in global memory (L2): correct for any size, only huge tiles land here
+        for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
+            const unsigned long long k = seg[i];
+            flatten_ids[start + i] = (int32_t)(uint32_t)k;
+            if (isect_ids) isect_ids[start + i] = hi_part | (long long)(k >> 32);
+        }
+    }
+}
+
+int bit_length(uint32_t v) {
+    int n = 0;
+    while (v) { ++n; v >>= 1; }
+    return n;
+}
+
+struct BinLayout {
+    int64_t diff_off, cursor_off, entries_off, total;
+};
+
+BinLayout bin_layout(int64_t C, int tile_w, int tile_h, int64_t M_cap) {
+    BinLayout L;
+    const int64_t G = (int64_t)(tile_w + 1) * (tile_h + 1);
+    const int64_t T = C * tile_w * tile_h;
+    L.diff_off = 0;
+    L.cursor_off = gsx_align256(C * G * 4);
+    L.entries_off = L.cursor_off + gsx_align256(T * 4);
+    L.total = L.entries_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8) + 256;
+    return L;
+}
+
+}  // namespace
+
+extern "C" int64_t gsx_isect_bin_workspace_bytes(int64_t C, int tile_w, int tile_h, int64_t M_cap) {
+    return bin_layout(C, tile_w, tile_h, M_cap).total;
+}
+
+extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, const float *depths, int64_t N, int64_t C,
+                                  int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev,
+                                  int32_t *status, int64_t *isect_ids, int32_t *flatten_ids, void *workspace,
+                                  int64_t workspace_bytes, void *stream) {
+    GSX_CHECK_ARG(means2d && radii && depths && offsets && M_dev && status && N >= 0 && C >= 1);
+    GSX_CHECK_ARG(tile_w > 0 && tile_h > 0 && M_cap >= 0 && M_cap < ((int64_t)1 << 31));
+    GSX_CHECK_ARG(M_cap == 0 || flatten_ids);
+    const int64_t n_tiles = (int64_t)tile_w * tile_h;
+    const int64_t T = C * n_tiles;
+    GSX_CHECK_ARG(T < ((int64_t)1 << 30) && C < 65536);
+    const int64_t G = (int64_t)(tile_w + 1) * (tile_h + 1);
+    GSX_CHECK_ARG(G * 4 + 8192 <= 65536);  // the difference grid must fit the default 64 KiB LDS window next to the scan buffer
+    const BinLayout L = bin_layout(C, tile_w, tile_h, M_cap);
+    if (!workspace || workspace_bytes < L.total) {
+        gsx_set_error("gsx_isect_bin_sort: workspace too small (%lld < %lld)", (long long)workspace_bytes,
+                      (long long)L.total);
+        return GSX_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    int *diff = (int *)(ws + L.diff_off);
+    int32_t *cursor = (int32_t *)(ws + L.cursor_off);
+    unsigned long long *entries = (unsigned long long *)(ws + L.entries_off);
+    if (hipMemsetAsync(diff, 0, (size_t)(C * G * 4), st) != hipSuccess) return GSX_E_LAUNCH;
+    const unsigned gblocks = (unsigned)((N + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
+    if (N > 0) {
+        hipLaunchKernelGGL(tile_diff_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(G * 4), st, means2d,
+                           radii, N, tile_w, tile_h, diff);
+        GSX_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), (size_t)(G * 4), st, diff, (int)C, tile_w, tile_h, M_cap,
+                       offsets, cursor, M_dev, status);
+    GSX_CHECK_LAUNCH();
+    if (N > 0 && M_cap > 0) {
+        hipLaunchKernelGGL(emit_binned_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4), st,
+                           means2d, radii, depths, N, tile_w, tile_h, M_cap, cursor, entries);
+        GSX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, offsets,
+                           (int)n_tiles, bit_length((uint32_t)n_tiles), M_cap, isect_ids, flatten_ids);
+        GSX_CHECK_LAUNCH();
+    }
+    return GSX_OK;
+}

@@ -104,15 +104,16 @@ __device__ __forceinline__ Quad make_quad(int tile_w, int tile_h, int W, int H) 
 template <int CH, int RS>
 __global__ __launch_bounds__(256) void raster_fwd_kernel(const float *__restrict__ rec, const float *__restrict__ bg,
                                                          const int32_t *__restrict__ offsets,
-                                                         const int32_t *__restrict__ flatten_ids, int64_t M, int W,
-                                                         int H, int tile_w, int tile_h, float vis_min_T,
-                                                         float *__restrict__ render, float *__restrict__ alphas,
-                                                         int32_t *__restrict__ last_ids,
+                                                         const int32_t *__restrict__ flatten_ids, int64_t M,
+                                                         int has_end, int W, int H, int tile_w, int tile_h,
+                                                         float vis_min_T, float *__restrict__ render,
+                                                         float *__restrict__ alphas, int32_t *__restrict__ last_ids,
                                                          int32_t *__restrict__ n_touched) {
     const Quad q = make_quad(tile_w, tile_h, W, H);
     const int n_tiles_total = gridDim.x;
-    const int start = offsets[q.tile];
-    const int end = (q.tile + 1 < n_tiles_total) ? offsets[q.tile + 1] : (int)M;
+    // has_end: offsets holds T+1 entries and M is the CAPACITY of flatten_ids (sync-free path); otherwise M is exact
+    const int start = min(offsets[q.tile], (int)M);
+    const int end = (has_end || q.tile + 1 < n_tiles_total) ? min(offsets[q.tile + 1], (int)M) : (int)M;
 
     float T = 1.0f;
     float pix[CH];
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(const float *__restrict
 template <int CH, int RS, bool ABS>
 __global__ __launch_bounds__(256) void raster_bwd_kernel(
     const float *__restrict__ rec, const float *__restrict__ bg, const int32_t *__restrict__ offsets,
-    const int32_t *__restrict__ flatten_ids, int64_t M, int W, int H, int tile_w, int tile_h,
+    const int32_t *__restrict__ flatten_ids, int64_t M, int has_end, int W, int H, int tile_w, int tile_h,
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
     const float *__restrict__ v_alphas, float *__restrict__ v_rec, float *__restrict__ v_abs) {
     constexpr int NG = 6 + CH;  // gradient entries per record: xy(2) conic(3) opacity(1) colors(CH)
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
     const Quad q = make_quad(tile_w, tile_h, W, H);
     const int t = threadIdx.x;
     const int64_t p = ((int64_t)q.c * H + min(q.py, H - 1)) * W + min(q.px, W - 1);
-    const int start = offsets[q.tile];
+    const int start = min(offsets[q.tile], (int)M);
     const int last = q.inside ? last_ids[p] : -1;
     int wmax = last;
 #pragma unroll
@@ -300,9 +301,9 @@ bool use_v1() {
 }  // namespace
 
 extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
-                              const int32_t *flatten_ids, int64_t M, int64_t C, int W, int H, int tile_w, int tile_h,
-                              float visibility_min_T, float *render, float *alphas, int32_t *last_ids,
-                              int32_t *n_touched, void *stream) {
+                              const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
+                              int tile_w, int tile_h, float visibility_min_T, float *render, float *alphas,
+                              int32_t *last_ids, int32_t *n_touched, void *stream) {
     GSX_CHECK_ARG(offsets && render && alphas && last_ids && n_touched && C >= 1 && W > 0 && H > 0);
     GSX_CHECK_ARG(tile_w == (W + GSX_TILE - 1) / GSX_TILE && tile_h == (H + GSX_TILE - 1) / GSX_TILE);
     GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31));
@@ -310,7 +311,7 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
     const int64_t T = C * tile_w * tile_h;
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
     hipStream_t st = (hipStream_t)stream;
-    const bool v1 = use_v1();
+    const bool v1 = use_v1() && !offsets_has_end;
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
         if (v1)                                                                                                     \
@@ -319,8 +320,8 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
                                render, alphas, last_ids, n_touched);                                                \
         else                                                                                                        \
             hipLaunchKernelGGL((raster_fwd_kernel<ch, rs>), dim3((unsigned)T), dim3(256), 0, st, rec, backgrounds, \
-                               offsets, flatten_ids, M, W, H, tile_w, tile_h, visibility_min_T, render, alphas,    \
-                               last_ids, n_touched);                                                                \
+                               offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, visibility_min_T,  \
+                               render, alphas, last_ids, n_touched);                                                \
     } while (0)
     switch (CH) {
         case 1: LAUNCH(1, 8); break;
@@ -336,9 +337,9 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
 }
 
 extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
-                              const int32_t *flatten_ids, int64_t M, int64_t C, int W, int H, int tile_w, int tile_h,
-                              const float *alphas, const int32_t *last_ids, const float *v_render,
-                              const float *v_alphas, float *v_rec, float *v_abs, void *stream) {
+                              const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
+                              int tile_w, int tile_h, const float *alphas, const int32_t *last_ids,
+                              const float *v_render, const float *v_alphas, float *v_rec, float *v_abs, void *stream) {
     GSX_CHECK_ARG(offsets && alphas && last_ids && v_render && v_alphas && C >= 1 && W > 0 && H > 0);
     GSX_CHECK_ARG(tile_w == (W + GSX_TILE - 1) / GSX_TILE && tile_h == (H + GSX_TILE - 1) / GSX_TILE);
     GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31));
@@ -346,13 +347,14 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     GSX_CHECK_ARG(rec && flatten_ids && v_rec);
     const int64_t T = C * tile_w * tile_h;
     hipStream_t st = (hipStream_t)stream;
-    const bool v1 = use_v1();
-#define ARGS rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
+    const bool v1 = use_v1() && !offsets_has_end;
+#define ARGS1 rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
+#define ARGS rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
         if (v1) {                                                                                                   \
-            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS); \
-            else hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS);      \
+            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS1); \
+            else hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS1);      \
         } else {                                                                                                    \
             if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS);    \
             else hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS);         \
@@ -368,6 +370,7 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     }
 #undef LAUNCH
 #undef ARGS
+#undef ARGS1
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }

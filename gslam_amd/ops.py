@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -203,6 +204,15 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
         tiles_per_gauss = torch.empty(Cn, N, dtype=torch.int32, device=dev)
         check(lib.gsx_isect_count(ptr(means2d), ptr(radii), Cn * N, tile_width, tile_height, ptr(tiles_per_gauss), st),
               "gsx_isect_count")
+    if sort and os.environ.get("GSX_SORT_V1", "0") != "1":
+        # v2: tile-binned sort (csrc/isect_bin.hip).  This gsplat-shaped API returns exactly-sized arrays, so M is read
+        # back once here; the fused gslam path (gslam_amd.rasterization) uses the same kernels without any read-back.
+        M = int(tiles_per_gauss.sum().item()) if Cn * N > 0 else 0
+        isect_ids = torch.empty(M, dtype=torch.int64, device=dev)
+        flatten_ids = torch.empty(M, dtype=torch.int32, device=dev)
+        if M > 0:
+            isect_bin_sort(means2d, radii, depths, tile_width, tile_height, M, isect_ids, flatten_ids)
+        return tiles_per_gauss, isect_ids, flatten_ids
     cum = torch.empty(Cn * N, dtype=torch.int64, device=dev)
     M = 0
     if Cn * N > 0:
@@ -219,6 +229,25 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
                                       M, 1 if sort else 0, ptr(isect_ids), ptr(flatten_ids), ptr(ws), ws.numel(), st),
               "gsx_isect_emit_sort")
     return tiles_per_gauss, isect_ids, flatten_ids
+
+
+@torch.no_grad()
+def isect_bin_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_width: int, tile_height: int, capacity: int,
+                   isect_ids: Optional[Tensor], flatten_ids: Tensor, offsets: Optional[Tensor] = None,
+                   M_dev: Optional[Tensor] = None, status: Optional[Tensor] = None):
+    """Sync-free K3..K7: fills ``flatten_ids`` (and ``isect_ids``) up to ``capacity`` and returns
+    (offsets int32 [T+1], M_dev int64 [1], status int32 [1]); status bit 0 = capacity overflow."""
+    Cn, N = radii.shape
+    dev = means2d.device
+    T = Cn * tile_width * tile_height
+    offsets = torch.empty(T + 1, dtype=torch.int32, device=dev) if offsets is None else offsets
+    M_dev = torch.empty(1, dtype=torch.int64, device=dev) if M_dev is None else M_dev
+    status = torch.zeros(1, dtype=torch.int32, device=dev) if status is None else status
+    ws = workspace(lib.gsx_isect_bin_workspace_bytes(Cn, tile_width, tile_height, capacity), dev, "isect_bin")
+    check(lib.gsx_isect_bin_sort(ptr(means2d), ptr(radii), ptr(depths), N, Cn, tile_width, tile_height, capacity,
+                                 ptr(offsets), ptr(M_dev), ptr(status), ptr(isect_ids), ptr(flatten_ids), ptr(ws),
+                                 ws.numel(), stream_ptr(dev)), "gsx_isect_bin_sort")
+    return offsets, M_dev, status
 
 
 @torch.no_grad()
@@ -242,12 +271,16 @@ class _RasterizeRecords(torch.autograd.Function):
     are ignored by the projection backward."""
 
     @staticmethod
-    def forward(ctx, rec, means2d, conics, backgrounds, offsets, flatten_ids, ch, width, height, vis_min_T, absgrad):
+    def forward(ctx, rec, means2d, conics, backgrounds, offsets, flatten_ids, ch, width, height, vis_min_T, absgrad,
+                has_end=False):
+        """has_end: ``offsets`` is the flat int32 [T+1] array of gsx_isect_bin_sort and ``flatten_ids`` a
+        capacity-sized buffer (sync-free path); otherwise the gsplat layout ([C,tile_h,tile_w] offsets, exact M)."""
         rec = _f32c(rec, "rec")
         Cn, N, RS = rec.shape
         assert RS == record_stride(ch)
         dev = rec.device
-        tile_h, tile_w = offsets.shape[1:]
+        tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
+        assert offsets.numel() == Cn * tile_h * tile_w + (1 if has_end else 0)
         bg = None if backgrounds is None else _f32c(backgrounds, "backgrounds")
         render = torch.empty(Cn, height, width, ch, dtype=torch.float32, device=dev)
         alphas = torch.empty(Cn, height, width, 1, dtype=torch.float32, device=dev)
@@ -255,11 +288,11 @@ class _RasterizeRecords(torch.autograd.Function):
         n_touched = torch.zeros(Cn, N, dtype=torch.int32, device=dev)
         offsets, flatten_ids = offsets.contiguous(), flatten_ids.contiguous()
         M = flatten_ids.shape[0]
-        check(lib.gsx_raster_fwd(ptr(rec), ch, ptr(bg), ptr(offsets), ptr(flatten_ids), M, Cn, width, height, tile_w,
-                                 tile_h, vis_min_T, ptr(render), ptr(alphas), ptr(last_ids), ptr(n_touched),
-                                 stream_ptr(dev)), "gsx_raster_fwd")
+        check(lib.gsx_raster_fwd(ptr(rec), ch, ptr(bg), ptr(offsets), ptr(flatten_ids), M, 1 if has_end else 0, Cn,
+                                 width, height, tile_w, tile_h, vis_min_T, ptr(render), ptr(alphas), ptr(last_ids),
+                                 ptr(n_touched), stream_ptr(dev)), "gsx_raster_fwd")
         ctx.save_for_backward(rec, bg, offsets, flatten_ids, alphas, last_ids)
-        ctx.cfg = (ch, width, height, absgrad)
+        ctx.cfg = (ch, width, height, absgrad, has_end)
         ctx.means2d_ref = means2d if absgrad else None
         ctx.mark_non_differentiable(n_touched, last_ids)
         return render, alphas, n_touched, last_ids
@@ -267,24 +300,25 @@ class _RasterizeRecords(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render, v_alphas, _v_nt, _v_last):
         rec, bg, offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
-        ch, width, height, absgrad = ctx.cfg
+        ch, width, height, absgrad, has_end = ctx.cfg
         Cn, N, RS = rec.shape
         dev = rec.device
-        tile_h, tile_w = offsets.shape[1:]
+        tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
         v_render = torch.zeros_like(alphas).expand(-1, -1, -1, ch).contiguous() if v_render is None \
             else v_render.contiguous()
         v_alphas = torch.zeros_like(alphas) if v_alphas is None else v_alphas.contiguous()
         v_rec = torch.zeros(Cn, N, RS, dtype=torch.float32, device=dev)
         v_abs = torch.zeros(Cn, N, 2, dtype=torch.float32, device=dev) if absgrad else None
-        check(lib.gsx_raster_bwd(ptr(rec), ch, ptr(bg), ptr(offsets), ptr(flatten_ids), flatten_ids.shape[0], Cn,
-                                 width, height, tile_w, tile_h, ptr(alphas), ptr(last_ids), ptr(v_render),
+        check(lib.gsx_raster_bwd(ptr(rec), ch, ptr(bg), ptr(offsets), ptr(flatten_ids), flatten_ids.shape[0],
+                                 1 if has_end else 0, Cn, width, height, tile_w, tile_h, ptr(alphas), ptr(last_ids),
+                                 ptr(v_render),
                                  ptr(v_alphas), ptr(v_rec), ptr(v_abs), stream_ptr(dev)), "gsx_raster_bwd")
         if absgrad and ctx.means2d_ref is not None:
             ctx.means2d_ref.absgrad = v_abs  # same side channel as gsplat (absgrad is off in gslam, rasterization.py:63)
         v_bg = None
         if bg is not None and ctx.needs_input_grad[3]:
             v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
-        return v_rec, v_rec[..., 0:2], v_rec[..., 2:5], v_bg, None, None, None, None, None, None, None
+        return v_rec, v_rec[..., 0:2], v_rec[..., 2:5], v_bg, None, None, None, None, None, None, None, None
 
 
 class _PackRecords(torch.autograd.Function):
@@ -372,3 +406,18 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor, masks
     if masks is not None:
         radii = masks.to(torch.int32)
     return _SphericalHarmonics.apply(int(degrees_to_use), dirs, coeffs, radii)
+
+
+@torch.no_grad()
+def rebuild_isect_ids(out, M: int) -> Tensor:
+    """Sorted gsplat keys (cam << (32+tile_n_bits) | tile << 32 | float_bits(depth)) for a sync-free render, built on
+    demand from flatten_ids / depths / offsets (nobody on the gslam hot path reads them)."""
+    flat = out._flatten_ids.long()
+    dev = flat.device
+    n_tiles = out.tile_width * out.tile_height
+    tnb = int(n_tiles).bit_length()
+    dbits = out.depths.detach().reshape(-1).view(torch.int32)[flat].long() & 0xFFFFFFFF
+    offsets = out.isect_offsets.reshape(-1).long()
+    tile = torch.searchsorted(offsets, torch.arange(M, device=dev), right=True) - 1
+    cam, tl = tile // n_tiles, tile % n_tiles
+    return (cam << (32 + tnb)) | (tl << 32) | dbits

@@ -1,16 +1,22 @@
 """Drop-in for gslam/rasterization.py: same ``rasterization(...)`` signature (pre-activation inputs) and the same
-``RasterizationOutput`` dataclass, computed by the HIP kernels of libgsx.so.
+``RasterizationOutput`` fields, computed by the HIP kernels of libgsx.so.
 
 Differences from the reference file are limited to what SURVEY.md §8a flags as dead or buggy there and which the
 build must not copy: the ``ED`` / ``RGB+ED`` post-processing (KeyError 'depthaps', rasterization.py:342-344) is
 implemented as the documented intent (depth / alpha), the >32-channel chunk loop (wrong variable at :323) and the
 ``covars`` path (:129-134 vs :147) are rejected explicitly.
+
+Sync-free by construction: the reference's ``isect_tiles`` reads the intersection count M back to the host in the
+middle of every render.  Here the tile-binned sort keeps every size on the device and writes into capacity-sized
+buffers; ``isect_ids`` / ``flatten_ids`` are trimmed lazily (first access) and capacity overflow is detected from
+an asynchronous copy of the device status word (``validate()`` forces the check).
 """
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass
-from typing import ClassVar, Optional
+import os
+import warnings
+from typing import Optional
 
 import torch
 from torch import Tensor
@@ -19,32 +25,121 @@ from . import ops
 from .ops import PROJ_BETAS, PROJ_LOG_SCALES, PROJ_RENDER_DEPTH
 
 
-@dataclass
 class RasterizationOutput:
-    """Field-for-field mirror of gslam/rasterization.py:17-41 (positional construction at backend.py:619 works)."""
-    per_gaussian_params: ClassVar[tuple] = ('radii', 'means2d')
-    rgbs: Tensor = None
-    alphas: Tensor = None
-    depthmaps: Tensor = None
-    betas: Tensor = None
-    tile_width: int = None
-    tile_height: int = None
-    tiles_per_gauss: Tensor = None
-    isect_ids: Tensor = None
-    flatten_ids: Tensor = None
-    isect_offsets: Tensor = None
-    width: int = None
-    height: int = None
-    tile_size: int = None
-    n_cameras: int = None
-    camera_ids: Tensor = None
-    gaussian_ids: Tensor = None
-    radii: Tensor = None
-    means2d: Tensor = None
-    depths: Tensor = None
-    conics: Tensor = None
-    opacities: Tensor = None
-    n_touched: Tensor = None
+    """Field-for-field mirror of the dataclass at gslam/rasterization.py:17-41 (same field order, so the positional
+    construction ``RasterizationOutput(None, alphas, depthmaps)`` of backend.py:619 works).  ``isect_ids`` and
+    ``flatten_ids`` are materialised on first access when they come from the sync-free path."""
+    per_gaussian_params = ('radii', 'means2d')
+    _FIELDS = ('rgbs', 'alphas', 'depthmaps', 'betas', 'tile_width', 'tile_height', 'tiles_per_gauss', 'isect_ids',
+               'flatten_ids', 'isect_offsets', 'width', 'height', 'tile_size', 'n_cameras', 'camera_ids',
+               'gaussian_ids', 'radii', 'means2d', 'depths', 'conics', 'opacities', 'n_touched')
+
+    def __init__(self, rgbs=None, alphas=None, depthmaps=None, betas=None, tile_width=None, tile_height=None,
+                 tiles_per_gauss=None, isect_ids=None, flatten_ids=None, isect_offsets=None, width=None, height=None,
+                 tile_size=None, n_cameras=None, camera_ids=None, gaussian_ids=None, radii=None, means2d=None,
+                 depths=None, conics=None, opacities=None, n_touched=None):
+        self.rgbs, self.alphas, self.depthmaps, self.betas = rgbs, alphas, depthmaps, betas
+        self.tile_width, self.tile_height, self.tiles_per_gauss = tile_width, tile_height, tiles_per_gauss
+        self._isect_ids, self._flatten_ids, self.isect_offsets = isect_ids, flatten_ids, isect_offsets
+        self.width, self.height, self.tile_size, self.n_cameras = width, height, tile_size, n_cameras
+        self.camera_ids, self.gaussian_ids, self.radii, self.means2d = camera_ids, gaussian_ids, radii, means2d
+        self.depths, self.conics, self.opacities, self.n_touched = depths, conics, opacities, n_touched
+        self._lazy = None      # (_IsectBuffers, generation) when the id arrays live in capacity-sized buffers
+        self._render = self._depth_index = self._betas_index = self._vis_count = None
+
+    def _materialise(self):
+        if self._lazy is not None:
+            bufs, M_dev, flat, ids_needed = self._lazy
+            M = int(M_dev.item())                      # the one read-back, only if somebody asks for the arrays
+            if M > flat.shape[0]:
+                raise RuntimeError(f"isect capacity overflow: {M} intersections > capacity {flat.shape[0]}; "
+                                   "call gslam_amd.rasterization.validate() and re-render")
+            self._flatten_ids = flat[:M]
+            self._isect_ids = ops.rebuild_isect_ids(self, M)
+            self._lazy = None
+
+    @property
+    def flatten_ids(self):
+        self._materialise()
+        return self._flatten_ids
+
+    @property
+    def isect_ids(self):
+        self._materialise()
+        return self._isect_ids
+
+    def __repr__(self):
+        return "RasterizationOutput(" + ", ".join(f"{f}=..." for f in self._FIELDS) + ")"
+
+
+class _IsectPool:
+    """Per-device capacity manager for the sync-free tile-binned sort."""
+    GROW = 1.5
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.capacity = 0
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._pinned = torch.zeros(2, dtype=torch.int64).pin_memory()
+        self._staging = torch.zeros(2, dtype=torch.int64, device=dev)
+        self._event: Optional[torch.cuda.Event] = None
+        self.overflowed = False
+        self.last_M = 0
+
+    def ensure(self, estimate: int):
+        want = int(estimate * self.GROW) + 4096
+        if want > self.capacity:
+            self.capacity = want
+
+    def poll(self, block: bool = False) -> bool:
+        """Consumes the asynchronous (M, status) copy of the previous render if it has arrived.  Returns False when
+        that render overflowed its capacity (capacity is grown for the next one)."""
+        ok = True
+        if self._event is not None and (block or self._event.query()):
+            if block:
+                self._event.synchronize()
+            M, st = int(self._pinned[0]), int(self._pinned[1])
+            self._event = None
+            self.last_M = M
+            if st & 1:
+                ok = False
+                self.overflowed = True
+                self.capacity = int(M * self.GROW) + 4096
+                self.status.zero_()
+            else:
+                self.ensure(M)
+        return ok
+
+    def post(self, M_dev: Tensor):
+        self._staging[0:1].copy_(M_dev)
+        self._staging[1:2].copy_(self.status)
+        self._pinned.copy_(self._staging, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+
+
+_POOLS: dict = {}
+
+
+def _pool(dev) -> _IsectPool:
+    key = torch.device(dev).index
+    p = _POOLS.get(key)
+    if p is None:
+        p = _IsectPool(dev)
+        _POOLS[key] = p
+    return p
+
+
+def validate(device=None) -> bool:
+    """Blocks until the last render's intersection count has arrived and returns True iff no sync-free render since
+    the previous call overflowed its buffers.  On False the caller should re-run the affected iteration (the capacity
+    has already been grown)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    p = _pool(dev)
+    p.poll(block=True)
+    bad = p.overflowed
+    p.overflowed = False
+    return not bad
 
 
 def rasterization(
@@ -76,7 +171,7 @@ def rasterization(
     mask: Optional[Tensor] = None,
 ) -> RasterizationOutput:
     """gslam ``rasterization`` (gslam/rasterization.py:44-360).  One fused projection+activation+packing kernel,
-    tile intersection + depth sort, one tiled rasterisation kernel; autograd reaches every pre-activation input and
+    tile-binned depth sort, one tiled rasterisation kernel; autograd reaches every pre-activation input and
     ``viewmats``.  The only caller in the reference passes packed=False (map.py:99)."""
     N = means.shape[0]
     C = viewmats.shape[0]
@@ -115,7 +210,8 @@ def rasterization(
 
     radii, means2d, depths, conics, _comps, rec, tiles_per_gauss, vis_count = ops._Projection.apply(
         means, quats, log_scales, viewmats, Ks, logit_opacities, logit_colors, log_uncertainties, int(width),
-        int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), False, flags, True, True, True)
+        int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), False, flags, True, True,
+        True)
 
     # backgrounds: [C,3] + 0 for depth + e^1 for beta (rasterization.py:236-239,251-255)
     bg = None
@@ -129,13 +225,33 @@ def rasterization(
 
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
-    _, isect_ids, flatten_ids = ops.isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height,
-                                                packed=False, n_cameras=C, tiles_per_gauss=tiles_per_gauss)
-    isect_offsets = ops.isect_offset_encode(isect_ids, C, tile_width, tile_height)
+    dev = means.device
+
+    lazy = None
+    if os.environ.get("GSX_SYNC_ISECT", "0") == "1":
+        # reference-shaped path: M is read back inside isect_tiles (one host sync per render)
+        _, isect_ids, flatten_ids = ops.isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height,
+                                                    packed=False, n_cameras=C, tiles_per_gauss=tiles_per_gauss)
+        isect_offsets = ops.isect_offset_encode(isect_ids, C, tile_width, tile_height)
+        raster_offsets, has_end = isect_offsets, False
+    else:
+        pool = _pool(dev)
+        pool.poll()
+        if pool.capacity == 0:
+            pool.ensure(int(tiles_per_gauss.sum().item()))      # first render on this device: one probe
+        cap = pool.capacity
+        flat_buf = torch.empty(cap, dtype=torch.int32, device=dev)
+        with torch.no_grad():
+            off1, M_dev, _ = ops.isect_bin_sort(means2d.detach(), radii, depths.detach(), tile_width, tile_height, cap,
+                                                None, flat_buf, status=pool.status)
+        pool.post(M_dev)
+        isect_offsets = off1[:-1].view(C, tile_height, tile_width)
+        raster_offsets, has_end, flatten_ids, isect_ids = off1, True, flat_buf, None
+        lazy = (pool, M_dev, flat_buf, True)
 
     render, alphas, n_touched, _last = ops._RasterizeRecords.apply(
-        rec, means2d, conics, bg, isect_offsets, flatten_ids, ch, int(width), int(height), float(visibility_min_T),
-        bool(absgrad))
+        rec, means2d, conics, bg, raster_offsets, flatten_ids, ch, int(width), int(height), float(visibility_min_T),
+        bool(absgrad), has_end)
 
     out = RasterizationOutput(
         rgbs=render[..., :3],
@@ -145,6 +261,7 @@ def rasterization(
         n_cameras=C, camera_ids=None, gaussian_ids=None, radii=radii, means2d=means2d, depths=depths, conics=conics,
         opacities=rec[..., 5], n_touched=n_touched.long(),
     )
+    out._lazy = lazy
     if depth_index is not None:
         out.depthmaps = render[..., depth_index]
         if render_mode == "RGB+ED":

@@ -112,18 +112,34 @@ int gsx_isect_emit_sort(const float *means2d, const int32_t *radii, const float 
 int gsx_isect_offset_encode(const int64_t *isect_ids, int64_t M, int64_t C, int tile_w, int tile_h,
                             int32_t *offsets /*[C,tile_h,tile_w]*/, void *stream);
 
+/* ---- K3..K7 v2: tile-binned depth sort (csrc/isect_bin.hip).  Same results as count/scan/emit_sort/offset_encode for
+ * sort=1, but sync-free: every size stays on the device.  offsets: int32 [T+1] (offsets[T] = min(M, INT_MAX));
+ * M_dev: int64 [1] = true number of intersections; status: int32 [1], bit 0 is OR-ed in when M > M_cap (entries
+ * beyond M_cap are dropped - the caller must re-run with a larger capacity); flatten_ids [M_cap]; isect_ids
+ * [M_cap] nullable. */
+int64_t gsx_isect_bin_workspace_bytes(int64_t C, int tile_w, int tile_h, int64_t M_cap);
+int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, const float *depths, int64_t N, int64_t C,
+                       int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev, int32_t *status,
+                       int64_t *isect_ids, int32_t *flatten_ids, void *workspace, int64_t workspace_bytes,
+                       void *stream);
+
 /* ---- K8: gsplat(fork) rasterize_to_pixels fwd (gslam/rasterization.py:325-339; fork: + n_touched) ----------------
  * rec: splat records [C*N, gsx_record_stride(CH)].  render [C,H,W,CH], alphas [C,H,W], last_ids [C,H,W] (global
  * sorted index of the last contributing entry, -1 if none), n_touched [C*N] int32 (must be zeroed by the caller).
+ * offsets_has_end = 0: offsets has T entries and M is the exact number of intersections (gsplat layout);
+ * offsets_has_end = 1: offsets has T+1 entries (gsx_isect_bin_sort) and M is the CAPACITY of flatten_ids - tile
+ * ranges are clamped to it, nothing is read back to the host.
  */
 int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds /*[C,CH] nullable*/, const int32_t *offsets,
-                   const int32_t *flatten_ids, int64_t M, int64_t C, int W, int H, int tile_w, int tile_h,
+                   const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H, int tile_w,
+                   int tile_h,
                    float visibility_min_T, float *render, float *alphas, int32_t *last_ids, int32_t *n_touched,
                    void *stream);
 /* ---- K9: rasterize_to_pixels bwd.  v_rec [C*N, stride] must be zeroed by the caller; gradients are accumulated
  * in record layout: v_xy(2) v_conic(3) v_opacity(1) v_colors(CH).  v_abs (nullable, [C*N,2], zeroed): absgrad.   */
 int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
-                   const int32_t *flatten_ids, int64_t M, int64_t C, int W, int H, int tile_w, int tile_h,
+                   const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H, int tile_w,
+                   int tile_h,
                    const float *alphas, const int32_t *last_ids, const float *v_render, const float *v_alphas,
                    float *v_rec, float *v_abs, void *stream);
 

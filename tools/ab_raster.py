@@ -42,6 +42,12 @@ def main():
         out = rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], viewmats, Ks, W, H,
                             packed=False, render_mode="RGB+D", log_uncertainties=sc["log_uncertainties"],
                             backgrounds=torch.zeros(C, 3, device=dev))
+        from gslam_amd.rasterization import validate
+        if not validate(dev):      # capacity grown after a size jump: render again
+            out = rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], viewmats, Ks,
+                                W, H, packed=False, render_mode="RGB+D", log_uncertainties=sc["log_uncertainties"],
+                                backgrounds=torch.zeros(C, 3, device=dev))
+            assert validate(dev)
         M = out.flatten_ids.shape[0]
         print(f"N={N} M={M} visible={(out.radii > 0).sum().item()}")
         # direct stage calls
@@ -51,7 +57,7 @@ def main():
             sc["means"].detach(), sc["quats"].detach(), sc["scales"].detach(), viewmats, Ks, sc["opacities"].detach(),
             sc["colors"].detach(), sc["log_uncertainties"].detach(), W, H, 0.3, 0.01, 1e10, 0.0, False, 1 | 2 | 4, True,
             True)
-        off, flat = out.isect_offsets, out.flatten_ids
+        off, flat = out.isect_offsets.contiguous(), out.flatten_ids.contiguous()
         bg = torch.zeros(C, 5, device=dev)
         bg[:, 4] = 2.718281828
         render = torch.empty(C, H, W, 5, device=dev)
@@ -64,15 +70,20 @@ def main():
         st = stream_ptr(dev)
 
         def fwd():
-            check(lib.gsx_raster_fwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, C, W, H, 40, 30, 0.5, ptr(render),
+            check(lib.gsx_raster_fwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, 40, 30, 0.5, ptr(render),
                                      ptr(alphas), ptr(last), ptr(nt), st), "fwd")
 
         def bwd():
-            check(lib.gsx_raster_bwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, C, W, H, 40, 30, ptr(alphas),
+            check(lib.gsx_raster_bwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, 40, 30, ptr(alphas),
                                      ptr(last), ptr(v_render), ptr(v_alpha), ptr(v_rec), None, st), "bwd")
 
         def sort():
             ops.isect_tiles(m2d, radii, dep, 16, 40, 30, tiles_per_gauss=tiles)
+
+        flat_buf = torch.empty(M, dtype=torch.int32, device=dev)
+
+        def sort2():
+            ops.isect_bin_sort(m2d, radii, dep, 40, 30, M, None, flat_buf)
 
         res = {}
         for rnd in range(2):
@@ -85,7 +96,11 @@ def main():
         for k, v in sorted(res.items()):
             print(f"  raster_{k[0]} {'v1' if k[1] == '1' else 'v2'}: median/min us per round = "
                   + ", ".join(f"{a:.1f}/{b:.1f}" for a, b in v))
-        print(f"  isect_tiles (count..sort, incl. M read-back): {timed(sort)[0]:.1f} us")
+        os.environ["GSX_SORT_V1"] = "1"
+        print(f"  isect_tiles v1 rocPRIM (scan..sort, incl. M read-back): {timed(sort)[0]:.1f} us")
+        os.environ["GSX_SORT_V1"] = "0"
+        print(f"  isect_bin_sort v2 (diff/offsets/emit/tile-sort, sync-free): {timed(sort2)[0]:.1f} us")
+        assert torch.equal(flat_buf, flat), "v2 sort differs from v1"
 
 
 if __name__ == "__main__":
