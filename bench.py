@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     return ap.parse_args()
 
 
@@ -172,12 +173,15 @@ def main():
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (1-GPU box): GSX_FORCE_DEVICE=0 puts every rank on cuda:0, GSX_DIST_BACKEND=gloo avoids RCCL's
+    # duplicate-GPU check.  The driver's multi-GPU runs use neither: one rank per GPU over RCCL/xGMI.
+    dev_index = int(os.environ.get("GSX_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from gslam_amd import dist as gdist
     import torch.distributed as td
-    gdist.init_from_env(device=dev)
+    gdist.init_from_env(backend=os.environ.get("GSX_DIST_BACKEND"), device=dev)
 
     from gslam_amd.map import GaussianSplattingData
     from gslam_amd.mapping import BundleAdjuster, MapConfig
@@ -189,7 +193,13 @@ def main():
     own = {c for c in range(world) if c % world == rank}
     window = make_window(world, W, H, dev, gt_scene, own)
     del gt_scene
-    ba = BundleAdjuster(splats, MapConfig())
+    use_graph = (world == 1) and not args.no_graph
+    ba = BundleAdjuster(splats, MapConfig(), capturable=use_graph)
+    step_fn = lambda: ba.step(window)
+    if use_graph:
+        from gslam_amd.mapping import GraphedBundleAdjuster
+        gba = GraphedBundleAdjuster(ba, window)
+        step_fn = gba.step
 
     def barrier():
         torch.cuda.synchronize()
@@ -200,11 +210,11 @@ def main():
     from gslam_amd.rasterization import validate
     for attempt in range(3):
         for _ in range(args.warmup):
-            ba.step(window)
+            step_fn()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            ba.step(window)
+            step_fn()
         barrier()
         elapsed = time.perf_counter() - t0
         # the render is sync-free (no M read-back inside a step); check afterwards that no step overflowed its
@@ -212,6 +222,9 @@ def main():
         if validate(dev):
             break
         print(f"bench.py: intersection capacity overflow on attempt {attempt}, re-running", file=sys.stderr)
+        if use_graph:
+            gba = GraphedBundleAdjuster(ba, window)
+            step_fn = gba.step
     else:
         raise RuntimeError("intersection buffers kept overflowing")
     if world > 1:
@@ -223,11 +236,17 @@ def main():
     value = world * args.steps / elapsed
 
     roofline, stages = None, None
-    if rank == 0 and not args.no_stage_timing:
-        with StageTimer() as st:
+    if not args.no_stage_timing:
+        # every rank runs the instrumented steps (they contain the collectives); only rank 0 keeps the timers
+        if rank == 0:
+            with StageTimer() as st:
+                for _ in range(10):
+                    ba.step(window)
+            stages = st.mean_us(skip=0)
+        else:
             for _ in range(10):
                 ba.step(window)
-        stages = st.mean_us(skip=0)
+    if rank == 0 and stages is not None:
         out = ba.last_outputs
         M = int(out.flatten_ids.shape[0])
         P = H * W
@@ -256,7 +275,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: 100k Gaussians, 640x480, render fwd+bwd (RGB+D+beta, CH=5) "
                                    "+ fused-SSIM + full mapping loss + fused Adam; 1 keyframe per GPU",
                        "gaussians": N, "width": W, "height": H, "keyframes_per_gpu": 1, "window": world,
-                       "parallelism": f"keyframe-sharded BA x{world}, 1 all-reduce of the [N,15] grad bucket"},
+                       "parallelism": f"keyframe-sharded BA x{world}, 1 all-reduce of the [N,15] grad bucket",
+                       "launch": "hip-graph replay of the whole step" if use_graph else "eager"},
         }
         if roofline is not None:
             line["roofline"] = roofline

@@ -52,8 +52,11 @@ PROTOTYPES = {
     "gsx_warp_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
     "gsx_warp_bwd_workspace_bytes": (i64, [i32, i32]),
     "gsx_warp_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),
+    "gsx_pose_zhou_fwd": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, vp]),
+    "gsx_pose_zhou_bwd": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, C.POINTER(vp),
+                                C.POINTER(vp), vp]),
     "gsx_adam_multi": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
-                             C.POINTER(f32), f32, f32, f32, i64, vp]),
+                             C.POINTER(f32), f32, f32, f32, i64, vp, vp]),
     "gsx_selftest": (i32, [vp, i64, vp]),
 }
 

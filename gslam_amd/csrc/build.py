@@ -25,6 +25,7 @@ SOURCES = {
     "ssim.hip": [],
     "loss.hip": [],
     "warp.hip": [],
+    "pose.hip": [],
     "misc.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",

@@ -52,19 +52,30 @@ __device__ __forceinline__ float gsx_wave_sum_dpp(float v) {
 // Interleaved partial reduction of N independent values: after the call, lanes 15/31/47/63 hold the sums of their
 // 16-lane DPP rows.  The N chains are advanced step by step so that consecutive DPP instructions are independent
 // (no s_nop wait states between a VALU write and the DPP read of the same register).
+// Written as inline asm (one v_add_f32_dpp per value and step): hipcc otherwise lowers about half of the steps to
+// v_mov_b32_dpp + v_add_f32.  Inline asm gets no automatic hazard padding, so the VALU-write -> DPP-read distance of
+// 2 wait states is kept by construction: N >= 3 interleaved chains, or an explicit s_nop between the steps.
 template <int N>
 __device__ __forceinline__ void gsx_row16_sum(float (&v)[N]) {
-#define GSX_ROW_STEP(ctrl)                                                                                   \
-    _Pragma("unroll") for (int k = 0; k < N; ++k) {                                                          \
-        const int x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k]), ctrl, 0xf, 0xf, true);   \
-        v[k] += __builtin_bit_cast(float, x);                                                                \
-    }
-    GSX_ROW_STEP(0x111)
-    GSX_ROW_STEP(0x112)
-    GSX_ROW_STEP(0x114)
-    GSX_ROW_STEP(0x118)
+#define GSX_ROW_STEP(SHR)                                                                                      \
+    if (N < 3) asm volatile("s_nop 1");                                                                        \
+    _Pragma("unroll") for (int k = 0; k < N; ++k)                                                              \
+        asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1"       \
+                     : "+v"(v[k]));
+    asm volatile("s_nop 1");  // the values were just produced by ordinary VALU instructions
+    GSX_ROW_STEP(1)
+    GSX_ROW_STEP(2)
+    GSX_ROW_STEP(4)
+    GSX_ROW_STEP(8)
+    if (N < 3) asm volatile("s_nop 1");
 #undef GSX_ROW_STEP
 }
+
+// 48-byte splat record fetched through the scalar data cache into SGPRs (uniform address): the broadcast of a
+// Gaussian to all 64 pixel lanes costs no VALU instruction and no LDS traffic.
+typedef float gsx_f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) gsx_f4 *gsx_cf4p;
+__device__ __forceinline__ gsx_cf4p gsx_scalar_ptr(const float *p) { return (gsx_cf4p)(uintptr_t)p; }
 
 __device__ __forceinline__ float gsx_wave_sum_shfl(float v) {
 #pragma unroll

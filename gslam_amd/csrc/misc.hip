@@ -164,13 +164,21 @@ struct AdamArgs {
     float *m[ADAM_MAX];
     float *v[ADAM_MAX];
     int64_t start[ADAM_MAX + 1];  // exclusive prefix of numels
-    float step_size[ADAM_MAX];    // lr / bias_correction1
+    float step_size[ADAM_MAX];    // lr / bias_correction1 (host-step mode)
+    float lr[ADAM_MAX];
+    const int64_t *step_dev;      // non-null: 1-based step lives on the device (graph-capturable)
     int count;
     float beta1, beta2, eps, bc2_sqrt;
 };
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
     const int64_t total = a.start[a.count];
+    float bc1 = 1.0f, bc2_sqrt = a.bc2_sqrt;
+    if (a.step_dev) {
+        const float t = (float)a.step_dev[0];
+        bc1 = 1.0f - powf(a.beta1, t);
+        bc2_sqrt = sqrtf(1.0f - powf(a.beta2, t));
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int k = 0;
 #pragma unroll
@@ -180,8 +188,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
         float m = a.m[k][j], v = a.v[k][j];
         m = m + (grad - m) * (1.0f - a.beta1);          // torch lerp form
         v = a.beta2 * v + (1.0f - a.beta2) * grad * grad;
-        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-        a.p[k][j] -= (a.step_size[k] * m) / denom;
+        const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+        const float step_size = a.step_dev ? a.lr[k] / bc1 : a.step_size[k];
+        a.p[k][j] -= (step_size * m) / denom;
         a.m[k][j] = m;
         a.v[k][j] = v;
     }
@@ -224,19 +233,22 @@ extern "C" int gsx_sh_bwd(int degree, const float *dirs, const float *coeffs, co
 
 extern "C" int gsx_adam_multi(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                               float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1,
-                              float beta2, float eps, int64_t step_host, void *stream) {
+                              float beta2, float eps, int64_t step_host, const int64_t *step_dev, void *stream) {
     GSX_CHECK_ARG(n_tensors >= 1 && n_tensors <= ADAM_MAX && params && grads && exp_avg && exp_avg_sq && numels && lrs);
-    GSX_CHECK_ARG(step_host >= 1);
+    GSX_CHECK_ARG(step_host >= 1 || step_dev);
     AdamArgs a;
     a.count = n_tensors;
     a.start[0] = 0;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step_host), bc2 = 1.0 - pow((double)beta2, (double)step_host);
+    a.step_dev = step_dev;
+    const double sh = (double)(step_host >= 1 ? step_host : 1);
+    const double bc1 = 1.0 - pow((double)beta1, sh), bc2 = 1.0 - pow((double)beta2, sh);
     for (int k = 0; k < ADAM_MAX; ++k) {
         const bool in = k < n_tensors;
         a.p[k] = in ? params[k] : nullptr; a.g[k] = in ? grads[k] : nullptr;
         a.m[k] = in ? exp_avg[k] : nullptr; a.v[k] = in ? exp_avg_sq[k] : nullptr;
         a.start[k + 1] = a.start[k] + (in ? numels[k] : 0);
         a.step_size[k] = in ? (float)((double)lrs[k] / bc1) : 0.f;
+        a.lr[k] = in ? lrs[k] : 0.f;
         if (in) GSX_CHECK_ARG(numels[k] >= 0 && (numels[k] == 0 || (params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k])));
     }
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.bc2_sqrt = (float)sqrt(bc2);

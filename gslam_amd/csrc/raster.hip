@@ -42,8 +42,47 @@ __device__ __forceinline__ Rec<RS> load_record(const float *__restrict__ rec, in
     return r;
 }
 
+// a splat record held in SGPRs (fetched with s_load_dwordx4 from a wave-uniform address)
+template <int RS>
+struct SRec {
+    gsx_f4 a, b, c;  // a = (mx, my, conic a, conic b)  b = (conic c, opacity, col0, col1)  c = (col2, col3, col4, pad)
+    __device__ __forceinline__ float color(int k) const {
+        switch (k) {
+            case 0: return b.z;
+            case 1: return b.w;
+            case 2: return c.x;
+            case 3: return c.y;
+            default: return c.z;
+        }
+    }
+};
+
+template <int RS>
+__device__ __forceinline__ SRec<RS> bcast_record(const float (&v)[RS], int j);
+
+template <int RS>
+__device__ __forceinline__ SRec<RS> sload_record(const float *__restrict__ rec, int g_uniform) {
+    const gsx_cf4p p = gsx_scalar_ptr(rec + (int64_t)g_uniform * RS);
+    SRec<RS> r;
+    r.a = p[0];
+    r.b = p[1];
+    if (RS > 8) r.c = p[2]; else r.c = gsx_f4{0.f, 0.f, 0.f, 0.f};
+    return r;
+}
+
 __device__ __forceinline__ float bcast(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// the same record broadcast out of lane j's VGPRs with v_readlane (no memory latency to hide, 1 VALU slot per float)
+template <int RS>
+__device__ __forceinline__ SRec<RS> bcast_record(const float (&v)[RS], int j) {
+    SRec<RS> r;
+    r.a = gsx_f4{bcast(v[0], j), bcast(v[1], j), bcast(v[2], j), bcast(v[3], j)};
+    r.b = gsx_f4{bcast(v[4], j), bcast(v[5], j), bcast(v[6], j), bcast(v[7], j)};
+    if (RS > 8) r.c = gsx_f4{bcast(v[8], j), bcast(v[9], j), bcast(v[10], j), 0.f};
+    else r.c = gsx_f4{0.f, 0.f, 0.f, 0.f};
+    return r;
 }
 
 // Can this Gaussian reach alpha >= 1/255 at ANY point of the rectangle [x0,x1]x[y0,y1] (pixel-centre coords)?
@@ -130,16 +169,15 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(const float *__restrict
         Rec<RS> r = load_record<RS>(rec, have ? g : 0);
         const bool maybe = have && may_touch(r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5], q.x0, q.y0, q.x1, q.y1);
         unsigned long long mask = __ballot(maybe);
+        // LANES = PIXELS from here on; the Gaussian's record is broadcast into scalar registers with v_readlane
+        // (measured faster here than re-fetching it through the scalar cache: nothing to wait for)
         while (mask != 0ull) {
             const int j = __ffsll((long long)mask) - 1;
             mask &= mask - 1ull;
-            // LANES = PIXELS from here on; the Gaussian's record is broadcast into scalar registers
-            const float mx = bcast(r.v[0], j), my = bcast(r.v[1], j);
-            const float ca = bcast(r.v[2], j), cb = bcast(r.v[3], j), cc = bcast(r.v[4], j);
-            const float opac = bcast(r.v[5], j);
-            const float dx = mx - q.fx, dy = my - q.fy;
-            const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
-            const float alpha = fminf(GSX_ALPHA_MAX, opac * __expf(-sigma));
+            const SRec<RS> cur = bcast_record<RS>(r.v, j);
+            const float dx = cur.a.x - q.fx, dy = cur.a.y - q.fy;
+            const float sigma = 0.5f * (cur.a.z * dx * dx + cur.b.x * dy * dy) + cur.a.w * dx * dy;
+            const float alpha = fminf(GSX_ALPHA_MAX, cur.b.y * __expf(-sigma));
             bool valid = !done && (sigma >= 0.0f) && (alpha >= GSX_ALPHA_MIN);
             const float nT = T * (1.0f - alpha);
             if (valid && nT <= GSX_T_MIN) { done = true; valid = false; }
@@ -149,7 +187,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(const float *__restrict
             }
             const float vis = valid ? alpha * T : 0.0f;
 #pragma unroll
-            for (int k = 0; k < CH; ++k) pix[k] += bcast(r.v[6 + k], j) * vis;
+            for (int k = 0; k < CH; ++k) pix[k] += cur.color(k) * vis;
             const bool touched = valid && (nT > vis_min_T);
             if (valid) { last = base + j; T = nT; }
             const unsigned long long tm = __ballot(touched);
@@ -165,7 +203,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(const float *__restrict
     }
 }
 
-template <int CH, int RS, bool ABS>
+template <int CH, int RS, bool ABS, bool SCALAR = false>
 __global__ __launch_bounds__(256) void raster_bwd_kernel(
     const float *__restrict__ rec, const float *__restrict__ bg, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ flatten_ids, int64_t M, int has_end, int W, int H, int tile_w, int tile_h,
@@ -200,7 +238,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
         buf[k] = 0.f;
         if (bg) bg_dot += bg[q.c * CH + k] * vo[k];
     }
-    const float va_out = q.inside ? v_alphas[p] : 0.f;
+    const float va_out = (q.inside && v_alphas) ? v_alphas[p] : 0.f;
 
     const int n = bmax - start + 1;
     const int n_batches = (n + 255) / 256;
@@ -222,47 +260,59 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
             Rec<RS> r = load_record<RS>(rec, g);
             const bool maybe = have && may_touch(r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5], q.x0, q.y0, q.x1, q.y1);
             unsigned long long mask = __ballot(maybe);
+            SRec<RS> nxt;
+            int jn = 0;
+            if (SCALAR && mask != 0ull) {
+                jn = 63 - __clzll((long long)mask);  // back to front
+                nxt = sload_record<RS>(rec, __builtin_amdgcn_readlane(g, jn));
+            }
             while (mask != 0ull) {
-                const int j = 63 - __clzll((long long)mask);  // back to front
-                mask &= ~(1ull << j);
-                const float mx = bcast(r.v[0], j), my = bcast(r.v[1], j);
-                const float a = bcast(r.v[2], j), bq = bcast(r.v[3], j), cq = bcast(r.v[4], j);
-                const float opac = bcast(r.v[5], j);
-                const float dx = mx - q.fx, dy = my - q.fy;
+                SRec<RS> cur;
+                int j;
+                if (SCALAR) {   // record re-fetched through the scalar cache, one entry ahead
+                    cur = nxt;
+                    j = jn;
+                    mask &= ~(1ull << j);
+                    if (mask != 0ull) {
+                        jn = 63 - __clzll((long long)mask);
+                        nxt = sload_record<RS>(rec, __builtin_amdgcn_readlane(g, jn));
+                    }
+                } else {        // record broadcast from lane j's registers
+                    j = 63 - __clzll((long long)mask);
+                    mask &= ~(1ull << j);
+                    cur = bcast_record<RS>(r.v, j);
+                }
+                const float a = cur.a.z, bq = cur.a.w, cq = cur.b.x, opac = cur.b.y;
+                const float dx = cur.a.x - q.fx, dy = cur.a.y - q.fy;
                 const float sigma = 0.5f * (a * dx * dx + cq * dy * dy) + bq * dx * dy;
                 const float vis = __expf(-sigma);
                 const float alpha = fminf(GSX_ALPHA_MAX, opac * vis);
                 const bool valid = (cbase + j <= last) && (sigma >= 0.0f) && (alpha >= GSX_ALPHA_MIN);
                 if (!__any(valid)) continue;
+                // branch-free: lanes that do not composite this entry carry fac = 0 and v_sigma = 0, so every
+                // product below is an exact zero for them and T / buf stay untouched
+                const float ra = valid ? __builtin_amdgcn_rcpf(1.0f - alpha) : 1.0f;
+                T *= ra;
+                const float fac = valid ? alpha * T : 0.0f;
                 float gr[NG];
+                float v_alpha = 0.f;
 #pragma unroll
-                for (int k = 0; k < NG; ++k) gr[k] = 0.f;
-                float gax = 0.f, gay = 0.f;
-                if (valid) {
-                    const float ra = 1.0f / (1.0f - alpha);
-                    T *= ra;
-                    const float fac = alpha * T;
-                    float v_alpha = 0.f;
-#pragma unroll
-                    for (int k = 0; k < CH; ++k) {
-                        const float ck = bcast(r.v[6 + k], j);
-                        gr[6 + k] = fac * vo[k];
-                        v_alpha += (ck * T - buf[k] * ra) * vo[k];
-                        buf[k] += ck * fac;
-                    }
-                    v_alpha += T_final * ra * va_out;
-                    v_alpha -= T_final * ra * bg_dot;
-                    if (opac * vis <= GSX_ALPHA_MAX) {
-                        const float v_sigma = -opac * vis * v_alpha;
-                        gr[2] = 0.5f * v_sigma * dx * dx;
-                        gr[3] = v_sigma * dx * dy;
-                        gr[4] = 0.5f * v_sigma * dy * dy;
-                        gr[0] = v_sigma * (a * dx + bq * dy);
-                        gr[1] = v_sigma * (bq * dx + cq * dy);
-                        gr[5] = vis * v_alpha;
-                        if (ABS) { gax = fabsf(gr[0]); gay = fabsf(gr[1]); }
-                    }
+                for (int k = 0; k < CH; ++k) {
+                    const float ck = cur.color(k);
+                    gr[6 + k] = fac * vo[k];
+                    v_alpha += (ck * T - buf[k] * ra) * vo[k];
+                    buf[k] += ck * fac;
                 }
+                v_alpha += T_final * ra * (va_out - bg_dot);
+                const bool g_ok = valid && (opac * vis <= GSX_ALPHA_MAX);   // alpha not clamped: sigma/opacity get gradient
+                const float v_sigma = g_ok ? -opac * vis * v_alpha : 0.0f;
+                gr[2] = 0.5f * v_sigma * dx * dx;
+                gr[3] = v_sigma * dx * dy;
+                gr[4] = 0.5f * v_sigma * dy * dy;
+                gr[0] = v_sigma * (a * dx + bq * dy);
+                gr[1] = v_sigma * (bq * dx + cq * dy);
+                gr[5] = g_ok ? vis * v_alpha : 0.0f;
+                const float gax = ABS ? fabsf(gr[0]) : 0.f, gay = ABS ? fabsf(gr[1]) : 0.f;
                 // 16-lane row sums of all NG entries, interleaved (DPP), then the four row leaders add into the
                 // entry's LDS accumulator row: one exec-mask change, NG ds_add_f32 with 4 active lanes each
                 const int slot = sub * 64 + j;
@@ -340,7 +390,7 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
                               const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
                               int tile_w, int tile_h, const float *alphas, const int32_t *last_ids,
                               const float *v_render, const float *v_alphas, float *v_rec, float *v_abs, void *stream) {
-    GSX_CHECK_ARG(offsets && alphas && last_ids && v_render && v_alphas && C >= 1 && W > 0 && H > 0);
+    GSX_CHECK_ARG(offsets && alphas && last_ids && v_render && C >= 1 && W > 0 && H > 0);  // v_alphas: NULL = 0
     GSX_CHECK_ARG(tile_w == (W + GSX_TILE - 1) / GSX_TILE && tile_h == (H + GSX_TILE - 1) / GSX_TILE);
     GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31));
     if (M == 0) return GSX_OK;
@@ -348,6 +398,8 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     const int64_t T = C * tile_w * tile_h;
     hipStream_t st = (hipStream_t)stream;
     const bool v1 = use_v1() && !offsets_has_end;
+    const char *sb = getenv("GSX_BWD_SCALAR");
+    const bool scalar_bwd = sb && sb[0] == '1';
 #define ARGS1 rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
 #define ARGS rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
 #define LAUNCH(ch, rs)                                                                                              \
@@ -355,9 +407,12 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
         if (v1) {                                                                                                   \
             if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS1); \
             else hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS1);      \
+        } else if (scalar_bwd) {                                                                                    \
+            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, true, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS);  \
+            else hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, false, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS);       \
         } else {                                                                                                    \
-            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS);    \
-            else hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS);         \
+            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, true, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS); \
+            else hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, false, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS);      \
         }                                                                                                           \
     } while (0)
     switch (CH) {

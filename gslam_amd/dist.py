@@ -32,7 +32,7 @@ def init_from_env(backend: str | None = None, device: torch.device | None = None
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kwargs = {}
-        if backend == "nccl" and device is not None:
+        if backend == "nccl" and device is not None and device.type == "cuda":
             kwargs["device_id"] = device
         td.init_process_group(backend=backend, **kwargs)
     return td.get_rank(), td.get_world_size()

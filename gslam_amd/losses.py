@@ -19,13 +19,23 @@ from .ops import workspace
 from .ssim import _strides
 
 
-class _FusedMappingLoss(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo, w_ssim,
-                w_iso, w_tv, mode):
-        """returns (total, photometric) as 0-dim tensors.
-        total = w_photo * photometric + w_ssim * (1 - ssim) + w_iso * isotropic + w_tv * tv"""
-        render, gt = render.contiguous(), gt.contiguous()
+def loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo, w_ssim, w_iso,
+                   w_tv, mode):
+    """Raw fused block (no autograd): returns (out2, v_render, v_exposure, v_log_scales) where out2[0] = total =
+    w_photo * photometric + w_ssim * (1 - ssim) + w_iso * isotropic + w_tv * tv and out2[1] = photometric, all on the
+    device; the v_* are d total / d input."""
+    with torch.no_grad():
+        render, gt = render.detach().contiguous(), gt.contiguous()
+        exposure = exposure.detach()
+        if log_scales is not None:
+            log_scales = log_scales.detach()
+        return _loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo,
+                               w_ssim, w_iso, w_tv, mode)
+
+
+def _loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo, w_ssim, w_iso,
+                    w_tv, mode):
+    if True:
         exposure = exposure.contiguous()
         Cn, H, W, CH = render.shape
         dev = render.device
@@ -74,6 +84,17 @@ class _FusedMappingLoss(torch.autograd.Function):
         c0 = (C.c_float * 5)(w_photo * pm, w_photo * pm, w_tv, -w_ssim / numel_ssim, w_iso)
         c1 = (C.c_float * 5)(pm, pm, 0.0, 0.0, 0.0)
         check(lib.gsx_combine_terms(5, terms, c0, c1, w_ssim, 0.0, ptr(out2), st), "gsx_combine_terms")
+        return out2, v_render, v_exposure, v_scales
+
+
+class _FusedMappingLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo, w_ssim,
+                w_iso, w_tv, mode):
+        """returns (total, photometric) as 0-dim tensors"""
+        out2, v_render, v_exposure, v_scales = loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count,
+                                                              depth_index, beta_index, w_photo, w_ssim, w_iso, w_tv,
+                                                              mode)
         ctx.save_for_backward(v_render, v_exposure, v_scales)
         total, photo = out2[0].clone(), out2[1].clone()
         ctx.mark_non_differentiable(photo)
@@ -111,6 +132,20 @@ def fused_mapping_loss(outputs, gt_imgs: Tensor, exposure_params: Tensor, log_sc
                                    -1 if outputs._betas_index is None else outputs._betas_index,
                                    shard * (1.0 - ssim_weight), shard * ssim_weight, iso_scale * iso_weight, tv_weight,
                                    0 if active_gs else 1)
+
+
+def mapping_loss_and_grads(outputs, gt_imgs: Tensor, exposure_params: Tensor, log_scales: Tensor, *, ssim_weight: float,
+                           iso_weight: float, tv_weight: float, active_gs: bool = True, shard: float = 1.0,
+                           iso_scale: float = 1.0, vis_count: Optional[Tensor] = None):
+    """Same numbers as fused_mapping_loss without the autograd node: (out2[total, photometric], v_render, v_exposure,
+    v_log_scales).  The caller seeds the backward with ``torch.autograd.backward([outputs._render], [v_render])``."""
+    if vis_count is None:
+        vis_count = outputs._vis_count
+    return loss_and_grads(outputs._render, outputs.alphas, gt_imgs, exposure_params, log_scales, vis_count,
+                          -1 if outputs._depth_index is None else outputs._depth_index,
+                          -1 if outputs._betas_index is None else outputs._betas_index,
+                          shard * (1.0 - ssim_weight), shard * ssim_weight, iso_scale * iso_weight, tv_weight,
+                          0 if active_gs else 1)
 
 
 def fused_tracking_loss(outputs, gt_img: Tensor, exposure_params: Tensor):

@@ -6,7 +6,7 @@ from typing import List
 
 import torch
 
-from .primitives import Camera, Pose
+from .primitives import Camera, Pose, pose_batch
 from .rasterization import RasterizationOutput, rasterization
 from .utils import create_batch
 
@@ -31,14 +31,23 @@ class GaussianSplattingData(torch.nn.Module):
             means=self.means, quats=self.quats, log_scales=self.scales, logit_opacities=self.opacities,
             logit_colors=self.colors, viewmats=viewmats, Ks=Ks, width=cameras[0].width, height=cameras[0].height,
             render_mode=render_mode, packed=False, log_uncertainties=self.log_uncertainties,
-            visibility_min_T=visibility_min_T, backgrounds=self.background.tile([len(cameras), 1]))
+            visibility_min_T=visibility_min_T, backgrounds=self._backgrounds(len(cameras)))
+
+    def _backgrounds(self, n_cams: int) -> torch.Tensor:
+        """self.background.tile([C, 1]) (map.py:73,102), cached per (C, buffer version)"""
+        key = (n_cams, self.background._version, self.background.data_ptr())
+        cache = self.__dict__.setdefault("_bg_cache", {})
+        if key not in cache:
+            cache.clear()
+            cache[key] = self.background.tile([n_cams, 1])
+        return cache[key]
 
     def render(self, cameras: List[Camera], viewmats: List[torch.Tensor], visibility_min_T: float = 0.5):
         return self._render(cameras, create_batch(viewmats), 'RGB+D', visibility_min_T)
 
     def forward(self, cameras: List[Camera], poses: List[Pose], render_depth: bool = False,
                 visibility_min_T: float = 0.5) -> RasterizationOutput:
-        viewmats = create_batch(poses, lambda x: x())
+        viewmats = pose_batch(poses)                                     # = create_batch(poses, lambda x: x())
         return self._render(cameras, viewmats, 'RGB+D' if render_depth else 'RGB', visibility_min_T)
 
     @staticmethod

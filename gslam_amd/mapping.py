@@ -15,7 +15,7 @@ import torch
 
 from . import dist as gdist
 from ._lib import check, lib, ptr, stream_ptr
-from .losses import fused_mapping_loss
+from .losses import fused_mapping_loss, mapping_loss_and_grads
 from .map import GaussianSplattingData
 from .optim import FusedAdam
 from .primitives import Frame
@@ -80,10 +80,11 @@ def mapping_loss(splats: GaussianSplattingData, outputs: RasterizationOutput, gt
 class MapOptimizers:
     """The six splat Adams + the pose Adam of backend.py:554-602,665-670 as two multi-tensor launches."""
 
-    def __init__(self, splats: GaussianSplattingData, conf: MapConfig):
+    def __init__(self, splats: GaussianSplattingData, conf: MapConfig, capturable: bool = False):
         self.conf = conf
+        self.capturable = capturable
         self.splat_opt = FusedAdam([{"params": [getattr(splats, name)], "lr": getattr(conf, lr)}
-                                    for name, lr in SPLAT_LRS])
+                                    for name, lr in SPLAT_LRS], capturable=capturable)
         self.pose_opt: Optional[FusedAdam] = None
         self._pose_ids = set()
 
@@ -94,7 +95,7 @@ class MapOptimizers:
         self._pose_ids.update(id(p) for p in params)
         group = {"params": params, "lr": self.conf.pose_optim_lr if lr is None else lr}
         if self.pose_opt is None:
-            self.pose_opt = FusedAdam([group])
+            self.pose_opt = FusedAdam([group], capturable=self.capturable)
         else:
             self.pose_opt.add_param_group(group)
 
@@ -112,11 +113,12 @@ class MapOptimizers:
 class BundleAdjuster:
     """One object per process/GPU.  ``step(window)`` is one iteration of the loop at backend.py:260-359."""
 
-    def __init__(self, splats: GaussianSplattingData, conf: Optional[MapConfig] = None, fused_loss: bool = True):
+    def __init__(self, splats: GaussianSplattingData, conf: Optional[MapConfig] = None, fused_loss: bool = True,
+                 capturable: bool = False):
         self.splats = splats
         self.conf = conf or MapConfig()
         self.fused_loss = fused_loss
-        self.optimizers = MapOptimizers(splats, self.conf)
+        self.optimizers = MapOptimizers(splats, self.conf, capturable=capturable)
         self.shard = gdist.KeyframeShard()
         self.bucket = gdist.GradBucket(splats) if self.shard.world_size > 1 else None
         self.total_step = 0
@@ -140,18 +142,27 @@ class BundleAdjuster:
         vis_count = outputs._vis_count                                  # = (radii > 0).sum(0), from K1
         if self.shard.world_size > 1:
             vis_count = self.shard.all_reduce_sum(vis_count.clone())
+        outputs.means2d.retain_grad()                                   # backend.py:326
         if self.fused_loss:
-            total, photometric = fused_mapping_loss(
+            # value and analytic gradient in one pass (csrc/loss.hip); the backward is seeded at the render tensor
+            out2, v_render, v_exposure, v_scales = mapping_loss_and_grads(
                 outputs, gt_imgs, exposure, self.splats.scales, ssim_weight=conf.ssim_weight,
                 iso_weight=conf.isotropic_regularization_weight,
                 tv_weight=conf.depth_regularization_weight if regularize else 0.0, active_gs=conf.active_gs,
                 shard=len(mine) / float(len(window)), iso_scale=1.0 / self.shard.world_size, vis_count=vis_count)
+            total, photometric = out2[0], out2[1]
+            torch.autograd.backward([outputs._render], [v_render])
+            if v_scales is not None:
+                self.splats.scales.grad.add_(v_scales)
+            for i, f in enumerate(mine):
+                if f.exposure_params.requires_grad:
+                    f.exposure_params.grad = v_exposure[i] if f.exposure_params.grad is None \
+                        else f.exposure_params.grad + v_exposure[i]
         else:
             total, photometric = mapping_loss(self.splats, outputs, gt_imgs, exposure, conf, regularize,
                                               c_total=len(window), visible_gaussians=vis_count > 0,
                                               iso_scale=1.0 / self.shard.world_size)
-        outputs.means2d.retain_grad()                                   # backend.py:326
-        total.backward()
+            total.backward()
         if self.bucket is not None:
             self.bucket.all_reduce()
         self.optimizers.step()
@@ -183,3 +194,35 @@ class BundleAdjuster:
             for f, d in zip(self.shard.select(window), outputs.depthmaps):
                 f.est_depths = d.detach().clone()
         return last
+
+
+class GraphedBundleAdjuster:
+    """A BA iteration over a FIXED window captured once into a HIP graph and replayed: the ~60 launches of a step
+    (pose chain, K1, binning, sort, K8, SSIM, loss, K9, K2, Adam, decay) cost one graph launch on the host.  Needs a
+    single-GPU BundleAdjuster built with capturable=True; the window's tensors (images, poses, exposure) are updated
+    in place between replays.  ``validate()`` (gslam_amd.rasterization) must be polled by the caller: the intersection
+    capacity is baked into the graph."""
+
+    def __init__(self, ba: BundleAdjuster, window: List[Frame], warmup: int = 3, regularize: bool = True):
+        assert ba.shard.world_size == 1, "graph capture is single-GPU; multi-GPU BA runs eagerly around the all-reduce"
+        assert ba.optimizers.capturable, "build the BundleAdjuster with capturable=True"
+        from .rasterization import validate
+        self.ba, self.window = ba, window
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 2)):
+                ba.step(window, regularize)
+            if not validate():                      # capacity grew: one more eager pass with the final capacity
+                ba.step(window, regularize)
+                assert validate()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.total, self.photometric = ba.step(window, regularize)
+
+    def step(self):
+        self.graph.replay()
+        self.ba.total_step += 1
+        return self.total, self.photometric

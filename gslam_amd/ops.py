@@ -87,6 +87,7 @@ class _Projection(torch.autograd.Function):
                               logit_opac if want_rec else None, logit_colors if want_rec else None,
                               log_unc if want_rec else None)
         ctx.cfg = (width, height, eps2d, near_plane, far_plane, flags, want_rec, calc_comp)
+        ctx.set_materialize_grads(False)        # undefined output grads arrive as None, not as zero-filled tensors
         ctx.mark_non_differentiable(radii)
         if tiles is not None:
             ctx.mark_non_differentiable(tiles)
@@ -96,6 +97,8 @@ class _Projection(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, v_rec, _v_tiles, _v_vis):
+        if v_means2d is None and v_depths is None and v_conics is None and v_comps is None and v_rec is None:
+            return (None,) * 19
         means, quats, scales, viewmats, Ks, radii, logit_opac, logit_colors, log_unc = ctx.saved_tensors
         width, height, eps2d, near_plane, far_plane, flags, want_rec, calc_comp = ctx.cfg
         N, Cn = means.shape[0], viewmats.shape[0]
@@ -292,6 +295,7 @@ class _RasterizeRecords(torch.autograd.Function):
                                  width, height, tile_w, tile_h, vis_min_T, ptr(render), ptr(alphas), ptr(last_ids),
                                  ptr(n_touched), stream_ptr(dev)), "gsx_raster_fwd")
         ctx.save_for_backward(rec, bg, offsets, flatten_ids, alphas, last_ids)
+        ctx.set_materialize_grads(False)
         ctx.cfg = (ch, width, height, absgrad, has_end)
         ctx.means2d_ref = means2d if absgrad else None
         ctx.mark_non_differentiable(n_touched, last_ids)
@@ -304,9 +308,11 @@ class _RasterizeRecords(torch.autograd.Function):
         Cn, N, RS = rec.shape
         dev = rec.device
         tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
+        if v_render is None and v_alphas is None:
+            return (None,) * 12
         v_render = torch.zeros_like(alphas).expand(-1, -1, -1, ch).contiguous() if v_render is None \
             else v_render.contiguous()
-        v_alphas = torch.zeros_like(alphas) if v_alphas is None else v_alphas.contiguous()
+        v_alphas = None if v_alphas is None else v_alphas.contiguous()      # NULL = zero gradient (kernel-side)
         v_rec = torch.zeros(Cn, N, RS, dtype=torch.float32, device=dev)
         v_abs = torch.zeros(Cn, N, 2, dtype=torch.float32, device=dev) if absgrad else None
         check(lib.gsx_raster_bwd(ptr(rec), ch, ptr(bg), ptr(offsets), ptr(flatten_ids), flatten_ids.shape[0],
@@ -336,6 +342,8 @@ class _PackRecords(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_rec):
+        if v_rec is None:
+            return None, None, None, None
         ch = ctx.ch
         # xy / conic columns are delivered through the pass-through inputs of _RasterizeRecords
         return None, None, v_rec[..., 6:6 + ch], v_rec[..., 5]
@@ -389,6 +397,8 @@ class _SphericalHarmonics(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_colors):
+        if v_colors is None:
+            return None, None, None, None
         dirs, coeffs, radii = ctx.saved_tensors
         Cn, N = dirs.shape[:2]
         Kc = coeffs.shape[1]

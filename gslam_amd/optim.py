@@ -15,8 +15,22 @@ _MAX = 8
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 capturable: bool = False):
+        """capturable=True keeps the step counter on the device (one int64 per parameter, like torch's capturable
+        Adam) so that ``step()`` can be captured into a HIP graph and replayed."""
+        self.capturable = capturable
+        self._shared_step = None          # device step shared by the groups given at construction
+        self._constructing = True
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._constructing = False
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        g = self.param_groups[-1]
+        g["_host_step"] = 0
+        g["_step_dev"] = None
+        g["_shared"] = self._constructing
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -26,30 +40,47 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         # bucket by (betas, eps, step) so that every launch shares its scalar state
         buckets: dict = {}
+        bumped = set()
         for group in self.param_groups:
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
+                continue
+            group["_host_step"] += 1
+            step_dev = None
+            if self.capturable:
+                dev0 = live[0].device
+                if group["_shared"]:
+                    if self._shared_step is None:
+                        self._shared_step = torch.full((1,), group["_host_step"] - 1, dtype=torch.int64, device=dev0)
+                    step_dev = self._shared_step
+                else:
+                    if group["_step_dev"] is None:
+                        group["_step_dev"] = torch.full((1,), group["_host_step"] - 1, dtype=torch.int64, device=dev0)
+                    step_dev = group["_step_dev"]
+                if id(step_dev) not in bumped:
+                    step_dev += 1
+                    bumped.add(id(step_dev))
+            for p in live:
                 st = self.state[p]
                 if not st:
-                    st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
                 if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32):
                     raise RuntimeError("FusedAdam needs contiguous float32 parameters on the GPU (no CPU fallback)")
-                key = (group["betas"], group["eps"], st["step"], p.device)
-                buckets.setdefault(key, []).append((p, p.grad.contiguous(), st, float(group["lr"])))
-        for (betas, eps, step, dev), items in buckets.items():
+                key = (group["betas"], group["eps"], 0 if self.capturable else group["_host_step"], p.device,
+                       id(step_dev))
+                buckets.setdefault(key, []).append((p, p.grad.contiguous(), st, float(group["lr"]), step_dev))
+        for (betas, eps, step, dev, _sid), items in buckets.items():
             for i in range(0, len(items), _MAX):
                 chunk = items[i:i + _MAX]
                 n = len(chunk)
                 arr = lambda xs: (C.c_void_p * n)(*xs)
                 check(lib.gsx_adam_multi(
-                    n, arr([p.data_ptr() for p, _, _, _ in chunk]), arr([g.data_ptr() for _, g, _, _ in chunk]),
-                    arr([s["exp_avg"].data_ptr() for _, _, s, _ in chunk]),
-                    arr([s["exp_avg_sq"].data_ptr() for _, _, s, _ in chunk]),
-                    (C.c_int64 * n)(*[p.numel() for p, _, _, _ in chunk]),
-                    (C.c_float * n)(*[lr for _, _, _, lr in chunk]),
-                    float(betas[0]), float(betas[1]), float(eps), int(step), stream_ptr(dev)), "gsx_adam_multi")
+                    n, arr([c_[0].data_ptr() for c_ in chunk]), arr([c_[1].data_ptr() for c_ in chunk]),
+                    arr([c_[2]["exp_avg"].data_ptr() for c_ in chunk]),
+                    arr([c_[2]["exp_avg_sq"].data_ptr() for c_ in chunk]),
+                    (C.c_int64 * n)(*[c_[0].numel() for c_ in chunk]),
+                    (C.c_float * n)(*[c_[3] for c_ in chunk]),
+                    float(betas[0]), float(betas[1]), float(eps), int(step),
+                    chunk[0][4].data_ptr() if self.capturable else None, stream_ptr(dev)), "gsx_adam_multi")
         return loss

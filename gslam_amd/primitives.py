@@ -44,6 +44,57 @@ class PoseZhou(torch.nn.Module):
 Pose = PoseZhou  # gslam/map.py:5 imports the pose type under this name
 
 
+class _PoseBatch(torch.autograd.Function):
+    """viewmats [C,4,4] of C PoseZhou modules in one launch (csrc/pose.hip); inputs are (Rt_0, dR_0, dt_0, Rt_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, learnable, *tensors):
+        import ctypes as C
+        from ._lib import check, lib, stream_ptr
+        n = len(learnable)
+        Rts, dRs, dts = tensors[0::3], tensors[1::3], tensors[2::3]
+        dev = Rts[0].device
+        out = torch.empty(n, 4, 4, dtype=torch.float32, device=dev)
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        check(lib.gsx_pose_zhou_fwd(n, arr(Rts), arr(dRs), arr(dts), (C.c_int * n)(*learnable), out.data_ptr(),
+                                    stream_ptr(dev)), "gsx_pose_zhou_fwd")
+        ctx.learnable = learnable
+        ctx.save_for_backward(*tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_view):
+        import ctypes as C
+        from ._lib import check, lib, stream_ptr
+        tensors = ctx.saved_tensors
+        learnable = ctx.learnable
+        n = len(learnable)
+        Rts, dRs, dts = tensors[0::3], tensors[1::3], tensors[2::3]
+        dev = v_view.device
+        v_dR = [torch.empty_like(t) for t in dRs]
+        v_dt = [torch.empty_like(t) for t in dts]
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        check(lib.gsx_pose_zhou_bwd(n, arr(Rts), arr(dRs), arr(dts), (C.c_int * n)(*learnable),
+                                    v_view.contiguous().data_ptr(), arr(v_dR), arr(v_dt), stream_ptr(dev)),
+              "gsx_pose_zhou_bwd")
+        grads = [None]
+        for i in range(n):
+            grads += [None, v_dR[i] if learnable[i] else None, v_dt[i] if learnable[i] else None]
+        return tuple(grads)
+
+
+def pose_batch(poses) -> torch.Tensor:
+    """== torch.stack([p() for p in poses]) for PoseZhou modules, as one HIP launch (and one for the backward)."""
+    poses = list(poses)
+    if (len(poses) > 16 or not all(isinstance(p, PoseZhou) for p in poses) or not poses[0].Rt.is_cuda
+            or any(p.Rt.dtype != torch.float32 for p in poses)):
+        return torch.stack([p() for p in poses], dim=0)
+    flat = []
+    for p in poses:
+        flat += [p.Rt.contiguous(), p.dR, p.dt]
+    return _PoseBatch.apply(tuple(1 if p.is_learnable else 0 for p in poses), *flat)
+
+
 @dataclass
 class Camera:
     intrinsics: torch.Tensor

@@ -43,7 +43,7 @@ class RasterizationOutput:
         self._isect_ids, self._flatten_ids, self.isect_offsets = isect_ids, flatten_ids, isect_offsets
         self.width, self.height, self.tile_size, self.n_cameras = width, height, tile_size, n_cameras
         self.camera_ids, self.gaussian_ids, self.radii, self.means2d = camera_ids, gaussian_ids, radii, means2d
-        self.depths, self.conics, self.opacities, self.n_touched = depths, conics, opacities, n_touched
+        self.depths, self.conics, self.opacities, self._n_touched = depths, conics, opacities, n_touched
         self._lazy = None      # (_IsectBuffers, generation) when the id arrays live in capacity-sized buffers
         self._render = self._depth_index = self._betas_index = self._vis_count = None
 
@@ -57,6 +57,17 @@ class RasterizationOutput:
             self._flatten_ids = flat[:M]
             self._isect_ids = ops.rebuild_isect_ids(self, M)
             self._lazy = None
+
+    @property
+    def n_touched(self):
+        """int64 like the reference's ``n_touched.long()`` (rasterization.py:352); converted on first access"""
+        if self._n_touched is not None and self._n_touched.dtype != torch.int64:
+            self._n_touched = self._n_touched.long()
+        return self._n_touched
+
+    @n_touched.setter
+    def n_touched(self, v):
+        self._n_touched = v
 
     @property
     def flatten_ids(self):
@@ -85,6 +96,7 @@ class _IsectPool:
         self._event: Optional[torch.cuda.Event] = None
         self.overflowed = False
         self.last_M = 0
+        self._graph_M = None
 
     def ensure(self, estimate: int):
         want = int(estimate * self.GROW) + 4096
@@ -110,6 +122,11 @@ class _IsectPool:
                 self.ensure(M)
         return ok
 
+    def note_captured(self, M_dev: Tensor):
+        """a render captured into a HIP graph cannot post its own async read-back; remember where its M lives so that
+        validate() can read it after replays"""
+        self._graph_M = M_dev
+
     def post(self, M_dev: Tensor):
         self._staging[0:1].copy_(M_dev)
         self._staging[1:2].copy_(self.status)
@@ -119,6 +136,32 @@ class _IsectPool:
 
 
 _POOLS: dict = {}
+_BG_CACHE: dict = {}
+
+
+def _packed_backgrounds(backgrounds: Optional[Tensor], C: int, with_depth: bool, with_beta: bool) -> Optional[Tensor]:
+    """[C,3] -> [C,CH]: + 0 for depth + e^1 for beta (rasterization.py:236-239,251-255).  Cached while the caller
+    keeps passing the same (unmodified) tensor, which is what map.py does every render."""
+    if backgrounds is None:
+        return None
+    if not (with_depth or with_beta):
+        return backgrounds
+    key = (backgrounds.data_ptr(), backgrounds._version, C, with_depth, with_beta, backgrounds.requires_grad)
+    hit = _BG_CACHE.get(key)
+    if hit is not None and not backgrounds.requires_grad:
+        return hit
+    parts = [backgrounds]
+    if with_depth:
+        parts.append(torch.zeros(C, 1, device=backgrounds.device, dtype=backgrounds.dtype))
+    if with_beta:
+        parts.append(torch.full((C, 1), math.e, device=backgrounds.device, dtype=backgrounds.dtype))
+    bg = torch.cat(parts, dim=-1)
+    if not backgrounds.requires_grad:
+        if len(_BG_CACHE) > 16:
+            _BG_CACHE.clear()
+        _BG_CACHE[key] = bg
+        _BG_CACHE[("keepalive",) + key] = backgrounds      # pin the id / data_ptr while cached
+    return bg
 
 
 def _pool(dev) -> _IsectPool:
@@ -137,6 +180,14 @@ def validate(device=None) -> bool:
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     p = _pool(dev)
     p.poll(block=True)
+    if p._graph_M is not None:                      # renders replayed from a HIP graph: status is sticky on the device
+        st = int(p.status.item())
+        p.last_M = int(p._graph_M.item())
+        if st & 1:
+            p.overflowed = True
+            p.capacity = int(p.last_M * p.GROW) + 4096
+            p.status.zero_()
+            p._graph_M = None                       # the captured graph is stale (capacity baked in): re-capture
     bad = p.overflowed
     p.overflowed = False
     return not bad
@@ -214,14 +265,7 @@ def rasterization(
         True)
 
     # backgrounds: [C,3] + 0 for depth + e^1 for beta (rasterization.py:236-239,251-255)
-    bg = None
-    if backgrounds is not None:
-        parts = [backgrounds]
-        if depth_index is not None:
-            parts.append(torch.zeros(C, 1, device=backgrounds.device, dtype=backgrounds.dtype))
-        if betas_index is not None:
-            parts.append(torch.full((C, 1), math.e, device=backgrounds.device, dtype=backgrounds.dtype))
-        bg = torch.cat(parts, dim=-1) if len(parts) > 1 else backgrounds
+    bg = _packed_backgrounds(backgrounds, C, depth_index is not None, betas_index is not None)
 
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
@@ -236,15 +280,22 @@ def rasterization(
         raster_offsets, has_end = isect_offsets, False
     else:
         pool = _pool(dev)
-        pool.poll()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            pool.poll()
         if pool.capacity == 0:
+            if capturing:
+                raise RuntimeError("render once eagerly before capturing a HIP graph (intersection capacity probe)")
             pool.ensure(int(tiles_per_gauss.sum().item()))      # first render on this device: one probe
         cap = pool.capacity
         flat_buf = torch.empty(cap, dtype=torch.int32, device=dev)
         with torch.no_grad():
             off1, M_dev, _ = ops.isect_bin_sort(means2d.detach(), radii, depths.detach(), tile_width, tile_height, cap,
                                                 None, flat_buf, status=pool.status)
-        pool.post(M_dev)
+        if not capturing:
+            pool.post(M_dev)
+        else:
+            pool.note_captured(M_dev)
         isect_offsets = off1[:-1].view(C, tile_height, tile_width)
         raster_offsets, has_end, flatten_ids, isect_ids = off1, True, flat_buf, None
         lazy = (pool, M_dev, flat_buf, True)
@@ -259,7 +310,7 @@ def rasterization(
         tile_width=tile_width, tile_height=tile_height, tiles_per_gauss=tiles_per_gauss, isect_ids=isect_ids,
         flatten_ids=flatten_ids, isect_offsets=isect_offsets, width=width, height=height, tile_size=tile_size,
         n_cameras=C, camera_ids=None, gaussian_ids=None, radii=radii, means2d=means2d, depths=depths, conics=conics,
-        opacities=rec[..., 5], n_touched=n_touched.long(),
+        opacities=rec[..., 5], n_touched=n_touched,
     )
     out._lazy = lazy
     if depth_index is not None:

@@ -25,6 +25,7 @@ class _WarpFn(torch.autograd.Function):
         check(lib.gsx_warp_fwd(ptr(T), ptr(K), ptr(Kinv), ptr(c1), ptr(d1), H, W, ptr(result), ptr(nwarps), ptr(keep),
                                stream_ptr(dev)), "gsx_warp_fwd")
         ctx.save_for_backward(T, K, Kinv, c1, d1)
+        ctx.set_materialize_grads(False)
         keep = keep.bool()
         ctx.mark_non_differentiable(keep)
         return result, nwarps, keep
@@ -34,6 +35,8 @@ class _WarpFn(torch.autograd.Function):
         T, K, Kinv, c1, d1 = ctx.saved_tensors
         H, W = d1.shape
         dev = T.device
+        if v_result is None and v_nwarps is None:
+            return None, None, None, None, None
         v_result = torch.zeros(H, W, 3, dtype=torch.float32, device=dev) if v_result is None else v_result.contiguous()
         v_nwarps = None if v_nwarps is None else v_nwarps.contiguous()
         v_T = torch.empty(4, 4, dtype=torch.float32, device=dev)

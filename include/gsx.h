@@ -136,7 +136,8 @@ int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds /*[C,CH] n
                    float visibility_min_T, float *render, float *alphas, int32_t *last_ids, int32_t *n_touched,
                    void *stream);
 /* ---- K9: rasterize_to_pixels bwd.  v_rec [C*N, stride] must be zeroed by the caller; gradients are accumulated
- * in record layout: v_xy(2) v_conic(3) v_opacity(1) v_colors(CH).  v_abs (nullable, [C*N,2], zeroed): absgrad.   */
+ * in record layout: v_xy(2) v_conic(3) v_opacity(1) v_colors(CH).  v_abs (nullable, [C*N,2], zeroed): absgrad.
+ * v_alphas nullable (= zero gradient).                                                                              */
 int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
                    const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H, int tile_w,
                    int tile_h,
@@ -198,12 +199,21 @@ int gsx_warp_bwd(const float *T, const float *K, const float *Kinv, const float 
                  const float *v_result, const float *v_nwarps /*nullable*/, float *v_T /*[4,4] overwritten*/,
                  void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- PoseZhou for a window of <= 16 poses in one launch (gslam/primitives.py:15-36,82-92).  Rt/dR/dt (and v_dR/v_dt)
+ * are HOST arrays of device pointers, one per pose ([4,4], [6], [3]); learnable: host int[C] (0 -> viewmat = Rt). */
+int gsx_pose_zhou_fwd(int C, const float *const *Rt, const float *const *dR, const float *const *dt,
+                      const int *learnable, float *viewmats /*[C,4,4]*/, void *stream);
+int gsx_pose_zhou_bwd(int C, const float *const *Rt, const float *const *dR, const float *const *dt,
+                      const int *learnable, const float *v_viewmats, float *const *v_dR, float *const *v_dt,
+                      void *stream);
+
 /* ---- fused Adam (torch.optim.Adam(fused=True) defaults; gslam/backend.py:565-602).  Up to 8 tensors per launch.
  * step_dev: device int64 holding the 1-based step AFTER increment is step_dev[0]+1; kernel does not modify it
  * when step_host > 0 (then step_host is used).                                                                      */
 int gsx_adam_multi(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                    float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1, float beta2,
-                   float eps, int64_t step_host, void *stream);
+                   float eps, int64_t step_host, const int64_t *step_dev /*nullable device int64: overrides step_host*/,
+                   void *stream);
 
 /* ---- self tests of device primitives (wave64 reductions); returns 0 if all pass.  scratch: >= 64 KiB device ----- */
 int gsx_selftest(void *scratch, int64_t scratch_bytes, void *stream);

@@ -93,6 +93,12 @@ def main():
                 res.setdefault(("fwd", ver), []).append(timed(fwd))
                 res.setdefault(("bwd", ver), []).append(timed(bwd))
         os.environ["GSX_RASTER_V1"] = "0"
+        for rnd in range(2):
+            for sc_ in ("1", "0"):
+                os.environ["GSX_BWD_SCALAR"] = sc_
+                bwd()
+                res.setdefault(("bwd-scalar" if sc_ == "1" else "bwd-readlane", "0"), []).append(timed(bwd))
+        os.environ["GSX_BWD_SCALAR"] = "0"
         for k, v in sorted(res.items()):
             print(f"  raster_{k[0]} {'v1' if k[1] == '1' else 'v2'}: median/min us per round = "
                   + ", ".join(f"{a:.1f}/{b:.1f}" for a, b in v))
