@@ -193,7 +193,7 @@ def main():
     own = {c for c in range(world) if c % world == rank}
     window = make_window(world, W, H, dev, gt_scene, own)
     del gt_scene
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = not args.no_graph
     ba = BundleAdjuster(splats, MapConfig(), capturable=use_graph)
     step_fn = lambda: ba.step(window)
     if use_graph:
@@ -276,7 +276,8 @@ def main():
                                    "+ fused-SSIM + full mapping loss + fused Adam; 1 keyframe per GPU",
                        "gaussians": N, "width": W, "height": H, "keyframes_per_gpu": 1, "window": world,
                        "parallelism": f"keyframe-sharded BA x{world}, 1 all-reduce of the [N,15] grad bucket",
-                       "launch": "hip-graph replay of the whole step" if use_graph else "eager"},
+                       "launch": ("eager" if not use_graph else "hip-graph replay of the whole step" if world == 1 else
+                                  "hip-graph replay (render+loss+backward | Adam) around one eager all-reduce")},
         }
         if roofline is not None:
             line["roofline"] = roofline

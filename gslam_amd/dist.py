@@ -82,11 +82,14 @@ class GradBucket:
         params = [getattr(self.splats, n) for n in GRAD_PARAMS]
         self._shapes = [tuple(p.shape) for p in params]
         total = sum(p.numel() for p in params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        n = params[0].shape[0]
+        # [N*15] gradients + [N] per-Gaussian visible-camera counts riding as a 16th fp32 column (exact: counts <= C)
+        self.flat = torch.zeros(total + n, dtype=torch.float32, device=params[0].device)
         self.views, off = [], 0
         for p in params:
             self.views.append(self.flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
+        self.counts = self.flat[off:off + n]
 
     def attach_zeroed(self):
         params = [getattr(self.splats, n) for n in GRAD_PARAMS]

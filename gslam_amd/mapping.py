@@ -125,10 +125,19 @@ class BundleAdjuster:
         self.last_outputs: Optional[RasterizationOutput] = None
 
     def step(self, window: List[Frame], regularize: bool = True, decay_opacity: bool = True):
-        """window = ALL keyframes of the BA window (every rank passes the same list); this rank renders its shard."""
+        """window = ALL keyframes of the BA window (every rank passes the same list); this rank renders its shard.
+        = render_backward() -> reduce() -> update(); the three phases are separately callable so that the two
+        compute phases can be replayed from HIP graphs around the one eager collective."""
+        total, photometric = self.render_backward(window, regularize)
+        self.reduce()
+        self.update(decay_opacity)
+        return total, photometric
+
+    def render_backward(self, window: List[Frame], regularize: bool = True):
         conf = self.conf
         self.total_step += 1
         mine = self.shard.select(window)
+        multi = self.shard.world_size > 1
         for f in mine:
             self.optimizers.add_pose(f.pose)
         self.optimizers.zero_grad()
@@ -140,16 +149,15 @@ class BundleAdjuster:
         exposure = create_batch(mine, lambda f: f.exposure_params)
         outputs = self.splats(cameras, poses, render_depth=True)
         vis_count = outputs._vis_count                                  # = (radii > 0).sum(0), from K1
-        if self.shard.world_size > 1:
-            vis_count = self.shard.all_reduce_sum(vis_count.clone())
         outputs.means2d.retain_grad()                                   # backend.py:326
         if self.fused_loss:
-            # value and analytic gradient in one pass (csrc/loss.hip); the backward is seeded at the render tensor
+            # value and analytic gradient in one pass (csrc/loss.hip); the backward is seeded at the render tensor.
+            # Multi-GPU: the isotropic term needs the window-wide visibility, so it moves behind the all-reduce.
             out2, v_render, v_exposure, v_scales = mapping_loss_and_grads(
                 outputs, gt_imgs, exposure, self.splats.scales, ssim_weight=conf.ssim_weight,
-                iso_weight=conf.isotropic_regularization_weight,
+                iso_weight=0.0 if multi else conf.isotropic_regularization_weight,
                 tv_weight=conf.depth_regularization_weight if regularize else 0.0, active_gs=conf.active_gs,
-                shard=len(mine) / float(len(window)), iso_scale=1.0 / self.shard.world_size, vis_count=vis_count)
+                shard=len(mine) / float(len(window)), vis_count=vis_count)
             total, photometric = out2[0], out2[1]
             torch.autograd.backward([outputs._render], [v_render])
             if v_scales is not None:
@@ -159,20 +167,43 @@ class BundleAdjuster:
                     f.exposure_params.grad = v_exposure[i] if f.exposure_params.grad is None \
                         else f.exposure_params.grad + v_exposure[i]
         else:
+            assert not multi, "the torch-formulated loss is the single-GPU reference path"
             total, photometric = mapping_loss(self.splats, outputs, gt_imgs, exposure, conf, regularize,
-                                              c_total=len(window), visible_gaussians=vis_count > 0,
-                                              iso_scale=1.0 / self.shard.world_size)
+                                              c_total=len(window), visible_gaussians=vis_count > 0)
             total.backward()
         if self.bucket is not None:
+            self.bucket.counts.copy_(vis_count)                         # int32 -> fp32 column of the bucket
+        self._vis_count = vis_count
+        self.last_outputs = outputs
+        return total.detach(), photometric.detach()
+
+    def reduce(self):
+        """the ONE data-path collective of an iteration: sum of the [N*15 + N] bucket over ranks (RCCL / xGMI)"""
+        if self.bucket is not None:
             self.bucket.all_reduce()
+
+    def update(self, decay_opacity: bool = True):
+        conf = self.conf
+        vis_count = self._vis_count
+        if self.bucket is not None:
+            vis_count = self.bucket.counts.to(torch.int32)              # window-wide visible-camera counts
+            w = conf.isotropic_regularization_weight
+            if w != 0.0:                                                # identical on every rank (replicated map)
+                sc = self.splats.scales
+                N = sc.shape[0]
+                v_scales = torch.empty_like(sc)
+                iso_sum = torch.empty(1, dtype=torch.float32, device=sc.device)
+                from .ops import workspace
+                ws = workspace(lib.gsx_isotropic_workspace_bytes(N), sc.device, "iso")
+                check(lib.gsx_isotropic_loss(ptr(sc.data), ptr(vis_count), N, w, ptr(iso_sum), ptr(v_scales), ptr(ws),
+                                             ws.numel(), stream_ptr(sc.device)), "gsx_isotropic_loss")
+                sc.grad.add_(v_scales)
         self.optimizers.step()
         if decay_opacity:
             with torch.no_grad():                                       # backend.py:356-359
                 op = self.splats.opacities
                 check(lib.gsx_opacity_decay(ptr(op.data), ptr(vis_count), op.shape[0], 1, conf.opacity_decay,
                                             stream_ptr(op.device)), "gsx_opacity_decay")
-        self.last_outputs = outputs
-        return total.detach(), photometric.detach()
 
     def optimize_map(self, window: List[Frame], n_iters: Optional[int] = None, regularize: bool = True,
                      early_stop: bool = True):
@@ -197,17 +228,17 @@ class BundleAdjuster:
 
 
 class GraphedBundleAdjuster:
-    """A BA iteration over a FIXED window captured once into a HIP graph and replayed: the ~60 launches of a step
-    (pose chain, K1, binning, sort, K8, SSIM, loss, K9, K2, Adam, decay) cost one graph launch on the host.  Needs a
-    single-GPU BundleAdjuster built with capturable=True; the window's tensors (images, poses, exposure) are updated
-    in place between replays.  ``validate()`` (gslam_amd.rasterization) must be polled by the caller: the intersection
-    capacity is baked into the graph."""
+    """A BA iteration over a FIXED window captured into HIP graphs and replayed: the ~45 launches of a step (pose
+    chain, K1, binning, sort, K8, SSIM, loss, K9, K2, Adam, decay) cost one graph launch on the host.  Multi-GPU: two
+    graphs (render+loss+backward | isotropic+Adam+decay) around the one eager all-reduce.  Needs a BundleAdjuster
+    built with capturable=True; the window's tensors (images, poses, exposure) are updated in place between replays.
+    ``validate()`` (gslam_amd.rasterization) must be polled by the caller: the intersection capacity is baked in."""
 
     def __init__(self, ba: BundleAdjuster, window: List[Frame], warmup: int = 3, regularize: bool = True):
-        assert ba.shard.world_size == 1, "graph capture is single-GPU; multi-GPU BA runs eagerly around the all-reduce"
         assert ba.optimizers.capturable, "build the BundleAdjuster with capturable=True"
         from .rasterization import validate
         self.ba, self.window = ba, window
+        self.multi = ba.shard.world_size > 1
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -219,10 +250,22 @@ class GraphedBundleAdjuster:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.total, self.photometric = ba.step(window, regularize)
+        self.graph2 = None
+        if not self.multi:
+            with torch.cuda.graph(self.graph):
+                self.total, self.photometric = ba.step(window, regularize)
+        else:
+            with torch.cuda.graph(self.graph):
+                self.total, self.photometric = ba.render_backward(window, regularize)
+            ba.reduce()
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+                ba.update()
 
     def step(self):
         self.graph.replay()
+        if self.multi:
+            self.ba.reduce()
+            self.graph2.replay()
         self.ba.total_step += 1
         return self.total, self.photometric

@@ -97,6 +97,7 @@ class _IsectPool:
         self.overflowed = False
         self.last_M = 0
         self._graph_M = None
+        self.signature = None       # (N, C, W, H) of the renders the capacity was sized for
 
     def ensure(self, estimate: int):
         want = int(estimate * self.GROW) + 4096
@@ -283,10 +284,15 @@ def rasterization(
         capturing = torch.cuda.is_current_stream_capturing()
         if not capturing:
             pool.poll()
-        if pool.capacity == 0:
+        sig = (N, C, int(width), int(height))
+        if pool.capacity == 0 or pool.signature != sig:
+            # a new problem shape (first render, map grown / pruned, other resolution or window size): size the buffers
+            # with ONE synchronous probe; between probes M only drifts with the poses and is tracked asynchronously
             if capturing:
-                raise RuntimeError("render once eagerly before capturing a HIP graph (intersection capacity probe)")
-            pool.ensure(int(tiles_per_gauss.sum().item()))      # first render on this device: one probe
+                raise RuntimeError("render this (N, C, W, H) once eagerly before capturing a HIP graph "
+                                   "(intersection capacity probe)")
+            pool.ensure(int(tiles_per_gauss.sum().item()))
+            pool.signature = sig
         cap = pool.capacity
         flat_buf = torch.empty(cap, dtype=torch.int32, device=dev)
         with torch.no_grad():

@@ -14,6 +14,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+def test_library_is_rebuilt_from_current_sources():
+    """a stale libgsx.so (sources edited, library not rebuilt) must never be what the tests or the GPU box run"""
+    from gslam_amd.csrc.build import OUT, SOURCES, HERE, build
+    build()                                                    # no-op when fresh, recompiles what changed
+    so = os.path.getmtime(OUT)
+    for src in list(SOURCES) + ["gsx_common.h", "raster_v1.inc"]:
+        assert os.path.getmtime(os.path.join(HERE, src)) <= so, f"{src} is newer than libgsx.so"
+
+
 def test_library_exports_every_declared_symbol():
     import ctypes as C
     from gslam_amd import _lib
@@ -184,4 +193,4 @@ def test_keyframe_sharded_ba_collectives_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, ok, vis, mx, t, numel in res:
-        assert ok and vis == 5 and mx == 1 and t == 1.0 and numel == 50 * 15
+        assert ok and vis == 5 and mx == 1 and t == 1.0 and numel == 50 * 16   # 15 gradient columns + the count column
