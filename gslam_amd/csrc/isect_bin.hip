@@ -16,16 +16,16 @@
 //   3. emit_binned   : per workgroup: LDS per-tile counts, ONE global atomic per touched tile to reserve a range,
 //                      LDS cursors to place 8-byte entries (depth_bits<<32 | flatten_id); rectangles larger than 16
 //                      tiles are walked cooperatively by the whole wavefront
-//   4. tile_sort     : one workgroup per tile, all-ascending ("mirrored") bitonic network on 64-bit keys in LDS
-//                      (<= 4096 entries) or in place in global memory (larger tiles); writes flatten_ids / isect_ids
+//   4. tile_sort     : one workgroup per tile: rank sort of 256-key chunks + multiway merge by lower bounds, all in
+//                      LDS (<= 4096 entries), or an in-place bitonic network in global memory for larger tiles;
+//                      writes flatten_ids / isect_ids
 #include "gsx_common.h"
 
 namespace {
 
 constexpr int BIN_THREADS = 256;
 constexpr int BIN_ITEMS = 4;          // Gaussians per thread in tile_diff / emit_binned
-constexpr int SORT_THREADS = 256;
-constexpr int SORT_LDS_CAP = 4096;    // keys sorted out of LDS (32 KiB); larger tiles sort in global memory
+constexpr int SORT_THREADS = 512;
 constexpr int COOP_AREA = 16;         // rectangles with more tiles than this are walked by the whole wavefront
 
 __device__ __forceinline__ uint32_t sat_u32(float f) {
@@ -219,37 +219,65 @@ __device__ __forceinline__ void cmp_exchange(Ptr k, int a, int b) {
     if (ka > kb) { k[a] = kb; k[b] = ka; }
 }
 
-// all-ascending bitonic network over the first n slots of k (virtual +inf padding up to the next power of two)
-template <typename Ptr>
+// all-ascending bitonic network over the first n slots of k (virtual +inf padding up to the next power of two).
+// Compare-exchange indices are dealt to the wavefronts in contiguous chunks of Lc, so every step whose partner
+// distance is <= Lc only touches the wavefront's own 2*Lc-element slice: LDS operations of one wavefront execute in
+// order, so such steps need no workgroup barrier (WAVE_LOCAL; LDS only).  For 512 keys that leaves 4 barriers of 45.
+template <bool WAVE_LOCAL, typename Ptr>
 __device__ __forceinline__ void bitonic_sort(Ptr k, int n) {
     int P = 1;
     while (P < n) P <<= 1;
     const int half = P >> 1;
+    const int nw = SORT_THREADS / 64;
+    const int Lc = max(64, half / nw);                  // CE indices per wavefront
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lo = wave * Lc;
+    bool prev_cross = true;
+    auto sync = [&](bool cross) {
+        if (!WAVE_LOCAL || cross || prev_cross) __syncthreads();
+        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        prev_cross = cross;
+    };
     for (int size = 2; size <= P; size <<= 1) {
         const int hs = size >> 1;
-        for (int i = threadIdx.x; i < half; i += SORT_THREADS) {  // mirror step
-            const int blk = i / hs, off = i - blk * hs;
-            const int a = blk * size + off, b = blk * size + size - 1 - off;
-            if (b < n) cmp_exchange(k, a, b);
-        }
-        __syncthreads();
-        for (int j = hs >> 1; j >= 1; j >>= 1) {  // half cleaners
-            for (int i = threadIdx.x; i < half; i += SORT_THREADS) {
-                const int blk = i / j, off = i - blk * j;
-                const int a = blk * 2 * j + off, b = a + j;
+        sync(size > 2 * Lc);
+        if (lo < half)
+            for (int i = lo + lane; i < lo + Lc; i += 64) {  // mirror step
+                const int blk = i / hs, off = i - blk * hs;
+                const int a = blk * size + off, b = blk * size + size - 1 - off;
                 if (b < n) cmp_exchange(k, a, b);
             }
-            __syncthreads();
+        for (int j = hs >> 1; j >= 1; j >>= 1) {  // half cleaners
+            sync(j > Lc);
+            if (lo < half)
+                for (int i = lo + lane; i < lo + Lc; i += 64) {
+                    const int blk = i / j, off = i - blk * j;
+                    const int a = blk * 2 * j + off, b = a + j;
+                    if (b < n) cmp_exchange(k, a, b);
+                }
         }
     }
+    __syncthreads();
 }
+
+// One workgroup per tile.  Tiles that fit the LDS window (n <= cap keys, cap chosen by the host from the capacity)
+// are merge-sorted by RANKS, ping-ponging between two LDS buffers:
+//   1. runs of 64 keys are sorted by counting ranks (position = number of smaller keys in the run; all lanes stream
+//      the run as 16-byte broadcast reads, (a - k) >> 63 is the comparison: keys are < 2^63)
+//   2. log2(n/64) merge levels: a key's position in the merged pair of runs = its position in its own run + the
+//      number of partner keys before it (lower bound from the left run, upper bound from the right run: a stable
+//      merge), found by a binary search in LDS.  One barrier per level, every key moves exactly once per level.
+// ~ (32 + sum of log2(run)) short steps per key instead of log^2(n)/2 compare-exchanges with a barrier each.
+// Larger tiles fall back to an in-place bitonic network in global memory (correct for any size).
+constexpr int RUN0 = 64;
 
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long long *__restrict__ entries,
                                                                  const int32_t *__restrict__ offsets, int n_tiles,
-                                                                 int tile_n_bits, int64_t M_cap,
+                                                                 int tile_n_bits, int64_t M_cap, int cap,
                                                                  int64_t *__restrict__ isect_ids,
                                                                  int32_t *__restrict__ flatten_ids) {
-    __shared__ unsigned long long s_keys[SORT_LDS_CAP];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
+    unsigned long long *src = s_mem, *dst = s_mem + cap;
     const int tile = blockIdx.x;
     const int64_t start = min((int64_t)offsets[tile], M_cap);
     const int64_t end = min((int64_t)offsets[tile + 1], M_cap);
@@ -258,18 +286,53 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long l
     const int c = tile / n_tiles, tl = tile - c * n_tiles;
     const long long hi_part = ((long long)c << (32 + tile_n_bits)) | ((long long)tl << 32);
     unsigned long long *seg = entries + start;
-    if (n <= SORT_LDS_CAP) {
-        for (int i = threadIdx.x; i < n; i += SORT_THREADS) s_keys[i] = seg[i];
+    if (n <= cap) {
+        const unsigned long long INF = ~0ull >> 1;            // larger than any key, still < 2^63
+        const int n_pad = (n + RUN0 - 1) / RUN0 * RUN0;       // <= cap (cap is a multiple of 64)
+        for (int i = threadIdx.x; i < n_pad; i += SORT_THREADS) src[i] = (i < n) ? seg[i] : INF;
         __syncthreads();
-        if (n > 1) bitonic_sort(s_keys, n);
         for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
-            const unsigned long long k = s_keys[i];
+            const unsigned long long k = src[i];
+            const int cb = i & ~(RUN0 - 1);
+            const ulonglong2 *s2 = reinterpret_cast<const ulonglong2 *>(src + cb);
+            unsigned int rank = 0;
+#pragma unroll 8
+            for (int m = 0; m < RUN0 / 2; ++m) {
+                const ulonglong2 a = s2[m];
+                rank += (unsigned int)((a.x - k) >> 63) + (unsigned int)((a.y - k) >> 63);
+            }
+            dst[cb + rank] = k;
+        }
+        __syncthreads();
+        { unsigned long long *t = src; src = dst; dst = t; }
+        for (int run = RUN0; run < n; run <<= 1) {
+            for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
+                const unsigned long long k = src[i];
+                const int r = i / run;
+                const int own = r * run, pair = (r & ~1) * run;
+                const int pb = (r ^ 1) * run;                          // partner run
+                const int plen = max(0, min(run, n - pb));
+                const bool right = (r & 1) != 0;
+                int lo = 0, hi = plen;                                  // left run: #partner < k ; right run: #partner <= k
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const unsigned long long v = src[pb + mid];
+                    const bool before = right ? (v <= k) : (v < k);
+                    if (before) lo = mid + 1; else hi = mid;
+                }
+                dst[pair + (i - own) + lo] = k;
+            }
+            __syncthreads();
+            unsigned long long *t = src; src = dst; dst = t;
+        }
+        for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
+            const unsigned long long k = src[i];
             flatten_ids[start + i] = (int32_t)(uint32_t)k;
             if (isect_ids) isect_ids[start + i] = hi_part | (long long)(k >> 32);
         }
     } else {
         __syncthreads();
-        bitonic_sort(seg, n);  // in place in global memory (L2): correct for any size, only huge tiles land here
+        bitonic_sort<false>(seg, n);  // in place in global memory (L2): correct for any size, only huge tiles land here
         for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
             const unsigned long long k = seg[i];
             flatten_ids[start + i] = (int32_t)(uint32_t)k;
@@ -342,8 +405,12 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
         hipLaunchKernelGGL(emit_binned_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4), st,
                            means2d, radii, depths, N, tile_w, tile_h, M_cap, cursor, entries);
         GSX_CHECK_LAUNCH();
-        hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, offsets,
-                           (int)n_tiles, bit_length((uint32_t)n_tiles), M_cap, isect_ids, flatten_ids);
+        // LDS window: 4x the average tile (tiles are unbalanced), between 512 and 4096 keys, two buffers of it
+        int64_t cap = 512;
+        while (cap < 4 * (M_cap / T + 1) && cap < 4096) cap <<= 1;
+        hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), (size_t)(2 * cap * 8), st, entries,
+                           offsets, (int)n_tiles, bit_length((uint32_t)n_tiles), M_cap, (int)cap, isect_ids,
+                           flatten_ids);
         GSX_CHECK_LAUNCH();
     }
     return GSX_OK;

@@ -154,21 +154,24 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(const float *__restrict
     const int start = min(offsets[q.tile], (int)M);
     const int end = (has_end || q.tile + 1 < n_tiles_total) ? min(offsets[q.tile + 1], (int)M) : (int)M;
 
-    float T = 1.0f;
+    // The CU has ONE scalar unit for its four SIMDs, so the per-entry loop keeps its state in vector registers and
+    // arithmetic instead of lane masks and branches: a finished pixel simply carries a live transmittance of 0.
+    float Tl = q.inside ? 1.0f : 0.0f;   // live transmittance (0 once the pixel has terminated / is outside the image)
+    float T_out = 1.0f;                  // transmittance to report: frozen at termination
     float pix[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) pix[k] = 0.f;
     int last = -1;
-    bool done = !q.inside;
 
     for (int base = start; base < end; base += 64) {
-        if (__all(done)) break;  // wave-uniform: every pixel of the quadrant is saturated
+        if (__all(Tl == 0.0f)) break;  // once per 64 entries: every pixel of the quadrant is saturated
         const int e = base + q.lane;
         const bool have = e < end;
         const int g = have ? flatten_ids[e] : 0;
-        Rec<RS> r = load_record<RS>(rec, have ? g : 0);
+        const Rec<RS> r = load_record<RS>(rec, g);
         const bool maybe = have && may_touch(r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5], q.x0, q.y0, q.x1, q.y1);
         unsigned long long mask = __ballot(maybe);
+        int touched_cnt = 0;             // lane j counts the pixels that entry j "touched" (T' > visibility_min_T)
         // LANES = PIXELS from here on; the Gaussian's record is broadcast into scalar registers with v_readlane
         // (measured faster here than re-fetching it through the scalar cache: nothing to wait for)
         while (mask != 0ull) {
@@ -178,27 +181,25 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(const float *__restrict
             const float dx = cur.a.x - q.fx, dy = cur.a.y - q.fy;
             const float sigma = 0.5f * (cur.a.z * dx * dx + cur.b.x * dy * dy) + cur.a.w * dx * dy;
             const float alpha = fminf(GSX_ALPHA_MAX, cur.b.y * __expf(-sigma));
-            bool valid = !done && (sigma >= 0.0f) && (alpha >= GSX_ALPHA_MIN);
-            const float nT = T * (1.0f - alpha);
-            if (valid && nT <= GSX_T_MIN) { done = true; valid = false; }
-            if (!__any(valid)) {
-                if (__all(done)) break;
-                continue;
-            }
-            const float vis = valid ? alpha * T : 0.0f;
+            const float a_eff = ((sigma >= 0.0f) && (alpha >= GSX_ALPHA_MIN)) ? alpha : 0.0f;
+            const float nT = Tl * (1.0f - a_eff);
+            const bool stop = nT <= GSX_T_MIN;                 // terminates now, or was already dead (Tl == 0)
+            const float vis = stop ? 0.0f : a_eff * Tl;
 #pragma unroll
             for (int k = 0; k < CH; ++k) pix[k] += cur.color(k) * vis;
-            const bool touched = valid && (nT > vis_min_T);
-            if (valid) { last = base + j; T = nT; }
-            const unsigned long long tm = __ballot(touched);
-            if (tm != 0ull && q.lane == 0) atomicAdd(&n_touched[__builtin_amdgcn_readlane(g, j)], __popcll(tm));
+            last = (vis > 0.0f) ? base + j : last;
+            const unsigned long long tm = __ballot((vis > 0.0f) && (nT > vis_min_T));
+            touched_cnt += (q.lane == j) ? __popcll(tm) : 0;
+            T_out = stop ? T_out : nT;
+            Tl = stop ? 0.0f : nT;
         }
+        if (touched_cnt > 0) atomicAdd(&n_touched[g], touched_cnt);
     }
     if (q.inside) {
         const int64_t p = ((int64_t)q.c * H + q.py) * W + q.px;
 #pragma unroll
-        for (int k = 0; k < CH; ++k) render[p * CH + k] = pix[k] + (bg ? T * bg[q.c * CH + k] : 0.f);
-        alphas[p] = 1.0f - T;
+        for (int k = 0; k < CH; ++k) render[p * CH + k] = pix[k] + (bg ? T_out * bg[q.c * CH + k] : 0.f);
+        alphas[p] = 1.0f - T_out;
         last_ids[p] = last;
     }
 }
@@ -287,13 +288,13 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
                 const float sigma = 0.5f * (a * dx * dx + cq * dy * dy) + bq * dx * dy;
                 const float vis = __expf(-sigma);
                 const float alpha = fminf(GSX_ALPHA_MAX, opac * vis);
-                const bool valid = (cbase + j <= last) && (sigma >= 0.0f) && (alpha >= GSX_ALPHA_MIN);
-                if (!__any(valid)) continue;
-                // branch-free: lanes that do not composite this entry carry fac = 0 and v_sigma = 0, so every
-                // product below is an exact zero for them and T / buf stay untouched
-                const float ra = valid ? __builtin_amdgcn_rcpf(1.0f - alpha) : 1.0f;
+                // scalar-light body (one scalar unit per CU): an entry that does not composite on this pixel simply
+                // carries alpha 0, which makes ra = 1, fac = 0 and v_sigma = 0 without any lane-mask logic
+                const float a_eff = ((cbase + j <= last) && (sigma >= 0.0f) && (alpha >= GSX_ALPHA_MIN)) ? alpha : 0.0f;
+                if (!__any(a_eff > 0.0f)) continue;
+                const float ra = __builtin_amdgcn_rcpf(1.0f - a_eff);
                 T *= ra;
-                const float fac = valid ? alpha * T : 0.0f;
+                const float fac = a_eff * T;
                 float gr[NG];
                 float v_alpha = 0.f;
 #pragma unroll
@@ -304,14 +305,15 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
                     buf[k] += ck * fac;
                 }
                 v_alpha += T_final * ra * (va_out - bg_dot);
-                const bool g_ok = valid && (opac * vis <= GSX_ALPHA_MAX);   // alpha not clamped: sigma/opacity get gradient
-                const float v_sigma = g_ok ? -opac * vis * v_alpha : 0.0f;
+                // gradient reaches sigma / opacity only where alpha was not clamped at 0.999
+                const float visw = ((a_eff > 0.0f) && (opac * vis <= GSX_ALPHA_MAX)) ? vis : 0.0f;
+                const float v_sigma = -opac * visw * v_alpha;
                 gr[2] = 0.5f * v_sigma * dx * dx;
                 gr[3] = v_sigma * dx * dy;
                 gr[4] = 0.5f * v_sigma * dy * dy;
                 gr[0] = v_sigma * (a * dx + bq * dy);
                 gr[1] = v_sigma * (bq * dx + cq * dy);
-                gr[5] = g_ok ? vis * v_alpha : 0.0f;
+                gr[5] = visw * v_alpha;
                 const float gax = ABS ? fabsf(gr[0]) : 0.f, gay = ABS ? fabsf(gr[1]) : 0.f;
                 // 16-lane row sums of all NG entries, interleaved (DPP), then the four row leaders add into the
                 // entry's LDS accumulator row: one exec-mask change, NG ds_add_f32 with 4 active lanes each
@@ -343,6 +345,261 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
     }
 }
 
+
+// =====================================================================================================================
+// v3: two pixels per lane.  A wavefront owns a 16x8 half tile: lane l composites the pixels (x, y) and (x, y + 4) with
+// x = l & 15, y = l >> 4.  Both pixels share dx, so half of the conic quadratic is computed once; the per-entry fixed
+// cost (record broadcast, loop control, ballots, and in the backward the DPP row sums and LDS adds) is paid once per
+// 128 pixels instead of once per 64.  Workgroup = 2 wavefronts = 128 threads per 16x16 tile.
+// =====================================================================================================================
+struct Half {
+    int tile, c, px, py0, py1, wave, lane;
+    bool in0, in1;
+    float fx, fy0, x0, y0, x1, y1;
+};
+
+__device__ __forceinline__ Half make_half(int tile_w, int tile_h, int W, int H) {
+    Half q;
+    const int tiles_per_cam = tile_w * tile_h;
+    q.tile = blockIdx.x;
+    q.c = q.tile / tiles_per_cam;
+    const int tl = q.tile - q.c * tiles_per_cam;
+    const int ty = tl / tile_w, tx = tl - ty * tile_w;
+    q.wave = threadIdx.x >> 6;
+    q.lane = threadIdx.x & 63;
+    const int bx = tx * GSX_TILE, by = ty * GSX_TILE + q.wave * 8;
+    q.px = bx + (q.lane & 15);
+    q.py0 = by + (q.lane >> 4);
+    q.py1 = q.py0 + 4;
+    q.in0 = (q.px < W) && (q.py0 < H);
+    q.in1 = (q.px < W) && (q.py1 < H);
+    q.fx = (float)q.px + 0.5f;
+    q.fy0 = (float)q.py0 + 0.5f;
+    q.x0 = (float)bx + 0.5f; q.y0 = (float)by + 0.5f;
+    q.x1 = (float)(bx + 15) + 0.5f; q.y1 = (float)(by + 7) + 0.5f;
+    return q;
+}
+
+template <int CH, int RS>
+__global__ __launch_bounds__(128) void raster_fwd_kernel2(const float *__restrict__ rec, const float *__restrict__ bg,
+                                                          const int32_t *__restrict__ offsets,
+                                                          const int32_t *__restrict__ flatten_ids, int64_t M,
+                                                          int has_end, int W, int H, int tile_w, int tile_h,
+                                                          float vis_min_T, float *__restrict__ render,
+                                                          float *__restrict__ alphas, int32_t *__restrict__ last_ids,
+                                                          int32_t *__restrict__ n_touched) {
+    const Half q = make_half(tile_w, tile_h, W, H);
+    const int n_tiles_total = gridDim.x;
+    const int start = min(offsets[q.tile], (int)M);
+    const int end = (has_end || q.tile + 1 < n_tiles_total) ? min(offsets[q.tile + 1], (int)M) : (int)M;
+
+    float T0 = 1.0f, T1 = 1.0f;
+    float pix0[CH], pix1[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) { pix0[k] = 0.f; pix1[k] = 0.f; }
+    int last0 = -1, last1 = -1;
+    bool done0 = !q.in0, done1 = !q.in1;
+
+    for (int base = start; base < end; base += 64) {
+        if (__all(done0 && done1)) break;
+        const int e = base + q.lane;
+        const bool have = e < end;
+        const int g = have ? flatten_ids[e] : 0;
+        Rec<RS> r = load_record<RS>(rec, have ? g : 0);
+        const bool maybe = have && may_touch(r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5], q.x0, q.y0, q.x1, q.y1);
+        unsigned long long mask = __ballot(maybe);
+        while (mask != 0ull) {
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const SRec<RS> cur = bcast_record<RS>(r.v, j);
+            const float dx = cur.a.x - q.fx, dy0 = cur.a.y - q.fy0, dy1 = dy0 - 4.0f;
+            const float h = 0.5f * cur.a.z * dx * dx, bdx = cur.a.w * dx, hc = 0.5f * cur.b.x;
+            const float sig0 = h + dy0 * (hc * dy0 + bdx), sig1 = h + dy1 * (hc * dy1 + bdx);
+            const float al0 = fminf(GSX_ALPHA_MAX, cur.b.y * __expf(-sig0));
+            const float al1 = fminf(GSX_ALPHA_MAX, cur.b.y * __expf(-sig1));
+            bool v0 = !done0 && (sig0 >= 0.0f) && (al0 >= GSX_ALPHA_MIN);
+            bool v1 = !done1 && (sig1 >= 0.0f) && (al1 >= GSX_ALPHA_MIN);
+            const float nT0 = T0 * (1.0f - al0), nT1 = T1 * (1.0f - al1);
+            if (v0 && nT0 <= GSX_T_MIN) { done0 = true; v0 = false; }
+            if (v1 && nT1 <= GSX_T_MIN) { done1 = true; v1 = false; }
+            if (!__any(v0 || v1)) {
+                if (__all(done0 && done1)) break;
+                continue;
+            }
+            const float vis0 = v0 ? al0 * T0 : 0.0f, vis1 = v1 ? al1 * T1 : 0.0f;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const float ck = cur.color(k);
+                pix0[k] += ck * vis0;
+                pix1[k] += ck * vis1;
+            }
+            const bool t0 = v0 && (nT0 > vis_min_T), t1 = v1 && (nT1 > vis_min_T);
+            if (v0) { last0 = base + j; T0 = nT0; }
+            if (v1) { last1 = base + j; T1 = nT1; }
+            const unsigned long long tm0 = __ballot(t0), tm1 = __ballot(t1);
+            if ((tm0 | tm1) != 0ull && q.lane == 0)
+                atomicAdd(&n_touched[__builtin_amdgcn_readlane(g, j)], __popcll(tm0) + __popcll(tm1));
+        }
+    }
+    if (q.in0) {
+        const int64_t p = ((int64_t)q.c * H + q.py0) * W + q.px;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) render[p * CH + k] = pix0[k] + (bg ? T0 * bg[q.c * CH + k] : 0.f);
+        alphas[p] = 1.0f - T0;
+        last_ids[p] = last0;
+    }
+    if (q.in1) {
+        const int64_t p = ((int64_t)q.c * H + q.py1) * W + q.px;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) render[p * CH + k] = pix1[k] + (bg ? T1 * bg[q.c * CH + k] : 0.f);
+        alphas[p] = 1.0f - T1;
+        last_ids[p] = last1;
+    }
+}
+
+template <int CH, int RS, bool ABS>
+__global__ __launch_bounds__(128) void raster_bwd_kernel2(
+    const float *__restrict__ rec, const float *__restrict__ bg, const int32_t *__restrict__ offsets,
+    const int32_t *__restrict__ flatten_ids, int64_t M, int has_end, int W, int H, int tile_w, int tile_h,
+    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
+    const float *__restrict__ v_alphas, float *__restrict__ v_rec, float *__restrict__ v_abs) {
+    constexpr int NG = 6 + CH;
+    constexpr int BATCH = 256;
+    __shared__ __attribute__((aligned(16))) float s_grad[BATCH * RS];
+    __shared__ float s_abs[ABS ? 2 * BATCH : 2];
+    __shared__ int s_id[BATCH];
+    __shared__ int s_wmax[2];
+
+    const Half q = make_half(tile_w, tile_h, W, H);
+    const int t = threadIdx.x;
+    const int64_t p0 = ((int64_t)q.c * H + min(q.py0, H - 1)) * W + min(q.px, W - 1);
+    const int64_t p1 = ((int64_t)q.c * H + min(q.py1, H - 1)) * W + min(q.px, W - 1);
+    const int start = min(offsets[q.tile], (int)M);
+    const int last0 = q.in0 ? last_ids[p0] : -1, last1 = q.in1 ? last_ids[p1] : -1;
+    int wmax = max(last0, last1);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
+    if (q.lane == 0) s_wmax[q.wave] = wmax;
+    __syncthreads();
+    const int bmax = max(s_wmax[0], s_wmax[1]);
+    if (bmax < start) return;
+
+    const float Tf0 = q.in0 ? 1.0f - alphas[p0] : 1.0f, Tf1 = q.in1 ? 1.0f - alphas[p1] : 1.0f;
+    float T0 = Tf0, T1 = Tf1;
+    float vo0[CH], vo1[CH], buf0[CH], buf1[CH];
+    float bgd0 = 0.f, bgd1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        vo0[k] = q.in0 ? v_render[p0 * CH + k] : 0.f;
+        vo1[k] = q.in1 ? v_render[p1 * CH + k] : 0.f;
+        buf0[k] = 0.f; buf1[k] = 0.f;
+        if (bg) { bgd0 += bg[q.c * CH + k] * vo0[k]; bgd1 += bg[q.c * CH + k] * vo1[k]; }
+    }
+    const float ka0 = ((q.in0 && v_alphas) ? v_alphas[p0] : 0.f) - bgd0;   // (v_alpha_out - bg . v_out)
+    const float ka1 = ((q.in1 && v_alphas) ? v_alphas[p1] : 0.f) - bgd1;
+
+    const int n = bmax - start + 1;
+    const int n_batches = (n + BATCH - 1) / BATCH;
+    for (int b = n_batches - 1; b >= 0; --b) {
+        const int batch_start = start + b * BATCH;
+        const int bsize = min(BATCH, start + n - batch_start);
+        __syncthreads();
+        for (int i = t; i < bsize; i += 128) s_id[i] = flatten_ids[batch_start + i];
+        for (int i = t; i < BATCH * RS; i += 128) s_grad[i] = 0.f;
+        if (ABS) for (int i = t; i < 2 * BATCH; i += 128) s_abs[i] = 0.f;
+        __syncthreads();
+        for (int sub = 3; sub >= 0; --sub) {
+            const int cbase = batch_start + sub * 64;
+            if (cbase >= batch_start + bsize || cbase > wmax) continue;  // wave-uniform
+            const int e = cbase + q.lane;
+            const bool have = (e < batch_start + bsize) && (e <= wmax);
+            const int g = have ? s_id[sub * 64 + q.lane] : 0;
+            Rec<RS> r = load_record<RS>(rec, g);
+            const bool maybe = have && may_touch(r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5], q.x0, q.y0, q.x1, q.y1);
+            unsigned long long mask = __ballot(maybe);
+            while (mask != 0ull) {
+                const int j = 63 - __clzll((long long)mask);  // back to front
+                mask &= ~(1ull << j);
+                const SRec<RS> cur = bcast_record<RS>(r.v, j);
+                const float a = cur.a.z, bq = cur.a.w, cq = cur.b.x, opac = cur.b.y;
+                const float dx = cur.a.x - q.fx, dy0 = cur.a.y - q.fy0, dy1 = dy0 - 4.0f;
+                const float h = 0.5f * a * dx * dx, bdx = bq * dx, hc = 0.5f * cq;
+                const float sig0 = h + dy0 * (hc * dy0 + bdx), sig1 = h + dy1 * (hc * dy1 + bdx);
+                const float vis0 = __expf(-sig0), vis1 = __expf(-sig1);
+                const float al0 = fminf(GSX_ALPHA_MAX, opac * vis0), al1 = fminf(GSX_ALPHA_MAX, opac * vis1);
+                const float ae0 = ((cbase + j <= last0) && (sig0 >= 0.0f) && (al0 >= GSX_ALPHA_MIN)) ? al0 : 0.0f;
+                const float ae1 = ((cbase + j <= last1) && (sig1 >= 0.0f) && (al1 >= GSX_ALPHA_MIN)) ? al1 : 0.0f;
+                if (!__any(fmaxf(ae0, ae1) > 0.0f)) continue;
+                const float ra0 = __builtin_amdgcn_rcpf(1.0f - ae0), ra1 = __builtin_amdgcn_rcpf(1.0f - ae1);
+                T0 *= ra0; T1 *= ra1;
+                const float fac0 = ae0 * T0, fac1 = ae1 * T1;
+                float gr[NG];
+                float va0 = 0.f, va1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const float ck = cur.color(k);
+                    gr[6 + k] = fac0 * vo0[k] + fac1 * vo1[k];
+                    va0 += (ck * T0 - buf0[k] * ra0) * vo0[k];
+                    va1 += (ck * T1 - buf1[k] * ra1) * vo1[k];
+                    buf0[k] += ck * fac0;
+                    buf1[k] += ck * fac1;
+                }
+                va0 += Tf0 * ra0 * ka0;
+                va1 += Tf1 * ra1 * ka1;
+                const float vw0 = ((ae0 > 0.0f) && (opac * vis0 <= GSX_ALPHA_MAX)) ? vis0 : 0.0f;
+                const float vw1 = ((ae1 > 0.0f) && (opac * vis1 <= GSX_ALPHA_MAX)) ? vis1 : 0.0f;
+                const float vs0 = -opac * vw0 * va0, vs1 = -opac * vw1 * va1;
+                const float vss = vs0 + vs1;
+                const float sdy = vs0 * dy0 + vs1 * dy1;                 // sum v_sigma * dy
+                gr[2] = 0.5f * vss * dx * dx;
+                gr[3] = sdy * dx;
+                gr[4] = 0.5f * (vs0 * dy0 * dy0 + vs1 * dy1 * dy1);
+                gr[0] = a * dx * vss + bq * sdy;
+                gr[1] = bq * dx * vss + cq * sdy;
+                gr[5] = vw0 * va0 + vw1 * va1;
+                float ab[2] = {0.f, 0.f};
+                if (ABS) {
+                    ab[0] = fabsf(vs0 * (a * dx + bq * dy0)) + fabsf(vs1 * (a * dx + bq * dy1));
+                    ab[1] = fabsf(vs0 * (bq * dx + cq * dy0)) + fabsf(vs1 * (bq * dx + cq * dy1));
+                }
+                const int slot = sub * 64 + j;
+                gsx_row16_sum<NG>(gr);
+                if (ABS) gsx_row16_sum<2>(ab);
+                if ((q.lane & 15) == 15) {
+                    gsx_lds_fadd_row<NG>((unsigned)(uintptr_t)&s_grad[slot * RS], gr);
+                    if (ABS) { gsx_lds_fadd(&s_abs[2 * slot], ab[0]); gsx_lds_fadd(&s_abs[2 * slot + 1], ab[1]); }
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = t; i < bsize * RS; i += 128) {
+            const int j = i / RS, k = i - j * RS;
+            if (k < NG) {
+                const float v = s_grad[i];
+                if (v != 0.f) atomicAdd(&v_rec[(int64_t)s_id[j] * RS + k], v);
+            }
+        }
+        if (ABS) {
+            for (int i = t; i < bsize * 2; i += 128) {
+                const float v = s_abs[i];
+                if (v != 0.f) atomicAdd(&v_abs[(int64_t)s_id[i >> 1] * 2 + (i & 1)], v);
+            }
+        }
+    }
+}
+
+// Kernel generation per launch: 1 = first generation, 2 = one pixel per lane (4 wavefronts per tile), 3 = two pixels
+// per lane (2 wavefronts per tile).  GSX_RASTER forces one; otherwise the forward takes v2 when the grid is small
+// (a single camera gives only ~4.7 wavefronts per SIMD with v2 and half of that with v3: latency hiding wins over
+// instruction count) and v3 when there are enough tiles to fill the chip; the backward takes v3 (its per-entry
+// reduction cost halves).  Thresholds from tools/ab_raster.py on MI355X.
+int raster_variant(bool backward, int64_t n_tiles) {
+    const char *e = getenv("GSX_RASTER");
+    if (e && e[0] >= '1' && e[0] <= '3') return e[0] - '0';
+    if (backward) return 3;
+    return n_tiles >= 8192 ? 3 : 2;
+}
+
 bool use_v1() {
     const char *e = getenv("GSX_RASTER_V1");
     return e && e[0] == '1';
@@ -361,15 +618,20 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
     const int64_t T = C * tile_w * tile_h;
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
     hipStream_t st = (hipStream_t)stream;
-    const bool v1 = use_v1() && !offsets_has_end;
+    const int variant = raster_variant(false, T);
+    const bool v1 = (use_v1() || variant == 1) && !offsets_has_end;
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
         if (v1)                                                                                                     \
             hipLaunchKernelGGL((raster_fwd_kernel_v1<ch, rs>), dim3((unsigned)T), dim3(256), 0, st, rec,           \
                                backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, visibility_min_T,       \
                                render, alphas, last_ids, n_touched);                                                \
-        else                                                                                                        \
+        else if (variant == 2)                                                                                      \
             hipLaunchKernelGGL((raster_fwd_kernel<ch, rs>), dim3((unsigned)T), dim3(256), 0, st, rec, backgrounds, \
+                               offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, visibility_min_T,  \
+                               render, alphas, last_ids, n_touched);                                                \
+        else                                                                                                        \
+            hipLaunchKernelGGL((raster_fwd_kernel2<ch, rs>), dim3((unsigned)T), dim3(128), 0, st, rec, backgrounds, \
                                offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, visibility_min_T,  \
                                render, alphas, last_ids, n_touched);                                                \
     } while (0)
@@ -397,7 +659,8 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     GSX_CHECK_ARG(rec && flatten_ids && v_rec);
     const int64_t T = C * tile_w * tile_h;
     hipStream_t st = (hipStream_t)stream;
-    const bool v1 = use_v1() && !offsets_has_end;
+    const int variant = raster_variant(true, T);
+    const bool v1 = (use_v1() || variant == 1) && !offsets_has_end;
     const char *sb = getenv("GSX_BWD_SCALAR");
     const bool scalar_bwd = sb && sb[0] == '1';
 #define ARGS1 rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
@@ -407,6 +670,9 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
         if (v1) {                                                                                                   \
             if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS1); \
             else hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS1);      \
+        } else if (variant == 3) {                                                                                  \
+            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel2<ch, rs, true>), dim3((unsigned)T), dim3(128), 0, st, ARGS);   \
+            else hipLaunchKernelGGL((raster_bwd_kernel2<ch, rs, false>), dim3((unsigned)T), dim3(128), 0, st, ARGS);        \
         } else if (scalar_bwd) {                                                                                    \
             if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, true, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS);  \
             else hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, false, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS);       \

@@ -1,14 +1,15 @@
-"""Interleaved A/B timing of render stages in ONE process (cdna guide rule 24): v1 vs v2 raster kernels etc.
-usage: python tools/ab_raster.py [N ...]"""
+"""Interleaved A/B timing of render stages in ONE process (cdna guide rule 24): raster kernel generations
+(GSX_RASTER=1|2|3), rocPRIM sort vs tile-binned sort.
+usage: python tools/ab_raster.py [N ...] [C=1 C=8]"""
 import os
 import sys
-import time
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gslam_amd import ops  # noqa: E402
-from gslam_amd.rasterization import rasterization  # noqa: E402
+from gslam_amd._lib import check, lib, ptr, stream_ptr  # noqa: E402
+from gslam_amd.rasterization import rasterization, validate  # noqa: E402
 from gslam_amd.synthetic import make_cameras, make_scene  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -30,84 +31,78 @@ def timed(fn, n=20):
     return ts[len(ts) // 2], ts[0]
 
 
-def main():
-    sizes = [int(a) for a in sys.argv[1:]] or [100_000, 500_000]
-    for N in sizes:
-        W, H, C = 640, 480, 1
-        sc = {k: v.to(dev) for k, v in make_scene(N, 0).items()}
-        viewmats, Ks = make_cameras(C, W, H)
-        viewmats, Ks = viewmats.to(dev), Ks.to(dev)
-        for k in ("means", "quats", "scales", "opacities", "colors", "log_uncertainties"):
-            sc[k].requires_grad_(True)
-        out = rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], viewmats, Ks, W, H,
-                            packed=False, render_mode="RGB+D", log_uncertainties=sc["log_uncertainties"],
-                            backgrounds=torch.zeros(C, 3, device=dev))
-        from gslam_amd.rasterization import validate
-        if not validate(dev):      # capacity grown after a size jump: render again
-            out = rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], viewmats, Ks,
-                                W, H, packed=False, render_mode="RGB+D", log_uncertainties=sc["log_uncertainties"],
-                                backgrounds=torch.zeros(C, 3, device=dev))
+def run(N, C, W=640, H=480):
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    sc = {k: v.to(dev) for k, v in make_scene(N, 0).items()}
+    viewmats, Ks = make_cameras(C, W, H)
+    viewmats, Ks = viewmats.to(dev), Ks.to(dev)
+
+    def render():
+        return rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], viewmats, Ks, W, H,
+                             packed=False, render_mode="RGB+D", log_uncertainties=sc["log_uncertainties"],
+                             backgrounds=torch.zeros(C, 3, device=dev))
+
+    with torch.no_grad():
+        out = render()
+        if not validate(dev):
+            out = render()
             assert validate(dev)
-        M = out.flatten_ids.shape[0]
-        print(f"N={N} M={M} visible={(out.radii > 0).sum().item()}")
-        # direct stage calls
-        from gslam_amd._lib import check, lib, ptr, stream_ptr
-        rec = torch.empty(C, N, 12, device=dev)
-        radii, m2d, dep, con, _, rec, tiles, _ = ops._Projection.apply(
-            sc["means"].detach(), sc["quats"].detach(), sc["scales"].detach(), viewmats, Ks, sc["opacities"].detach(),
-            sc["colors"].detach(), sc["log_uncertainties"].detach(), W, H, 0.3, 0.01, 1e10, 0.0, False, 1 | 2 | 4, True,
-            True)
-        off, flat = out.isect_offsets.contiguous(), out.flatten_ids.contiguous()
-        bg = torch.zeros(C, 5, device=dev)
-        bg[:, 4] = 2.718281828
-        render = torch.empty(C, H, W, 5, device=dev)
-        alphas = torch.empty(C, H, W, 1, device=dev)
-        last = torch.empty(C, H, W, dtype=torch.int32, device=dev)
-        nt = torch.zeros(C, N, dtype=torch.int32, device=dev)
-        v_render = torch.randn(C, H, W, 5, device=dev)
-        v_alpha = torch.randn(C, H, W, 1, device=dev)
-        v_rec = torch.zeros(C, N, 12, device=dev)
-        st = stream_ptr(dev)
+    M = out.flatten_ids.shape[0]
+    print(f"N={N} C={C} {W}x{H} M={M} visible={(out.radii > 0).sum().item()}")
+    radii, m2d, dep, con, _, rec, tiles, _ = ops._Projection.apply(
+        sc["means"], sc["quats"], sc["scales"], viewmats, Ks, sc["opacities"], sc["colors"], sc["log_uncertainties"], W,
+        H, 0.3, 0.01, 1e10, 0.0, False, 1 | 2 | 4, True, True)
+    off, flat = out.isect_offsets.contiguous(), out.flatten_ids.contiguous()
+    bg = torch.zeros(C, 5, device=dev)
+    bg[:, 4] = 2.718281828
+    render_t = torch.empty(C, H, W, 5, device=dev)
+    alphas = torch.empty(C, H, W, 1, device=dev)
+    last = torch.empty(C, H, W, dtype=torch.int32, device=dev)
+    nt = torch.zeros(C, N, dtype=torch.int32, device=dev)
+    v_render = torch.randn(C, H, W, 5, device=dev)
+    v_alpha = torch.randn(C, H, W, 1, device=dev)
+    v_rec = torch.zeros(C, N, 12, device=dev)
+    st = stream_ptr(dev)
 
-        def fwd():
-            check(lib.gsx_raster_fwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, 40, 30, 0.5, ptr(render),
-                                     ptr(alphas), ptr(last), ptr(nt), st), "fwd")
+    def fwd():
+        check(lib.gsx_raster_fwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, tw, th, 0.5, ptr(render_t),
+                                 ptr(alphas), ptr(last), ptr(nt), st), "fwd")
 
-        def bwd():
-            check(lib.gsx_raster_bwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, 40, 30, ptr(alphas),
-                                     ptr(last), ptr(v_render), ptr(v_alpha), ptr(v_rec), None, st), "bwd")
+    def bwd():
+        check(lib.gsx_raster_bwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, tw, th, ptr(alphas),
+                                 ptr(last), ptr(v_render), ptr(v_alpha), ptr(v_rec), None, st), "bwd")
 
-        def sort():
-            ops.isect_tiles(m2d, radii, dep, 16, 40, 30, tiles_per_gauss=tiles)
+    def sort1():
+        ops.isect_tiles(m2d, radii, dep, 16, tw, th, tiles_per_gauss=tiles)
 
-        flat_buf = torch.empty(M, dtype=torch.int32, device=dev)
+    flat_buf = torch.empty(M, dtype=torch.int32, device=dev)
 
-        def sort2():
-            ops.isect_bin_sort(m2d, radii, dep, 40, 30, M, None, flat_buf)
+    def sort2():
+        ops.isect_bin_sort(m2d, radii, dep, tw, th, M, None, flat_buf)
 
-        res = {}
-        for rnd in range(2):
-            for ver in ("1", "0"):
-                os.environ["GSX_RASTER_V1"] = ver
-                fwd()
-                res.setdefault(("fwd", ver), []).append(timed(fwd))
-                res.setdefault(("bwd", ver), []).append(timed(bwd))
-        os.environ["GSX_RASTER_V1"] = "0"
-        for rnd in range(2):
-            for sc_ in ("1", "0"):
-                os.environ["GSX_BWD_SCALAR"] = sc_
-                bwd()
-                res.setdefault(("bwd-scalar" if sc_ == "1" else "bwd-readlane", "0"), []).append(timed(bwd))
-        os.environ["GSX_BWD_SCALAR"] = "0"
-        for k, v in sorted(res.items()):
-            print(f"  raster_{k[0]} {'v1' if k[1] == '1' else 'v2'}: median/min us per round = "
-                  + ", ".join(f"{a:.1f}/{b:.1f}" for a, b in v))
-        os.environ["GSX_SORT_V1"] = "1"
-        print(f"  isect_tiles v1 rocPRIM (scan..sort, incl. M read-back): {timed(sort)[0]:.1f} us")
-        os.environ["GSX_SORT_V1"] = "0"
-        print(f"  isect_bin_sort v2 (diff/offsets/emit/tile-sort, sync-free): {timed(sort2)[0]:.1f} us")
-        assert torch.equal(flat_buf, flat), "v2 sort differs from v1"
+    res = {}
+    for _ in range(2):
+        for ver in ("1", "2", "3"):
+            os.environ["GSX_RASTER"] = ver
+            fwd()
+            res.setdefault(("fwd", ver), []).append(timed(fwd))
+            res.setdefault(("bwd", ver), []).append(timed(bwd))
+    os.environ.pop("GSX_RASTER", None)
+    fwd()
+    res[("fwd", "auto")] = [timed(fwd)]
+    res[("bwd", "auto")] = [timed(bwd)]
+    for k, v in sorted(res.items()):
+        print(f"  raster_{k[0]} v{k[1]}: median/min us = " + ", ".join(f"{a:.1f}/{b:.1f}" for a, b in v))
+    os.environ["GSX_SORT_V1"] = "1"
+    print(f"  isect_tiles v1 rocPRIM (scan..sort, incl. M read-back): {timed(sort1)[0]:.1f} us")
+    os.environ["GSX_SORT_V1"] = "0"
+    print(f"  isect_bin_sort v2 (diff/offsets/emit/tile-sort, sync-free): {timed(sort2)[0]:.1f} us")
+    assert torch.equal(flat_buf, flat), "v2 sort differs from v1"
 
 
 if __name__ == "__main__":
-    main()
+    args = [a for a in sys.argv[1:] if not a.startswith("C=")]
+    cams = [int(a[2:]) for a in sys.argv[1:] if a.startswith("C=")] or [1]
+    for N in [int(a) for a in args] or [100_000, 500_000]:
+        for C in cams:
+            run(N, C)
