@@ -198,8 +198,20 @@ def main():
     step_fn = lambda: ba.step(window)
     if use_graph:
         from gslam_amd.mapping import GraphedBundleAdjuster
-        gba = GraphedBundleAdjuster(ba, window)
-        step_fn = gba.step
+        gba, ok = None, 1
+        try:
+            gba = GraphedBundleAdjuster(ba, window)
+        except Exception as e:  # e.g. a runtime that cannot capture next to a live RCCL communicator
+            ok = 0
+            print(f"bench.py[rank {rank}]: HIP-graph capture failed ({e!r}); running eagerly", file=sys.stderr)
+        if world > 1:           # all ranks must take the same path
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            td.all_reduce(flag, op=td.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            step_fn = gba.step
+        else:
+            use_graph = False
 
     def barrier():
         torch.cuda.synchronize()
@@ -225,6 +237,8 @@ def main():
         if use_graph:
             gba = GraphedBundleAdjuster(ba, window)
             step_fn = gba.step
+        else:
+            step_fn = lambda: ba.step(window)
     else:
         raise RuntimeError("intersection buffers kept overflowing")
     if world > 1:
