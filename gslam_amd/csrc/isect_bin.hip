@@ -16,9 +16,9 @@
 //   3. emit_binned   : per workgroup: LDS per-tile counts, ONE global atomic per touched tile to reserve a range,
 //                      LDS cursors to place 8-byte entries (depth_bits<<32 | flatten_id); rectangles larger than 16
 //                      tiles are walked cooperatively by the whole wavefront
-//   4. tile_sort     : one workgroup per tile: rank sort of 256-key chunks + multiway merge by lower bounds, all in
-//                      LDS (<= 4096 entries), or an in-place bitonic network in global memory for larger tiles;
-//                      writes flatten_ids / isect_ids
+//   4. tile_sort     : one workgroup per tile: merge sort by ranks (64-key rank-sorted runs, then log2(n/64) stable
+//                      rank-merge levels with binary searches) in an LDS window of up to 8192 keys; larger tiles
+//                      continue the merge levels in global memory; writes flatten_ids / isect_ids
 #include "gsx_common.h"
 
 namespace {
@@ -213,71 +213,77 @@ __global__ __launch_bounds__(BIN_THREADS) void emit_binned_kernel(const float *_
 }
 
 // ---- 4. per-tile sort -----------------------------------------------------------------------------------------------
-template <typename Ptr>
-__device__ __forceinline__ void cmp_exchange(Ptr k, int a, int b) {
-    const unsigned long long ka = k[a], kb = k[b];
-    if (ka > kb) { k[a] = kb; k[b] = ka; }
-}
-
-// all-ascending bitonic network over the first n slots of k (virtual +inf padding up to the next power of two).
-// Compare-exchange indices are dealt to the wavefronts in contiguous chunks of Lc, so every step whose partner
-// distance is <= Lc only touches the wavefront's own 2*Lc-element slice: LDS operations of one wavefront execute in
-// order, so such steps need no workgroup barrier (WAVE_LOCAL; LDS only).  For 512 keys that leaves 4 barriers of 45.
-template <bool WAVE_LOCAL, typename Ptr>
-__device__ __forceinline__ void bitonic_sort(Ptr k, int n) {
-    int P = 1;
-    while (P < n) P <<= 1;
-    const int half = P >> 1;
-    const int nw = SORT_THREADS / 64;
-    const int Lc = max(64, half / nw);                  // CE indices per wavefront
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lo = wave * Lc;
-    bool prev_cross = true;
-    auto sync = [&](bool cross) {
-        if (!WAVE_LOCAL || cross || prev_cross) __syncthreads();
-        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        prev_cross = cross;
-    };
-    for (int size = 2; size <= P; size <<= 1) {
-        const int hs = size >> 1;
-        sync(size > 2 * Lc);
-        if (lo < half)
-            for (int i = lo + lane; i < lo + Lc; i += 64) {  // mirror step
-                const int blk = i / hs, off = i - blk * hs;
-                const int a = blk * size + off, b = blk * size + size - 1 - off;
-                if (b < n) cmp_exchange(k, a, b);
-            }
-        for (int j = hs >> 1; j >= 1; j >>= 1) {  // half cleaners
-            sync(j > Lc);
-            if (lo < half)
-                for (int i = lo + lane; i < lo + Lc; i += 64) {
-                    const int blk = i / j, off = i - blk * j;
-                    const int a = blk * 2 * j + off, b = a + j;
-                    if (b < n) cmp_exchange(k, a, b);
-                }
-        }
-    }
-    __syncthreads();
-}
-
-// One workgroup per tile.  Tiles that fit the LDS window (n <= cap keys, cap chosen by the host from the capacity)
-// are merge-sorted by RANKS, ping-ponging between two LDS buffers:
+// One workgroup per tile.  Up to `cap` keys (LDS window chosen by the host from the capacity) are merge-sorted by
+// RANKS, ping-ponging between two LDS buffers:
 //   1. runs of 64 keys are sorted by counting ranks (position = number of smaller keys in the run; all lanes stream
 //      the run as 16-byte broadcast reads, (a - k) >> 63 is the comparison: keys are < 2^63)
 //   2. log2(n/64) merge levels: a key's position in the merged pair of runs = its position in its own run + the
 //      number of partner keys before it (lower bound from the left run, upper bound from the right run: a stable
-//      merge), found by a binary search in LDS.  One barrier per level, every key moves exactly once per level.
+//      merge), found by a binary search.  One barrier per level, every key moves exactly once per level.
 // ~ (32 + sum of log2(run)) short steps per key instead of log^2(n)/2 compare-exchanges with a barrier each.
-// Larger tiles fall back to an in-place bitonic network in global memory (correct for any size).
+// Tiles larger than the window sort window-sized chunks in LDS and continue the same merge levels in global memory
+// (L2), ping-ponging between the entry buffer and a scratch copy.
 constexpr int RUN0 = 64;
 
+// one rank-merge level: runs of length `run` in src[0..n) -> runs of 2*run in dst
+template <typename Ptr>
+__device__ __forceinline__ void merge_level(Ptr src, Ptr dst, int n, int run) {
+    for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
+        const unsigned long long k = src[i];
+        const int r = i / run;
+        const int own = r * run, pair = (r & ~1) * run;
+        const int pb = (r ^ 1) * run;                          // partner run
+        const int plen = max(0, min(run, n - pb));
+        const bool right = (r & 1) != 0;
+        int lo = 0, hi = plen;                                  // left run: #partner < k ; right run: #partner <= k
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const unsigned long long v = src[pb + mid];
+            const bool before = right ? (v <= k) : (v < k);
+            if (before) lo = mid + 1; else hi = mid;
+        }
+        dst[pair + (i - own) + lo] = k;
+    }
+}
+
+// sorts n <= cap keys read from `in` (global); returns the LDS buffer that holds the sorted keys
+__device__ __forceinline__ unsigned long long *lds_sort(const unsigned long long *__restrict__ in, int n,
+                                                        unsigned long long *bufA, unsigned long long *bufB) {
+    const unsigned long long INF = ~0ull >> 1;            // larger than any key, still < 2^63
+    const int n_pad = (n + RUN0 - 1) / RUN0 * RUN0;       // <= cap (cap is a multiple of 64)
+    unsigned long long *src = bufA, *dst = bufB;
+    __syncthreads();                                       // callers may still be reading the buffers
+    for (int i = threadIdx.x; i < n_pad; i += SORT_THREADS) src[i] = (i < n) ? in[i] : INF;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
+        const unsigned long long k = src[i];
+        const int cb = i & ~(RUN0 - 1);
+        const ulonglong2 *s2 = reinterpret_cast<const ulonglong2 *>(src + cb);
+        unsigned int rank = 0;
+#pragma unroll 8
+        for (int m = 0; m < RUN0 / 2; ++m) {
+            const ulonglong2 a = s2[m];
+            rank += (unsigned int)((a.x - k) >> 63) + (unsigned int)((a.y - k) >> 63);
+        }
+        dst[cb + rank] = k;
+    }
+    __syncthreads();
+    { unsigned long long *t = src; src = dst; dst = t; }
+    for (int run = RUN0; run < n; run <<= 1) {
+        merge_level(src, dst, n, run);
+        __syncthreads();
+        unsigned long long *t = src; src = dst; dst = t;
+    }
+    return src;
+}
+
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long long *__restrict__ entries,
+                                                                 unsigned long long *__restrict__ scratch,
                                                                  const int32_t *__restrict__ offsets, int n_tiles,
                                                                  int tile_n_bits, int64_t M_cap, int cap,
                                                                  int64_t *__restrict__ isect_ids,
                                                                  int32_t *__restrict__ flatten_ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
-    unsigned long long *src = s_mem, *dst = s_mem + cap;
     const int tile = blockIdx.x;
     const int64_t start = min((int64_t)offsets[tile], M_cap);
     const int64_t end = min((int64_t)offsets[tile + 1], M_cap);
@@ -286,58 +292,28 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long l
     const int c = tile / n_tiles, tl = tile - c * n_tiles;
     const long long hi_part = ((long long)c << (32 + tile_n_bits)) | ((long long)tl << 32);
     unsigned long long *seg = entries + start;
+    const unsigned long long *sorted;
     if (n <= cap) {
-        const unsigned long long INF = ~0ull >> 1;            // larger than any key, still < 2^63
-        const int n_pad = (n + RUN0 - 1) / RUN0 * RUN0;       // <= cap (cap is a multiple of 64)
-        for (int i = threadIdx.x; i < n_pad; i += SORT_THREADS) src[i] = (i < n) ? seg[i] : INF;
-        __syncthreads();
-        for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
-            const unsigned long long k = src[i];
-            const int cb = i & ~(RUN0 - 1);
-            const ulonglong2 *s2 = reinterpret_cast<const ulonglong2 *>(src + cb);
-            unsigned int rank = 0;
-#pragma unroll 8
-            for (int m = 0; m < RUN0 / 2; ++m) {
-                const ulonglong2 a = s2[m];
-                rank += (unsigned int)((a.x - k) >> 63) + (unsigned int)((a.y - k) >> 63);
-            }
-            dst[cb + rank] = k;
+        sorted = lds_sort(seg, n, s_mem, s_mem + cap);
+    } else {
+        for (int cb = 0; cb < n; cb += cap) {              // window-sized chunks: sort in LDS, write back in place
+            const int len = min(cap, n - cb);
+            const unsigned long long *res = lds_sort(seg + cb, len, s_mem, s_mem + cap);
+            for (int i = threadIdx.x; i < len; i += SORT_THREADS) seg[cb + i] = res[i];
         }
         __syncthreads();
-        { unsigned long long *t = src; src = dst; dst = t; }
-        for (int run = RUN0; run < n; run <<= 1) {
-            for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
-                const unsigned long long k = src[i];
-                const int r = i / run;
-                const int own = r * run, pair = (r & ~1) * run;
-                const int pb = (r ^ 1) * run;                          // partner run
-                const int plen = max(0, min(run, n - pb));
-                const bool right = (r & 1) != 0;
-                int lo = 0, hi = plen;                                  // left run: #partner < k ; right run: #partner <= k
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    const unsigned long long v = src[pb + mid];
-                    const bool before = right ? (v <= k) : (v < k);
-                    if (before) lo = mid + 1; else hi = mid;
-                }
-                dst[pair + (i - own) + lo] = k;
-            }
+        unsigned long long *src = seg, *dst = scratch + start;
+        for (int run = cap; run < n; run <<= 1) {          // remaining merge levels through global memory (L2)
+            merge_level(src, dst, n, run);
             __syncthreads();
             unsigned long long *t = src; src = dst; dst = t;
         }
-        for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
-            const unsigned long long k = src[i];
-            flatten_ids[start + i] = (int32_t)(uint32_t)k;
-            if (isect_ids) isect_ids[start + i] = hi_part | (long long)(k >> 32);
-        }
-    } else {
-        __syncthreads();
-        bitonic_sort<false>(seg, n);  // in place in global memory (L2): correct for any size, only huge tiles land here
-        for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
-            const unsigned long long k = seg[i];
-            flatten_ids[start + i] = (int32_t)(uint32_t)k;
-            if (isect_ids) isect_ids[start + i] = hi_part | (long long)(k >> 32);
-        }
+        sorted = src;
+    }
+    for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
+        const unsigned long long k = sorted[i];
+        flatten_ids[start + i] = (int32_t)(uint32_t)k;
+        if (isect_ids) isect_ids[start + i] = hi_part | (long long)(k >> 32);
     }
 }
 
@@ -348,7 +324,7 @@ int bit_length(uint32_t v) {
 }
 
 struct BinLayout {
-    int64_t diff_off, cursor_off, entries_off, total;
+    int64_t diff_off, cursor_off, entries_off, scratch_off, total;
 };
 
 BinLayout bin_layout(int64_t C, int tile_w, int tile_h, int64_t M_cap) {
@@ -358,7 +334,8 @@ BinLayout bin_layout(int64_t C, int tile_w, int tile_h, int64_t M_cap) {
     L.diff_off = 0;
     L.cursor_off = gsx_align256(C * G * 4);
     L.entries_off = L.cursor_off + gsx_align256(T * 4);
-    L.total = L.entries_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8) + 256;
+    L.scratch_off = L.entries_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);
+    L.total = L.scratch_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8) + 256;
     return L;
 }
 
@@ -391,6 +368,7 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
     int *diff = (int *)(ws + L.diff_off);
     int32_t *cursor = (int32_t *)(ws + L.cursor_off);
     unsigned long long *entries = (unsigned long long *)(ws + L.entries_off);
+    unsigned long long *scratch = (unsigned long long *)(ws + L.scratch_off);
     if (hipMemsetAsync(diff, 0, (size_t)(C * G * 4), st) != hipSuccess) return GSX_E_LAUNCH;
     const unsigned gblocks = (unsigned)((N + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
     if (N > 0) {
@@ -407,8 +385,15 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
         GSX_CHECK_LAUNCH();
         // LDS window: 4x the average tile (tiles are unbalanced), between 512 and 4096 keys, two buffers of it
         int64_t cap = 512;
-        while (cap < 4 * (M_cap / T + 1) && cap < 4096) cap <<= 1;
-        hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), (size_t)(2 * cap * 8), st, entries,
+        while (cap < 4 * (M_cap / T + 1) && cap < 8192) cap <<= 1;
+        const size_t lds_bytes = (size_t)(2 * cap * 8);     // up to 128 KiB of the CU's 160 KiB
+        if (lds_bytes > 64 * 1024 &&
+            hipFuncSetAttribute((const void *)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess) {
+            gsx_set_error("gsx_isect_bin_sort: cannot raise the dynamic LDS limit to %zu bytes", lds_bytes);
+            return GSX_E_LAUNCH;
+        }
+        hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), lds_bytes, st, entries, scratch,
                            offsets, (int)n_tiles, bit_length((uint32_t)n_tiles), M_cap, (int)cap, isect_ids,
                            flatten_ids);
         GSX_CHECK_LAUNCH();
