@@ -30,6 +30,23 @@ void gsx_set_error(const char *fmt, ...);
 
 static inline int64_t gsx_align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
+// ---- zero fill -----------------------------------------------------------------------------------------------------
+// All zero fills go through a kernel, never hipMemsetAsync: a memset node captured into a HIP graph was observed
+// (ROCm 7.2, gfx950) to write a non-zero pattern from the second replay of the graph on.
+#ifdef __HIPCC__
+static __global__ __launch_bounds__(256) void gsx_zero_u32_kernel(uint32_t *__restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+// n_words 4-byte words at p (4-byte aligned); returns false if the launch failed
+static inline bool gsx_zero_async(void *p, int64_t n_words, hipStream_t st) {
+    if (n_words <= 0) return true;
+    hipLaunchKernelGGL(gsx_zero_u32_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, (uint32_t *)p,
+                       n_words);
+    return hipGetLastError() == hipSuccess;
+}
+#endif
+
 // ---- wave64 primitives --------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 // DPP row/bcast reduction: 4 row_shr steps inside each 16-lane row, then row_bcast:15 / row_bcast:31 (gfx9).

@@ -201,7 +201,7 @@ extern "C" int gsx_isect_offset_encode(const int64_t *isect_ids, int64_t M, int6
     const int64_t n_tiles = (int64_t)tile_w * tile_h;
     const int64_t T = C * n_tiles;
     if (M == 0) {
-        if (hipMemsetAsync(offsets, 0, sizeof(int32_t) * T, st) != hipSuccess) return GSX_E_LAUNCH;
+        if (!gsx_zero_async(offsets, T, st)) return GSX_E_LAUNCH;
         return GSX_OK;
     }
     GSX_CHECK_ARG(isect_ids);

@@ -113,7 +113,9 @@ __global__ __launch_bounds__(1024) void tile_offsets_kernel(const int *__restric
         __syncthreads();
         for (int i = t; i < n_tiles; i += 1024) {
             const int y = i / tile_w, x = i - y * tile_w;
-            offsets[(int64_t)c * n_tiles + i] = s_g[y * gw + x];  // per-tile count, scanned in place below
+            const int cnt = s_g[y * gw + x];
+            if (cnt < 0) atomicOr(status, 2);                     // corrupt difference grid (never from a sane input)
+            offsets[(int64_t)c * n_tiles + i] = max(cnt, 0);      // per-tile count, scanned in place below
         }
         __syncthreads();
     }
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(BIN_THREADS) void emit_binned_kernel(const float *_
         const unsigned int klo = (unsigned int)idx, khi = has ? __float_as_uint(depths[idx]) : 0u;
         walk_rects(rects[it], tile_w, klo, khi, [&](int tile, unsigned int lo, unsigned int hi) {
             const int pos = atomicAdd(&s_cnt[tile], 1);
-            if ((int64_t)pos < M_cap) entries[pos] = ((unsigned long long)hi << 32) | lo;
+            if ((uint64_t)(uint32_t)pos < (uint64_t)M_cap) entries[pos] = ((unsigned long long)hi << 32) | lo;
         });
     }
 }
@@ -281,12 +283,12 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long l
                                                                  unsigned long long *__restrict__ scratch,
                                                                  const int32_t *__restrict__ offsets, int n_tiles,
                                                                  int tile_n_bits, int64_t M_cap, int cap,
-                                                                 int64_t *__restrict__ isect_ids,
+                                                                 uint32_t id_max, int64_t *__restrict__ isect_ids,
                                                                  int32_t *__restrict__ flatten_ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
     const int tile = blockIdx.x;
-    const int64_t start = min((int64_t)offsets[tile], M_cap);
-    const int64_t end = min((int64_t)offsets[tile + 1], M_cap);
+    const int64_t start = max((int64_t)0, min((int64_t)offsets[tile], M_cap));
+    const int64_t end = max((int64_t)0, min((int64_t)offsets[tile + 1], M_cap));
     const int n = (int)(end - start);
     if (n <= 0) return;
     const int c = tile / n_tiles, tl = tile - c * n_tiles;
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long l
     }
     for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
         const unsigned long long k = sorted[i];
-        flatten_ids[start + i] = (int32_t)(uint32_t)k;
+        flatten_ids[start + i] = (int32_t)min((uint32_t)k, id_max);   // never hand an out-of-range gather index on
         if (isect_ids) isect_ids[start + i] = hi_part | (long long)(k >> 32);
     }
 }
@@ -354,7 +356,7 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
     GSX_CHECK_ARG(M_cap == 0 || flatten_ids);
     const int64_t n_tiles = (int64_t)tile_w * tile_h;
     const int64_t T = C * n_tiles;
-    GSX_CHECK_ARG(T < ((int64_t)1 << 30) && C < 65536);
+    GSX_CHECK_ARG(T < ((int64_t)1 << 30) && C < 65536 && C * N < ((int64_t)1 << 31));
     const int64_t G = (int64_t)(tile_w + 1) * (tile_h + 1);
     GSX_CHECK_ARG(G * 4 + 8192 <= 65536);  // the difference grid must fit the default 64 KiB LDS window next to the scan buffer
     const BinLayout L = bin_layout(C, tile_w, tile_h, M_cap);
@@ -369,7 +371,7 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
     int32_t *cursor = (int32_t *)(ws + L.cursor_off);
     unsigned long long *entries = (unsigned long long *)(ws + L.entries_off);
     unsigned long long *scratch = (unsigned long long *)(ws + L.scratch_off);
-    if (hipMemsetAsync(diff, 0, (size_t)(C * G * 4), st) != hipSuccess) return GSX_E_LAUNCH;
+    if (!gsx_zero_async(diff, C * G, st)) return GSX_E_LAUNCH;
     const unsigned gblocks = (unsigned)((N + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
     if (N > 0) {
         hipLaunchKernelGGL(tile_diff_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(G * 4), st, means2d,
@@ -394,7 +396,8 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
             return GSX_E_LAUNCH;
         }
         hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), lds_bytes, st, entries, scratch,
-                           offsets, (int)n_tiles, bit_length((uint32_t)n_tiles), M_cap, (int)cap, isect_ids,
+                           offsets, (int)n_tiles, bit_length((uint32_t)n_tiles), M_cap, (int)cap,
+                           (uint32_t)(C * N - 1), isect_ids,
                            flatten_ids);
         GSX_CHECK_LAUNCH();
     }

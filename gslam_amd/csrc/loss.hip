@@ -258,7 +258,7 @@ extern "C" int gsx_isotropic_loss(const float *log_scales, const int32_t *vis_co
     GSX_CHECK_ARG(log_scales && vis_count && sum_out && v_log_scales && N >= 0);
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) {
-        if (hipMemsetAsync(sum_out, 0, sizeof(float), st) != hipSuccess) return GSX_E_LAUNCH;
+        if (!gsx_zero_async(sum_out, 1, st)) return GSX_E_LAUNCH;
         return GSX_OK;
     }
     if (!workspace || workspace_bytes < gsx_isotropic_workspace_bytes(N)) {

@@ -560,7 +560,7 @@ extern "C" int gsx_project_bwd(const float *means, const float *quats, const flo
     if (v_rec && (flags & GSX_PROJ_BETAS)) GSX_CHECK_ARG(log_uncertainties && v_log_unc);
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) {
-        if (v_viewmats && hipMemsetAsync(v_viewmats, 0, sizeof(float) * 16 * C, st) != hipSuccess) return GSX_E_LAUNCH;
+        if (v_viewmats && !gsx_zero_async(v_viewmats, 16 * C, st)) return GSX_E_LAUNCH;
         return GSX_OK;
     }
     const unsigned blocks = (unsigned)((N + PBWD_THREADS - 1) / PBWD_THREADS);

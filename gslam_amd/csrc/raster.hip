@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(const float *__restrict
     const Quad q = make_quad(tile_w, tile_h, W, H);
     const int n_tiles_total = gridDim.x;
     // has_end: offsets holds T+1 entries and M is the CAPACITY of flatten_ids (sync-free path); otherwise M is exact
-    const int start = min(offsets[q.tile], (int)M);
-    const int end = (has_end || q.tile + 1 < n_tiles_total) ? min(offsets[q.tile + 1], (int)M) : (int)M;
+    const int start = max(0, min(offsets[q.tile], (int)M));
+    const int end = (has_end || q.tile + 1 < n_tiles_total) ? max(0, min(offsets[q.tile + 1], (int)M)) : (int)M;
 
     // The CU has ONE scalar unit for its four SIMDs, so the per-entry loop keeps its state in vector registers and
     // arithmetic instead of lane masks and branches: a finished pixel simply carries a live transmittance of 0.
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
     const Quad q = make_quad(tile_w, tile_h, W, H);
     const int t = threadIdx.x;
     const int64_t p = ((int64_t)q.c * H + min(q.py, H - 1)) * W + min(q.px, W - 1);
-    const int start = min(offsets[q.tile], (int)M);
+    const int start = max(0, min(offsets[q.tile], (int)M));
     const int last = q.inside ? last_ids[p] : -1;
     int wmax = last;
 #pragma unroll
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel2(const float *__restric
                                                           int32_t *__restrict__ n_touched) {
     const Half q = make_half(tile_w, tile_h, W, H);
     const int n_tiles_total = gridDim.x;
-    const int start = min(offsets[q.tile], (int)M);
-    const int end = (has_end || q.tile + 1 < n_tiles_total) ? min(offsets[q.tile + 1], (int)M) : (int)M;
+    const int start = max(0, min(offsets[q.tile], (int)M));
+    const int end = (has_end || q.tile + 1 < n_tiles_total) ? max(0, min(offsets[q.tile + 1], (int)M)) : (int)M;
 
     float T0 = 1.0f, T1 = 1.0f;
     float pix0[CH], pix1[CH];
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel2(
     const int t = threadIdx.x;
     const int64_t p0 = ((int64_t)q.c * H + min(q.py0, H - 1)) * W + min(q.px, W - 1);
     const int64_t p1 = ((int64_t)q.c * H + min(q.py1, H - 1)) * W + min(q.px, W - 1);
-    const int start = min(offsets[q.tile], (int)M);
+    const int start = max(0, min(offsets[q.tile], (int)M));
     const int last0 = q.in0 ? last_ids[p0] : -1, last1 = q.in1 ? last_ids[p1] : -1;
     int wmax = max(last0, last1);
 #pragma unroll

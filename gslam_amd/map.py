@@ -38,8 +38,9 @@ class GaussianSplattingData(torch.nn.Module):
         key = (n_cams, self.background._version, self.background.data_ptr())
         cache = self.__dict__.setdefault("_bg_cache", {})
         if key not in cache:
-            cache.clear()
-            cache[key] = self.background.tile([n_cams, 1])
+            if len(cache) >= 64:
+                return self.background.tile([n_cams, 1])
+            cache[key] = self.background.tile([n_cams, 1])   # never evicted: HIP graphs may hold its address
         return cache[key]
 
     def render(self, cameras: List[Camera], viewmats: List[torch.Tensor], visibility_min_T: float = 0.5):

@@ -249,19 +249,20 @@ class GraphedBundleAdjuster:
                 assert validate()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # warm-up and capture share one side stream (autograd pins AccumulateGrad nodes to the stream of first use)
         self.graph = torch.cuda.CUDAGraph()
         self.graph2 = None
         # thread_local: the RCCL watchdog thread may query events while this thread captures
         mode = "thread_local" if self.multi else "global"
         if not self.multi:
-            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode=mode):
                 self.total, self.photometric = ba.step(window, regularize)
         else:
-            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode=mode):
                 self.total, self.photometric = ba.render_backward(window, regularize)
             ba.reduce()
             self.graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=mode):
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool(), stream=side, capture_error_mode=mode):
                 ba.update()
 
     def step(self):

@@ -157,9 +157,8 @@ def _packed_backgrounds(backgrounds: Optional[Tensor], C: int, with_depth: bool,
     if with_beta:
         parts.append(torch.full((C, 1), math.e, device=backgrounds.device, dtype=backgrounds.dtype))
     bg = torch.cat(parts, dim=-1)
-    if not backgrounds.requires_grad:
-        if len(_BG_CACHE) > 16:
-            _BG_CACHE.clear()
+    if not backgrounds.requires_grad and len(_BG_CACHE) < 512:
+        # entries are never evicted: a captured HIP graph may have a cached tensor's address baked in (they are tiny)
         _BG_CACHE[key] = bg
         _BG_CACHE[("keepalive",) + key] = backgrounds      # pin the id / data_ptr while cached
     return bg

@@ -112,3 +112,99 @@ def warp_track(new_frame: Frame, ref_frame: Frame, ref_img: torch.Tensor, ref_de
         opt.step()
         sched.step()
     return loss
+
+
+class GraphedTracker:
+    """The tracking closure (C = 1 render forward + active-nerf loss + backward to the pose delta and the exposure
+    parameters, gslam/frontend.py:621-649) captured once into a HIP graph over a persistent "slot" and replayed for
+    every closure of every frame: ~12 kernel launches become one graph launch.  The optimiser logic (10 Adam steps +
+    one strong-Wolfe L-BFGS step, frontend.py:613-658) stays on the host exactly as in the reference, including its
+    one ``loss.item()`` read-back per closure."""
+
+    def __init__(self, splats: GaussianSplattingData, camera, conf: Optional[TrackingConfig] = None):
+        from .losses import fused_tracking_loss
+        from .primitives import PoseZhou
+        from .rasterization import validate
+        self.conf = conf or TrackingConfig()
+        self.splats, self.camera = splats, camera
+        dev = splats.means.device
+        H, W = camera.height, camera.width
+        self.pose = PoseZhou(torch.eye(4, device=dev)).to(dev)
+        self.exposure = torch.zeros(2, device=dev, requires_grad=True)
+        self.img = torch.zeros(H, W, 3, device=dev)
+        self.params = [self.pose.dt, self.pose.dR, self.exposure]
+        self._loss_fn = fused_tracking_loss
+        self.graph = None
+        self.loss = None
+        self._validate = validate
+
+    def _closure_body(self):
+        for p in self.params:
+            p.grad = None               # AccumulateGrad then adopts the fresh gradient tensor (no accumulate kernel)
+        out = self.splats([self.camera], [self.pose], render_depth=True)
+        loss = self._loss_fn(out, self.img, self.exposure)
+        loss.backward()
+        return loss.detach()
+
+    def load(self, frame: Frame, prev_exposure: Optional[torch.Tensor] = None):
+        with torch.no_grad():
+            self.pose.Rt.copy_(frame.pose())
+            self.pose.dR.zero_()
+            self.pose.dt.zero_()
+            self.img.copy_(frame.img)
+            self.exposure.copy_(frame.exposure_params if prev_exposure is None else prev_exposure)
+
+    def capture(self):
+        # warm-up and capture run on the SAME side stream: autograd pins each leaf's AccumulateGrad node to the stream
+        # it was first used on, and a capture on another stream would push the accumulation out of the graph
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._closure_body()
+            assert self._validate(), "intersection capacity changed during warm-up; capture again"
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.loss = self._closure_body()
+
+    def closure(self):
+        if self.graph is None:
+            return self._closure_body()
+        self.graph.replay()
+        return self.loss
+
+    def track(self, frame: Frame, prev_exposure: Optional[torch.Tensor] = None, max_eval: Optional[int] = None):
+        """igs_track_lbfgs on the slot; writes the optimised pose / exposure back into ``frame``.  Returns
+        (last_loss, n_closures)."""
+        conf = self.conf
+        self.load(frame, prev_exposure)
+        if self.graph is None:
+            self.capture()
+            self.load(frame, prev_exposure)
+        n_evals = 0
+        last = None
+
+        def closure():
+            nonlocal n_evals, last
+            n_evals += 1
+            loss = self.closure()
+            last = loss.item()                      # frontend.py:648 ("this sync is okay because lbfgs syncs anyway")
+            return loss
+
+        warm = torch.optim.Adam(self.params, conf.pose_optim_lr)
+        for _ in range(conf.n_adam_warmup):
+            closure()
+            warm.step()
+        kw = {} if max_eval is None else {"max_eval": max_eval}
+        lbfgs = torch.optim.LBFGS(self.params, history_size=conf.lbfgs_history, line_search_fn='strong_wolfe',
+                                  tolerance_change=1e-9, lr=conf.pose_optim_lr, **kw)
+        lbfgs.step(closure)
+        with torch.no_grad():
+            new_pose = self.pose().detach().clone()
+            frame.pose.Rt.copy_(new_pose)
+            frame.pose.dR.zero_()
+            frame.pose.dt.zero_()
+            frame.exposure_params.data.copy_(self.exposure.detach())
+        return last, n_evals
