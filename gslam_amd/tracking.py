@@ -117,11 +117,16 @@ def warp_track(new_frame: Frame, ref_frame: Frame, ref_img: torch.Tensor, ref_de
 class GraphedTracker:
     """The tracking closure (C = 1 render forward + active-nerf loss + backward to the pose delta and the exposure
     parameters, gslam/frontend.py:621-649) captured once into a HIP graph over a persistent "slot" and replayed for
-    every closure of every frame: ~12 kernel launches become one graph launch.  The optimiser logic (10 Adam steps +
-    one strong-Wolfe L-BFGS step, frontend.py:613-658) stays on the host exactly as in the reference, including its
-    one ``loss.item()`` read-back per closure."""
+    every closure of every frame: ~12 kernel launches become one graph launch.
 
-    def __init__(self, splats: GaussianSplattingData, camera, conf: Optional[TrackingConfig] = None):
+    ``device_optimizer=True`` (default) also moves the optimiser of frontend.py:613-658 - 10 Adam steps, then one
+    strong-Wolfe L-BFGS step - onto the device (csrc/track_opt.h): the state machine is advanced by one single-lane
+    kernel at the end of the captured closure, so a tracked frame is ``n_adam + max_eval + 1`` graph launches and ONE
+    read-back at the end instead of one ``loss.item()`` per closure (frontend.py:648).  With ``False`` the optimiser
+    logic stays on the host exactly as in the reference (torch.optim.Adam / torch.optim.LBFGS)."""
+
+    def __init__(self, splats: GaussianSplattingData, camera, conf: Optional[TrackingConfig] = None,
+                 device_optimizer: bool = True, max_eval: int = 25):
         from .losses import fused_tracking_loss
         from .primitives import PoseZhou
         from .rasterization import validate
@@ -137,14 +142,31 @@ class GraphedTracker:
         self.graph = None
         self.loss = None
         self._validate = validate
+        self.device_optimizer = device_optimizer
+        self.max_eval = max_eval
+        self._state = self._report = None
+        if device_optimizer:
+            from ._lib import lib
+            self._state = torch.zeros(int(lib.gsx_track_opt_state_bytes()), dtype=torch.uint8, device=dev)
+            self._report = torch.zeros(8, dtype=torch.float32, device=dev)
 
-    def _closure_body(self):
+    def _closure_body(self, advance: bool = False):
         for p in self.params:
             p.grad = None               # AccumulateGrad then adopts the fresh gradient tensor (no accumulate kernel)
         out = self.splats([self.camera], [self.pose], render_depth=True)
         loss = self._loss_fn(out, self.img, self.exposure)
         loss.backward()
-        return loss.detach()
+        loss = loss.detach()
+        if advance:
+            import ctypes as C
+            from ._lib import check, lib, stream_ptr
+            n = len(self.params)
+            check(lib.gsx_track_opt_advance(
+                self._state.data_ptr(), n, (C.c_void_p * n)(*[p.data_ptr() for p in self.params]),
+                (C.c_void_p * n)(*[p.grad.data_ptr() for p in self.params]),
+                (C.c_int * n)(*[p.numel() for p in self.params]), loss.data_ptr(),
+                stream_ptr(loss.device)), "gsx_track_opt_advance")
+        return loss
 
     def load(self, frame: Frame, prev_exposure: Optional[torch.Tensor] = None):
         with torch.no_grad():
@@ -167,7 +189,7 @@ class GraphedTracker:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
-            self.loss = self._closure_body()
+            self.loss = self._closure_body(advance=self.device_optimizer)
 
     def closure(self):
         if self.graph is None:
@@ -175,14 +197,42 @@ class GraphedTracker:
         self.graph.replay()
         return self.loss
 
-    def track(self, frame: Frame, prev_exposure: Optional[torch.Tensor] = None, max_eval: Optional[int] = None):
+    def _write_back(self, frame: Frame):
+        with torch.no_grad():
+            new_pose = self.pose().detach().clone()
+            frame.pose.Rt.copy_(new_pose)
+            frame.pose.dR.zero_()
+            frame.pose.dt.zero_()
+            frame.exposure_params.data.copy_(self.exposure.detach())
+
+    def track(self, frame: Frame, prev_exposure: Optional[torch.Tensor] = None, max_eval: Optional[int] = None,
+              sync: bool = True):
         """igs_track_lbfgs on the slot; writes the optimised pose / exposure back into ``frame``.  Returns
-        (last_loss, n_closures)."""
+        (last_loss, n_closures); with the device optimiser and ``sync=False`` both are left on the device (the
+        8-float report tensor of gsx_track_opt_report is returned instead) and the call does not block."""
         conf = self.conf
         self.load(frame, prev_exposure)
         if self.graph is None:
             self.capture()
             self.load(frame, prev_exposure)
+        if self.device_optimizer:
+            from ._lib import check, lib, stream_ptr
+            dev = self.img.device
+            me = self.max_eval if max_eval is None else max_eval
+            n_par = sum(p.numel() for p in self.params)
+            # torch.optim.LBFGS defaults of the reference call (frontend.py:613-619): max_iter 20, tolerance_grad 1e-7
+            check(lib.gsx_track_opt_init(self._state.data_ptr(), n_par, conf.n_adam_warmup, conf.pose_optim_lr,
+                                         conf.pose_optim_lr, conf.lbfgs_history, 20, me, 1e-7, 1e-9, stream_ptr(dev)),
+                  "gsx_track_opt_init")
+            for _ in range(conf.n_adam_warmup + me + 1):   # a line search may overshoot max_eval by one evaluation
+                self.graph.replay()
+            check(lib.gsx_track_opt_report(self._state.data_ptr(), self._report.data_ptr(), stream_ptr(dev)),
+                  "gsx_track_opt_report")
+            self._write_back(frame)
+            if not sync:
+                return self._report
+            rep = self._report.cpu()
+            return float(rep[4]), int(rep[1])
         n_evals = 0
         last = None
 
@@ -201,10 +251,5 @@ class GraphedTracker:
         lbfgs = torch.optim.LBFGS(self.params, history_size=conf.lbfgs_history, line_search_fn='strong_wolfe',
                                   tolerance_change=1e-9, lr=conf.pose_optim_lr, **kw)
         lbfgs.step(closure)
-        with torch.no_grad():
-            new_pose = self.pose().detach().clone()
-            frame.pose.Rt.copy_(new_pose)
-            frame.pose.dR.zero_()
-            frame.pose.dt.zero_()
-            frame.exposure_params.data.copy_(self.exposure.detach())
+        self._write_back(frame)
         return last, n_evals

@@ -215,6 +215,20 @@ int gsx_adam_multi(int n_tensors, float *const *params, const float *const *grad
                    float eps, int64_t step_host, const int64_t *step_dev /*nullable device int64: overrides step_host*/,
                    void *stream);
 
+/* ---- device-resident tracking optimiser: the host logic of gslam/frontend.py:604-662 (10 torch.optim.Adam steps, then
+ * ONE torch.optim.LBFGS(line_search_fn='strong_wolfe').step()) as a state machine advanced once per closure
+ * evaluation, so that a tracked frame needs no loss.item() read-back (frontend.py:648).  `state`: device buffer of
+ * gsx_track_opt_state_bytes().  advance: params/grads/numels are HOST arrays (<= 4 tensors, <= 16 scalars in all) of
+ * device pointers; `loss` is a device float.  After advance the parameters hold the next evaluation point, or the
+ * result once the machine is done (further calls are no-ops).  report: out8 (device) = phase (4 = done),
+ * evaluations, L-BFGS iterations, stop reason, last evaluated loss, loss at the result, L-BFGS evaluations, Adam steps. */
+int64_t gsx_track_opt_state_bytes(void);
+int gsx_track_opt_init(void *state, int n_params, int n_adam, float lr_adam, double lr_lbfgs, int history, int max_iter,
+                       int max_eval, double tol_grad, double tol_change, void *stream);
+int gsx_track_opt_advance(void *state, int n_tensors, float *const *params, const float *const *grads,
+                          const int *numels, const float *loss, void *stream);
+int gsx_track_opt_report(const void *state, float *out8, void *stream);
+
 /* ---- self tests of device primitives (wave64 reductions); returns 0 if all pass.  scratch: >= 64 KiB device ----- */
 int gsx_selftest(void *scratch, int64_t scratch_bytes, void *stream);
 

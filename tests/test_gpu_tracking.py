@@ -1,0 +1,140 @@
+"""Tracking on the GPU: the graphed closure must be replayable (regression test for the memset-node corruption), and
+the device-resident optimiser (csrc/track_opt.h through the C ABI) must do what torch.optim.Adam + torch.optim.LBFGS
+do on the host (gslam/frontend.py:604-662).  Run with -m gpu."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _setup(dev, n=20000, W=320, H=240):
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.primitives import Camera, Frame, PoseZhou
+    from gslam_amd.synthetic import make_intrinsics, make_scene, make_viewmat
+    K = make_intrinsics(W, H).to(dev)
+    cam = Camera(K, H, W)
+    sc = make_scene(n, 0)
+    sc["scales"] = sc["scales"] + 0.4
+    m = GaussianSplattingData.from_dict(sc, dev).no_grad_clone()
+
+    def frame(i, start):
+        V = make_viewmat(i).to(dev)
+        with torch.no_grad():
+            img = m([cam], [PoseZhou(V, is_learnable=False).to(dev)], render_depth=False).rgbs[0].clamp(0, 1)
+        V0 = make_viewmat(start).to(dev)
+        return Frame(img=img.contiguous(), timestamp=0.0, camera=cam, pose=PoseZhou(V0).to(dev), gt_pose=V, index=i,
+                     exposure_params=torch.zeros(2, device=dev))
+    return m, cam, frame
+
+
+def _pose_err(frame):
+    with torch.no_grad():
+        return float((frame.pose()[:3, 3] - frame.gt_pose[:3, 3]).norm())
+
+
+def test_graph_replays_are_idempotent(dev):
+    """Second and later replays of the captured closure give the first replay's numbers (they did not while the
+    difference grid was cleared by a hipMemsetAsync graph node)."""
+    from gslam_amd import rasterization as R
+    from gslam_amd.tracking import GraphedTracker
+    m, cam, frame = _setup(dev)
+    tr = GraphedTracker(m, cam, device_optimizer=False)
+    f = frame(1, 0)
+    tr.load(f)
+    tr.capture()
+    tr.load(f)
+    vals = []
+    for _ in range(4):
+        l = tr.closure()
+        torch.cuda.synchronize()
+        vals.append((float(l), [g.clone() for g in (p.grad for p in tr.params)]))
+    assert R.validate(dev)
+    pool = R._pool(dev)
+    assert int(pool.status.item()) == 0
+    for v, gs in vals[1:]:
+        assert abs(v - vals[0][0]) <= 1e-6 * max(1.0, abs(vals[0][0]))
+        for a, b in zip(gs, vals[0][1]):
+            assert torch.allclose(a, b, rtol=1e-3, atol=1e-7)
+
+
+def test_device_optimizer_matches_host_state_machine(dev):
+    """gsx_track_opt_* (device) against the same C code compiled for the host, on an analytic objective."""
+    from gslam_amd._lib import check, lib
+    so = os.path.join(HERE, "_build", "libtrackopt_host.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-ffp-contract=off", "-o", so,
+                           os.path.join(HERE, "trackopt_host.c"), "-lm"])
+    host = C.CDLL(so)
+    host.trackopt_state_bytes.restype = C.c_long
+    host.trackopt_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_int, C.c_int,
+                                   C.c_double, C.c_double]
+    host.trackopt_advance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+
+    def fn(x):
+        return (100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1.0 - x[:-1]) ** 2).sum()
+
+    n, n_adam, lr = 11, 3, 0.5
+    x0 = (torch.arange(n, dtype=torch.float32) / n - 0.5)
+    st_h = C.create_string_buffer(host.trackopt_state_bytes())
+    host.trackopt_init(st_h, n, n_adam, lr, lr, 5, 20, 25, 1e-7, 1e-9)
+    st_d = torch.zeros(int(lib.gsx_track_opt_state_bytes()), dtype=torch.uint8, device=dev)
+    check(lib.gsx_track_opt_init(st_d.data_ptr(), n, n_adam, lr, lr, 5, 20, 25, 1e-7, 1e-9, None), "init")
+    ph = x0.clone().numpy()
+    pd = [x0[0:3].clone().to(dev), x0[3:9].clone().to(dev), x0[9:11].clone().to(dev)]   # three tensors like the tracker
+    rep = torch.zeros(8, device=dev)
+    for k in range(40):
+        xh = torch.from_numpy(ph.copy()).requires_grad_(True)
+        lh = fn(xh)
+        lh.backward()
+        xd = torch.cat(pd).detach().cpu()
+        assert torch.allclose(xd, torch.from_numpy(ph), rtol=1e-5, atol=1e-6), (k, xd, ph)
+        gh = xh.grad.numpy().astype(np.float32)
+        host.trackopt_advance(st_h, ph.ctypes.data, gh.ctypes.data, float(lh))
+        gd = torch.from_numpy(gh).to(dev)
+        gds = [gd[0:3].contiguous(), gd[3:9].contiguous(), gd[9:11].contiguous()]
+        loss_d = torch.tensor([float(lh)], device=dev)
+        check(lib.gsx_track_opt_advance(st_d.data_ptr(), 3, (C.c_void_p * 3)(*[t.data_ptr() for t in pd]),
+                                        (C.c_void_p * 3)(*[t.data_ptr() for t in gds]), (C.c_int * 3)(3, 6, 2),
+                                        loss_d.data_ptr(), None), "advance")
+        torch.cuda.synchronize()
+    check(lib.gsx_track_opt_report(st_d.data_ptr(), rep.data_ptr(), None), "report")
+    r = rep.cpu()
+    assert int(r[0]) == 4 and int(r[1]) == host.trackopt_evals(st_h) and int(r[2]) == host.trackopt_iters(st_h)
+    assert int(r[3]) == host.trackopt_stop_reason(st_h)
+
+
+def test_device_optimizer_tracks_like_host_optimizer(dev):
+    from gslam_amd.tracking import GraphedTracker
+    m, cam, frame = _setup(dev)
+    res = {}
+    for mode in (False, True):
+        tr = GraphedTracker(m, cam, device_optimizer=mode)
+        errs, losses, evals = [], [], []
+        for i in (1, 2, 3):
+            f = frame(i, i - 1)                       # start from the previous frame's pose, as the frontend does
+            e0 = _pose_err(f)
+            loss, n = tr.track(f)
+            torch.cuda.synchronize()
+            errs.append((e0, _pose_err(f)))
+            losses.append(loss)
+            evals.append(n)
+        res[mode] = (errs, losses, evals)
+    for mode in (False, True):
+        errs, losses, evals = res[mode]
+        for (e0, e1), n in zip(errs, evals):
+            assert e1 < 0.5 * e0, (mode, e0, e1)      # both optimisers pull the pose towards the ground truth
+            assert 11 <= n <= 37
+    for lh, ld in zip(res[False][1], res[True][1]):
+        assert ld <= 3.0 * lh + 1e-5 and lh <= 3.0 * ld + 1e-5, (lh, ld)

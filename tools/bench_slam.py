@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--ba-iters", type=int, default=15)
     ap.add_argument("--window", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--host-optimizer", action="store_true",
+                    help="keep torch.optim.Adam / LBFGS on the host (one loss.item() per closure, as the reference)")
     args = ap.parse_args()
     from gslam_amd.map import GaussianSplattingData
     from gslam_amd.mapping import BundleAdjuster, GraphedBundleAdjuster
@@ -51,7 +53,7 @@ def main():
     frames = [gt_frame(i) for i in range(args.frames + args.window)]
     keyframes = frames[:args.window]                       # pre-seeded window so that BA runs at its full size
     ba = BundleAdjuster(backend_map, capturable=not args.no_graph)
-    tracker = GraphedTracker(frontend_map, cam, TrackingConfig())
+    tracker = GraphedTracker(frontend_map, cam, TrackingConfig(), device_optimizer=not (args.host_optimizer or args.no_graph))
     if args.no_graph:
         tracker.capture = lambda: None
     # warm-up (allocations, capacity probes, graph captures)
@@ -90,7 +92,8 @@ def main():
         "ms_per_frame": round(elapsed / args.frames * 1e3, 2), "closures_per_frame": round(n_closures / args.frames, 1),
         "ms_per_closure": round(t_track / max(n_closures, 1) * 1e3, 3), "ba_iters": n_ba, "ba_window": args.window,
         "ms_per_ba_iter": round(t_map / max(n_ba, 1) * 1e3, 3), "tracking_share": round(t_track / elapsed, 3),
-        "launch": "eager" if args.no_graph else "hip-graph", "capacity_ok": ok}))
+        "launch": "eager" if args.no_graph else "hip-graph",
+        "optimizer": "device state machine" if tracker.device_optimizer else "host torch.optim", "capacity_ok": ok}))
 
 
 if __name__ == "__main__":
