@@ -283,14 +283,15 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long l
                                                                  unsigned long long *__restrict__ scratch,
                                                                  const int32_t *__restrict__ offsets, int n_tiles,
                                                                  int tile_n_bits, int64_t M_cap, int cap,
-                                                                 uint32_t id_max, int64_t *__restrict__ isect_ids,
+                                                                 int n_lo, int n_hi, uint32_t id_max,
+                                                                 int64_t *__restrict__ isect_ids,
                                                                  int32_t *__restrict__ flatten_ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
     const int tile = blockIdx.x;
     const int64_t start = max((int64_t)0, min((int64_t)offsets[tile], M_cap));
     const int64_t end = max((int64_t)0, min((int64_t)offsets[tile + 1], M_cap));
     const int n = (int)(end - start);
-    if (n <= 0) return;
+    if (n <= n_lo || n > n_hi) return;                       // not this launch's size class (n_lo >= 0: empty tiles)
     const int c = tile / n_tiles, tl = tile - c * n_tiles;
     const long long hi_part = ((long long)c << (32 + tile_n_bits)) | ((long long)tl << 32);
     unsigned long long *seg = entries + start;
@@ -385,20 +386,29 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
         hipLaunchKernelGGL(emit_binned_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4), st,
                            means2d, radii, depths, N, tile_w, tile_h, M_cap, cursor, entries);
         GSX_CHECK_LAUNCH();
-        // LDS window: 4x the average tile (tiles are unbalanced), between 512 and 4096 keys, two buffers of it
-        int64_t cap = 512;
-        while (cap < 4 * (M_cap / T + 1) && cap < 8192) cap <<= 1;
-        const size_t lds_bytes = (size_t)(2 * cap * 8);     // up to 128 KiB of the CU's 160 KiB
-        if (lds_bytes > 64 * 1024 &&
-            hipFuncSetAttribute((const void *)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess) {
-            gsx_set_error("gsx_isect_bin_sort: cannot raise the dynamic LDS limit to %zu bytes", lds_bytes);
-            return GSX_E_LAUNCH;
+        // Tile sizes are only known on the device (sync-free), so the sort runs as up to two launches over all tiles,
+        // each taking one size class and leaving the rest (an early exit): tiles of up to 2048 keys sort in a 32 KiB
+        // LDS window at full occupancy (4 workgroups of 8 wavefronts per CU); larger tiles get an 8192-key window
+        // (128 KiB, one workgroup per CU) and, beyond that, merge levels through global memory.  The second launch is
+        // skipped when the capacity says no tile can be that large.
+        const int small_cap = 2048, big_cap = 8192;
+        const uint32_t id_max = (uint32_t)(C * N - 1);
+        const int tnb = bit_length((uint32_t)n_tiles);
+        hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), (size_t)(2 * small_cap * 8), st,
+                           entries, scratch, offsets, (int)n_tiles, tnb, M_cap, small_cap, 0, small_cap, id_max,
+                           isect_ids, flatten_ids);
+        GSX_CHECK_LAUNCH();
+        if (M_cap > small_cap) {
+            const size_t lds_bytes = (size_t)(2 * big_cap * 8);     // 128 KiB of the CU's 160 KiB
+            if (hipFuncSetAttribute((const void *)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes) != hipSuccess) {
+                gsx_set_error("gsx_isect_bin_sort: cannot raise the dynamic LDS limit to %zu bytes", lds_bytes);
+                return GSX_E_LAUNCH;
+            }
+            hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), lds_bytes, st, entries, scratch,
+                               offsets, (int)n_tiles, tnb, M_cap, big_cap, small_cap, 0x7fffffff, id_max, isect_ids,
+                               flatten_ids);
         }
-        hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), lds_bytes, st, entries, scratch,
-                           offsets, (int)n_tiles, bit_length((uint32_t)n_tiles), M_cap, (int)cap,
-                           (uint32_t)(C * N - 1), isect_ids,
-                           flatten_ids);
         GSX_CHECK_LAUNCH();
     }
     return GSX_OK;
