@@ -88,6 +88,21 @@ __device__ __forceinline__ void gsx_row16_sum(float (&v)[N]) {
 #undef GSX_ROW_STEP
 }
 
+// Same, continued over the four rows: afterwards lane 63 holds the sum over all 64 lanes (row_bcast:15 into rows 1 and
+// 3, then row_bcast:31 into rows 2 and 3).
+template <int N>
+__device__ __forceinline__ void gsx_wave63_sum(float (&v)[N]) {
+    gsx_row16_sum<N>(v);
+    if (N < 3) asm volatile("s_nop 1");
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v[k]));
+    if (N < 3) asm volatile("s_nop 1");
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v[k]));
+}
+
 // 48-byte splat record fetched through the scalar data cache into SGPRs (uniform address): the broadcast of a
 // Gaussian to all 64 pixel lanes costs no VALU instruction and no LDS traffic.
 typedef float gsx_f4 __attribute__((ext_vector_type(4)));

@@ -588,16 +588,17 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel2(
     }
 }
 
+#include "raster_v4.inc"
+
 // Kernel generation per launch: 1 = first generation, 2 = one pixel per lane (4 wavefronts per tile), 3 = two pixels
-// per lane (2 wavefronts per tile).  GSX_RASTER forces one; otherwise the forward takes v2 when the grid is small
-// (a single camera gives only ~4.7 wavefronts per SIMD with v2 and half of that with v3: latency hiding wins over
-// instruction count) and v3 when there are enough tiles to fill the chip; the backward takes v3 (its per-entry
-// reduction cost halves).  Thresholds from tools/ab_raster.py on MI355X.
+// per lane (2 wavefronts per tile), 4 = two pixels per lane with the LDS-compacted survivor list (raster_v4.inc).
+// GSX_RASTER forces one (A/B runs, parity tests); otherwise v4, which tools/ab_raster.py measures fastest on MI355X at
+// every size tried (100 k / 500 k Gaussians, 1 and 8 cameras), forward and backward; absgrad launches use v3.
 int raster_variant(bool backward, int64_t n_tiles) {
     const char *e = getenv("GSX_RASTER");
-    if (e && e[0] >= '1' && e[0] <= '3') return e[0] - '0';
-    if (backward) return 3;
-    return n_tiles >= 8192 ? 3 : 2;
+    if (e && e[0] >= '1' && e[0] <= '4') return e[0] - '0';
+    (void)backward; (void)n_tiles;
+    return 4;
 }
 
 bool use_v1() {
@@ -611,18 +612,27 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
                               const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
                               int tile_w, int tile_h, float visibility_min_T, float *render, float *alphas,
                               int32_t *last_ids, int32_t *n_touched, void *stream) {
-    GSX_CHECK_ARG(offsets && render && alphas && last_ids && n_touched && C >= 1 && W > 0 && H > 0);
+    GSX_CHECK_ARG(offsets && render && alphas && last_ids && C >= 1 && W > 0 && H > 0);   // n_touched: NULL = not wanted
     GSX_CHECK_ARG(tile_w == (W + GSX_TILE - 1) / GSX_TILE && tile_h == (H + GSX_TILE - 1) / GSX_TILE);
     GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31));
     GSX_CHECK_ARG(M == 0 || (rec && flatten_ids));
     const int64_t T = C * tile_w * tile_h;
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
     hipStream_t st = (hipStream_t)stream;
-    const int variant = raster_variant(false, T);
-    const bool v1 = (use_v1() || variant == 1) && !offsets_has_end;
+    const int variant = n_touched ? raster_variant(false, T) : 4;   // only the v4 kernel can skip the touched counts
+    const bool v1 = (use_v1() || variant == 1) && !offsets_has_end && n_touched;
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
-        if (v1)                                                                                                     \
+        if (variant == 4 && !v1) {                                                                                  \
+            if (n_touched)                                                                                          \
+                hipLaunchKernelGGL((raster_fwd_kernel4<ch, rs, true>), dim3((unsigned)T), dim3(128), 0, st, rec,    \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   visibility_min_T, render, alphas, last_ids, n_touched);                          \
+            else                                                                                                    \
+                hipLaunchKernelGGL((raster_fwd_kernel4<ch, rs, false>), dim3((unsigned)T), dim3(128), 0, st, rec,   \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   visibility_min_T, render, alphas, last_ids, n_touched);                          \
+        } else if (v1)                                                                                              \
             hipLaunchKernelGGL((raster_fwd_kernel_v1<ch, rs>), dim3((unsigned)T), dim3(256), 0, st, rec,           \
                                backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, visibility_min_T,       \
                                render, alphas, last_ids, n_touched);                                                \
@@ -661,16 +671,31 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     hipStream_t st = (hipStream_t)stream;
     const int variant = raster_variant(true, T);
     const bool v1 = (use_v1() || variant == 1) && !offsets_has_end;
+    const char *bb = getenv("GSX_BWD_MODE");
+    const int bwd_mode = (bb && bb[0] >= '0' && bb[0] <= '2') ? bb[0] - '0' : 1;
     const char *sb = getenv("GSX_BWD_SCALAR");
     const bool scalar_bwd = sb && sb[0] == '1';
 #define ARGS1 rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
 #define ARGS rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
-        if (v1) {                                                                                                   \
+        if (variant == 4 && !v1 && !v_abs) {                                                                        \
+            if (bwd_mode == 2)                                                                                      \
+                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 128, 2>), dim3((unsigned)T), dim3(128), 0, st, rec, \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
+            else if (bwd_mode == 1)                                                                                 \
+                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 1>), dim3((unsigned)T), dim3(128), 0, st, rec, \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
+            else                                                                                                    \
+                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 0>), dim3((unsigned)T), dim3(128), 0, st, rec,    \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
+        } else if (v1) {                                                                                            \
             if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS1); \
             else hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS1);      \
-        } else if (variant == 3) {                                                                                  \
+        } else if (variant >= 3) {                                                                                  \
             if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel2<ch, rs, true>), dim3((unsigned)T), dim3(128), 0, st, ARGS);   \
             else hipLaunchKernelGGL((raster_bwd_kernel2<ch, rs, false>), dim3((unsigned)T), dim3(128), 0, st, ARGS);        \
         } else if (scalar_bwd) {                                                                                    \

@@ -154,7 +154,7 @@ def test_raster_properties_full_size(dev, n, c, W, H, ch):
     if n <= 500_000:
         # three generations of kernels (different work decompositions) agree, forward and backward
         ref = render(c1, "1", grad=True)
-        for variant in ("2", "3"):
+        for variant in ("2", "3", "4"):
             got = render(c1, variant, grad=True)
             # the generations order the conic arithmetic differently, so a pixel whose alpha sits exactly on the
             # 1/255 or T <= 1e-4 cut may flip: bound the worst pixel loosely, the bulk tightly

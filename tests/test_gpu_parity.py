@@ -172,10 +172,14 @@ def _oracle_pipeline(o, sc, viewmats, Ks, W, H, ch, seed=3):
     return m2d, con, colors, opac, bg, off, flat
 
 
+@pytest.mark.parametrize("variant", [None, "2", "3", "4"])
 @pytest.mark.parametrize("n,c,W,H,ch", [(3000, 1, 640, 480, 5), (3000, 2, 320, 240, 3), (2000, 1, 200, 120, 1),
                                          (2000, 1, 330, 250, 4), (2000, 1, 330, 250, 2)])
-def test_raster_forward_backward_vs_oracle(dev, oracle32, n, c, W, H, ch):
+def test_raster_forward_backward_vs_oracle(dev, oracle32, monkeypatch, n, c, W, H, ch, variant):
+    """every generation of the raster kernels (GSX_RASTER; None = the per-launch selection) against the CPU oracle"""
     from gslam_amd import ops
+    if variant is not None:
+        monkeypatch.setenv("GSX_RASTER", variant)
     from gslam_amd.synthetic import make_cameras, make_scene
     sc = make_scene(n, 4)
     sc["scales"] = sc["scales"] + 0.7   # fatter splats: deeper per-pixel lists, exercises early termination
@@ -191,7 +195,8 @@ def test_raster_forward_backward_vs_oracle(dev, oracle32, n, c, W, H, ch):
     l1 = np.abs(_np(render) - o_render).mean()
     assert l1 < 1e-5, l1
     assert np.abs(_np(render) - o_render).max() < 2e-3
-    assert np.abs(_np(alphas) - o_alpha).max() < 1e-4
+    # a pixel whose alpha sits on the 1/255 cut may flip between CPU expf and the GPU's exp2 (<= 1/255 of T each)
+    assert np.abs(_np(alphas) - o_alpha).max() < 5e-3 and np.abs(_np(alphas) - o_alpha).mean() < 1e-6
     nt_mismatch = (_np(n_touched) != o_nt).mean()
     assert nt_mismatch < 2e-3, nt_mismatch
     assert o_nt.sum() > 0 and (o_last >= 0).mean() > 0.3

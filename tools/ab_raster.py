@@ -82,11 +82,16 @@ def run(N, C, W=640, H=480):
 
     res = {}
     for _ in range(2):
-        for ver in ("1", "2", "3"):
+        for ver in ("2", "3", "4"):
             os.environ["GSX_RASTER"] = ver
             fwd()
             res.setdefault(("fwd", ver), []).append(timed(fwd))
             res.setdefault(("bwd", ver), []).append(timed(bwd))
+    os.environ["GSX_RASTER"] = "4"
+    for mode in ("0", "1", "2"):
+        os.environ["GSX_BWD_MODE"] = mode
+        res[("bwd", "4/mode" + mode)] = [timed(bwd), timed(bwd)]
+    os.environ.pop("GSX_BWD_MODE", None)
     os.environ.pop("GSX_RASTER", None)
     fwd()
     res[("fwd", "auto")] = [timed(fwd)]
