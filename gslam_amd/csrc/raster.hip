@@ -591,14 +591,15 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel2(
 #include "raster_v4.inc"
 
 // Kernel generation per launch: 1 = first generation, 2 = one pixel per lane (4 wavefronts per tile), 3 = two pixels
-// per lane (2 wavefronts per tile), 4 = two pixels per lane with the LDS-compacted survivor list (raster_v4.inc).
-// GSX_RASTER forces one (A/B runs, parity tests); otherwise v4, which tools/ab_raster.py measures fastest on MI355X at
-// every size tried (100 k / 500 k Gaussians, 1 and 8 cameras), forward and backward; absgrad launches use v3.
+// per lane (2 wavefronts per tile), 4 = v3's mapping with the LDS-compacted survivor list (raster_v4.inc), 5 = the
+// same with one pixel per lane in the forward.  GSX_RASTER forces one (A/B runs, parity tests); otherwise 5: forward
+// with one pixel per lane (fastest at every size tried on MI355X, 1 and 8 cameras, tools/ab_raster.py), backward with
+// two (its per-entry cross-lane reduction is paid per wavefront); absgrad launches use the v3 backward.
 int raster_variant(bool backward, int64_t n_tiles) {
     const char *e = getenv("GSX_RASTER");
-    if (e && e[0] >= '1' && e[0] <= '4') return e[0] - '0';
+    if (e && e[0] >= '1' && e[0] <= '5') return e[0] - '0';
     (void)backward; (void)n_tiles;
-    return 4;
+    return 5;
 }
 
 bool use_v1() {
@@ -619,11 +620,20 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
     const int64_t T = C * tile_w * tile_h;
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
     hipStream_t st = (hipStream_t)stream;
-    const int variant = n_touched ? raster_variant(false, T) : 4;   // only the v4 kernel can skip the touched counts
+    const int variant = n_touched ? raster_variant(false, T) : 5;   // only the v4 kernels can skip the touched counts
     const bool v1 = (use_v1() || variant == 1) && !offsets_has_end && n_touched;
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
-        if (variant == 4 && !v1) {                                                                                  \
+        if (variant == 5 && !v1) {                                                                                  \
+            if (n_touched)                                                                                          \
+                hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, rec,   \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   visibility_min_T, render, alphas, last_ids, n_touched);                          \
+            else                                                                                                    \
+                hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, rec,  \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   visibility_min_T, render, alphas, last_ids, n_touched);                          \
+        } else if (variant == 4 && !v1) {                                                                           \
             if (n_touched)                                                                                          \
                 hipLaunchKernelGGL((raster_fwd_kernel4<ch, rs, true>), dim3((unsigned)T), dim3(128), 0, st, rec,    \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
@@ -672,24 +682,20 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     const int variant = raster_variant(true, T);
     const bool v1 = (use_v1() || variant == 1) && !offsets_has_end;
     const char *bb = getenv("GSX_BWD_MODE");
-    const int bwd_mode = (bb && bb[0] >= '0' && bb[0] <= '2') ? bb[0] - '0' : 1;
+    const int bwd_mode = (bb && bb[0] == '0') ? 0 : 1;
     const char *sb = getenv("GSX_BWD_SCALAR");
     const bool scalar_bwd = sb && sb[0] == '1';
 #define ARGS1 rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
 #define ARGS rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
-        if (variant == 4 && !v1 && !v_abs) {                                                                        \
-            if (bwd_mode == 2)                                                                                      \
-                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 128, 2>), dim3((unsigned)T), dim3(128), 0, st, rec, \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
-            else if (bwd_mode == 1)                                                                                 \
-                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 1>), dim3((unsigned)T), dim3(128), 0, st, rec, \
+        if (variant >= 4 && !v1 && !v_abs) {                                                                        \
+            if (bwd_mode == 0)                                                                                      \
+                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 0>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
                                    alphas, last_ids, v_render, v_alphas, v_rec);                                    \
             else                                                                                                    \
-                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 0>), dim3((unsigned)T), dim3(128), 0, st, rec,    \
+                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 1>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
                                    alphas, last_ids, v_render, v_alphas, v_rec);                                    \
         } else if (v1) {                                                                                            \

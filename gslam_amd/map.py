@@ -25,13 +25,15 @@ class GaussianSplattingData(torch.nn.Module):
         self.ages = torch.nn.Parameter(ages, requires_grad=False)
         self.register_buffer('background', torch.tensor([0.0, 0.0, 0.0], device=self.means.device).float())
 
-    def _render(self, cameras: List[Camera], viewmats: torch.Tensor, render_mode: str, visibility_min_T: float):
+    def _render(self, cameras: List[Camera], viewmats: torch.Tensor, render_mode: str, visibility_min_T: float,
+                need_n_touched: bool = True):
         Ks = create_batch(cameras, lambda x: x.intrinsics)
         return rasterization(
             means=self.means, quats=self.quats, log_scales=self.scales, logit_opacities=self.opacities,
             logit_colors=self.colors, viewmats=viewmats, Ks=Ks, width=cameras[0].width, height=cameras[0].height,
             render_mode=render_mode, packed=False, log_uncertainties=self.log_uncertainties,
-            visibility_min_T=visibility_min_T, backgrounds=self._backgrounds(len(cameras)))
+            visibility_min_T=visibility_min_T, backgrounds=self._backgrounds(len(cameras)),
+            need_n_touched=need_n_touched)
 
     def _backgrounds(self, n_cams: int) -> torch.Tensor:
         """self.background.tile([C, 1]) (map.py:73,102), cached per (C, buffer version)"""
@@ -47,9 +49,11 @@ class GaussianSplattingData(torch.nn.Module):
         return self._render(cameras, create_batch(viewmats), 'RGB+D', visibility_min_T)
 
     def forward(self, cameras: List[Camera], poses: List[Pose], render_depth: bool = False,
-                visibility_min_T: float = 0.5) -> RasterizationOutput:
+                visibility_min_T: float = 0.5, need_n_touched: bool = True) -> RasterizationOutput:
+        """``need_n_touched=False`` (extension): skip the touched-pixel counts nobody reads in the optimisation loops
+        (only visibility pruning does, backend.py:370-375); ``outputs.n_touched`` is then None."""
         viewmats = pose_batch(poses)                                     # = create_batch(poses, lambda x: x())
-        return self._render(cameras, viewmats, 'RGB+D' if render_depth else 'RGB', visibility_min_T)
+        return self._render(cameras, viewmats, 'RGB+D' if render_depth else 'RGB', visibility_min_T, need_n_touched)
 
     @staticmethod
     def empty(device: str = 'cuda') -> "GaussianSplattingData":

@@ -42,6 +42,7 @@ class MapConfig:
     num_iters_initialization: int = 400
     ssim_weight: float = 0.2
     active_gs: bool = True
+    enable_visibility_pruning: bool = False     # backend.py:94; the only reader of RasterizationOutput.n_touched
     device: str = 'cuda'
 
 
@@ -114,9 +115,13 @@ class BundleAdjuster:
     """One object per process/GPU.  ``step(window)`` is one iteration of the loop at backend.py:260-359."""
 
     def __init__(self, splats: GaussianSplattingData, conf: Optional[MapConfig] = None, fused_loss: bool = True,
-                 capturable: bool = False):
+                 capturable: bool = False, need_n_touched: Optional[bool] = None):
+        """need_n_touched: keep the rasteriser's touched-pixel counts in ``last_outputs`` (read by visibility pruning
+        only, backend.py:370-375); default = the configuration's ``enable_visibility_pruning`` (off, backend.py:94)."""
         self.splats = splats
         self.conf = conf or MapConfig()
+        self.need_n_touched = bool(getattr(self.conf, "enable_visibility_pruning", False)) \
+            if need_n_touched is None else bool(need_n_touched)
         self.fused_loss = fused_loss
         self.optimizers = MapOptimizers(splats, self.conf, capturable=capturable)
         self.shard = gdist.KeyframeShard()
@@ -147,7 +152,7 @@ class BundleAdjuster:
         poses = [f.pose for f in mine]
         gt_imgs = create_batch(mine, lambda f: f.img)
         exposure = create_batch(mine, lambda f: f.exposure_params)
-        outputs = self.splats(cameras, poses, render_depth=True)
+        outputs = self.splats(cameras, poses, render_depth=True, need_n_touched=self.need_n_touched)
         vis_count = outputs._vis_count                                  # = (radii > 0).sum(0), from K1
         outputs.means2d.retain_grad()                                   # backend.py:326
         if self.fused_loss:

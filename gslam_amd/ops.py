@@ -278,9 +278,10 @@ class _RasterizeRecords(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rec, means2d, conics, backgrounds, offsets, flatten_ids, ch, width, height, vis_min_T, absgrad,
-                has_end=False):
+                has_end=False, want_touched=True):
         """has_end: ``offsets`` is the flat int32 [T+1] array of gsx_isect_bin_sort and ``flatten_ids`` a
-        capacity-sized buffer (sync-free path); otherwise the gsplat layout ([C,tile_h,tile_w] offsets, exact M)."""
+        capacity-sized buffer (sync-free path); otherwise the gsplat layout ([C,tile_h,tile_w] offsets, exact M).
+        want_touched=False skips the per-Gaussian touched-pixel counts (n_touched comes back as None)."""
         rec = _f32c(rec, "rec")
         Cn, N, RS = rec.shape
         assert RS == record_stride(ch)
@@ -291,7 +292,7 @@ class _RasterizeRecords(torch.autograd.Function):
         render = torch.empty(Cn, height, width, ch, dtype=torch.float32, device=dev)
         alphas = torch.empty(Cn, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(Cn, height, width, dtype=torch.int32, device=dev)
-        n_touched = torch.zeros(Cn, N, dtype=torch.int32, device=dev)
+        n_touched = torch.zeros(Cn, N, dtype=torch.int32, device=dev) if want_touched else None
         offsets, flatten_ids = offsets.contiguous(), flatten_ids.contiguous()
         M = flatten_ids.shape[0]
         check(lib.gsx_raster_fwd(ptr(rec), ch, ptr(bg), ptr(offsets), ptr(flatten_ids), M, 1 if has_end else 0, Cn,
@@ -301,7 +302,10 @@ class _RasterizeRecords(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.cfg = (ch, width, height, absgrad, has_end)
         ctx.means2d_ref = means2d if absgrad else None
-        ctx.mark_non_differentiable(n_touched, last_ids)
+        if n_touched is not None:
+            ctx.mark_non_differentiable(n_touched, last_ids)
+        else:
+            ctx.mark_non_differentiable(last_ids)
         return render, alphas, n_touched, last_ids
 
     @staticmethod
@@ -312,7 +316,7 @@ class _RasterizeRecords(torch.autograd.Function):
         dev = rec.device
         tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
         if v_render is None and v_alphas is None:
-            return (None,) * 12
+            return (None,) * 13
         v_render = torch.zeros_like(alphas).expand(-1, -1, -1, ch).contiguous() if v_render is None \
             else v_render.contiguous()
         v_alphas = None if v_alphas is None else v_alphas.contiguous()      # NULL = zero gradient (kernel-side)
@@ -327,7 +331,7 @@ class _RasterizeRecords(torch.autograd.Function):
         v_bg = None
         if bg is not None and ctx.needs_input_grad[3]:
             v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
-        return v_rec, v_rec[..., 0:2], v_rec[..., 2:5], v_bg, None, None, None, None, None, None, None, None
+        return v_rec, v_rec[..., 0:2], v_rec[..., 2:5], v_bg, None, None, None, None, None, None, None, None, None
 
 
 class _PackRecords(torch.autograd.Function):

@@ -220,10 +220,14 @@ def rasterization(
     log_uncertainties: Optional[Tensor] = None,
     visibility_min_T: float = 0.5,
     mask: Optional[Tensor] = None,
+    need_n_touched: bool = True,
 ) -> RasterizationOutput:
     """gslam ``rasterization`` (gslam/rasterization.py:44-360).  One fused projection+activation+packing kernel,
     tile-binned depth sort, one tiled rasterisation kernel; autograd reaches every pre-activation input and
-    ``viewmats``.  The only caller in the reference passes packed=False (map.py:99)."""
+    ``viewmats``.  The only caller in the reference passes packed=False (map.py:99).
+
+    ``need_n_touched`` (extension, default True = reference behaviour): False skips the per-Gaussian touched-pixel
+    counts, which only visibility pruning reads (backend.py:370-375); ``n_touched`` is then None."""
     N = means.shape[0]
     C = viewmats.shape[0]
     assert means.shape == (N, 3), means.shape
@@ -307,7 +311,7 @@ def rasterization(
 
     render, alphas, n_touched, _last = ops._RasterizeRecords.apply(
         rec, means2d, conics, bg, raster_offsets, flatten_ids, ch, int(width), int(height), float(visibility_min_T),
-        bool(absgrad), has_end)
+        bool(absgrad), has_end, bool(need_n_touched))
 
     out = RasterizationOutput(
         rgbs=render[..., :3],

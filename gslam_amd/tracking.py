@@ -153,7 +153,7 @@ class GraphedTracker:
     def _closure_body(self, advance: bool = False):
         for p in self.params:
             p.grad = None               # AccumulateGrad then adopts the fresh gradient tensor (no accumulate kernel)
-        out = self.splats([self.camera], [self.pose], render_depth=True)
+        out = self.splats([self.camera], [self.pose], render_depth=True, need_n_touched=False)   # tracking never reads it
         loss = self._loss_fn(out, self.img, self.exposure)
         loss.backward()
         loss = loss.detach()

@@ -1,5 +1,5 @@
 """Interleaved A/B timing of render stages in ONE process (cdna guide rule 24): raster kernel generations
-(GSX_RASTER=1|2|3), rocPRIM sort vs tile-binned sort.
+(GSX_RASTER=1..5), rocPRIM sort vs tile-binned sort.
 usage: python tools/ab_raster.py [N ...] [C=1 C=8]"""
 import os
 import sys
@@ -82,16 +82,11 @@ def run(N, C, W=640, H=480):
 
     res = {}
     for _ in range(2):
-        for ver in ("2", "3", "4"):
+        for ver in ("2", "4", "5"):
             os.environ["GSX_RASTER"] = ver
             fwd()
             res.setdefault(("fwd", ver), []).append(timed(fwd))
             res.setdefault(("bwd", ver), []).append(timed(bwd))
-    os.environ["GSX_RASTER"] = "4"
-    for mode in ("0", "1", "2"):
-        os.environ["GSX_BWD_MODE"] = mode
-        res[("bwd", "4/mode" + mode)] = [timed(bwd), timed(bwd)]
-    os.environ.pop("GSX_BWD_MODE", None)
     os.environ.pop("GSX_RASTER", None)
     fwd()
     res[("fwd", "auto")] = [timed(fwd)]
