@@ -67,7 +67,7 @@ class StageTimer:
     """Times every C-ABI launch with HIP events on the stream the kernels are launched on (torch's current stream)."""
     STAGES = ("gsx_project_fwd", "gsx_isect_bin_sort", "gsx_isect_scan", "gsx_isect_emit_sort",
               "gsx_isect_offset_encode", "gsx_map_loss", "gsx_isotropic_loss", "gsx_raster_fwd",
-              "gsx_raster_bwd", "gsx_project_bwd", "gsx_ssim_fwd", "gsx_ssim_bwd", "gsx_adam_multi")
+              "gsx_raster_bwd", "gsx_project_bwd", "gsx_ssim_fwd", "gsx_ssim_bwd", "gsx_adam_multi", "gsx_adam_multi_steps")
 
     def __init__(self):
         self.events = {s: [] for s in self.STAGES}
@@ -120,6 +120,7 @@ def algorithmic_bytes(N, C, M, P, CH):
         "gsx_ssim_fwd": 72 * P,
         "gsx_ssim_bwd": 72 * P,
         "gsx_adam_multi": 420 * N,
+        "gsx_adam_multi_steps": 420 * N,
     }
 
 

@@ -57,6 +57,9 @@ PROTOTYPES = {
                                 C.POINTER(vp), vp]),
     "gsx_adam_multi": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
                              C.POINTER(f32), f32, f32, f32, i64, vp, vp]),
+    "gsx_adam_multi_steps": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
+                                   C.POINTER(f32), f32, f32, f32, C.POINTER(vp), vp]),
+    "gsx_counters_add": (i32, [i32, C.POINTER(vp), i64, vp]),
     "gsx_track_opt_state_bytes": (i64, []),
     "gsx_track_opt_init": (i32, [vp, i32, i32, f32, C.c_double, i32, i32, i32, C.c_double, C.c_double, vp]),
     "gsx_track_opt_advance": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, vp]),

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int deg, const float *__res
 }
 
 // ---- fused multi-tensor Adam --------------------------------------------------------------------------------------
-constexpr int ADAM_MAX = 8;
+constexpr int ADAM_MAX = 32;
 struct AdamArgs {
     float *p[ADAM_MAX];
     const float *g[ADAM_MAX];
@@ -166,7 +166,10 @@ struct AdamArgs {
     int64_t start[ADAM_MAX + 1];  // exclusive prefix of numels
     float step_size[ADAM_MAX];    // lr / bias_correction1 (host-step mode)
     float lr[ADAM_MAX];
-    const int64_t *step_dev;      // non-null: 1-based step lives on the device (graph-capturable)
+    const int64_t *step_dev;      // non-null: the step lives on the device (graph-capturable)
+    const int64_t *step_of[ADAM_MAX];   // per-tensor mode: each tensor's own device step counter (1-based, already
+                                        // incremented for this update; tensors join the optimiser at different times)
+    int per_tensor;
     int count;
     float beta1, beta2, eps, bc2_sqrt;
 };
@@ -174,15 +177,26 @@ struct AdamArgs {
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
     const int64_t total = a.start[a.count];
     float bc1 = 1.0f, bc2_sqrt = a.bc2_sqrt;
-    if (a.step_dev) {
+    if (a.step_dev && !a.per_tensor) {
         const float t = (float)a.step_dev[0];
         bc1 = 1.0f - powf(a.beta1, t);
         bc2_sqrt = sqrtf(1.0f - powf(a.beta2, t));
     }
+    int k_cached = -1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int k = 0;
+        int lo = 0, hi = a.count - 1;                   // last tensor whose start is <= i
 #pragma unroll
-        for (int q = 1; q < ADAM_MAX; ++q) k += (q < a.count && i >= a.start[q]) ? 1 : 0;
+        for (int it = 0; it < 5; ++it) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.start[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const int k = lo;
+        if (a.per_tensor && k != k_cached) {
+            const float t = (float)a.step_of[k][0];
+            bc1 = 1.0f - powf(a.beta1, t);
+            bc2_sqrt = sqrtf(1.0f - powf(a.beta2, t));
+            k_cached = k;
+        }
         const int64_t j = i - a.start[k];
         const float grad = a.g[k][j];
         float m = a.m[k][j], v = a.v[k][j];
@@ -194,6 +208,16 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
         a.m[k][j] = m;
         a.v[k][j] = v;
     }
+}
+
+struct CounterArgs {
+    int64_t *p[16];
+    int n;
+    int64_t delta;
+};
+
+__global__ void counters_add_kernel(CounterArgs a) {
+    if (threadIdx.x < a.n) a.p[threadIdx.x][0] += a.delta;
 }
 
 // ---- self test ------------------------------------------------------------------------------------------------------
@@ -231,32 +255,64 @@ extern "C" int gsx_sh_bwd(int degree, const float *dirs, const float *coeffs, co
     return GSX_OK;
 }
 
-extern "C" int gsx_adam_multi(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
-                              float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1,
-                              float beta2, float eps, int64_t step_host, const int64_t *step_dev, void *stream) {
+static int adam_launch(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                       float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1, float beta2,
+                       float eps, int64_t step_host, const int64_t *step_dev, const int64_t *const *steps, void *stream) {
     GSX_CHECK_ARG(n_tensors >= 1 && n_tensors <= ADAM_MAX && params && grads && exp_avg && exp_avg_sq && numels && lrs);
-    GSX_CHECK_ARG(step_host >= 1 || step_dev);
+    GSX_CHECK_ARG(step_host >= 1 || step_dev || steps);
     AdamArgs a;
     a.count = n_tensors;
     a.start[0] = 0;
-    a.step_dev = step_dev;
+    a.step_dev = steps ? steps[0] : step_dev;
+    a.per_tensor = steps ? 1 : 0;
     const double sh = (double)(step_host >= 1 ? step_host : 1);
     const double bc1 = 1.0 - pow((double)beta1, sh), bc2 = 1.0 - pow((double)beta2, sh);
     for (int k = 0; k < ADAM_MAX; ++k) {
         const bool in = k < n_tensors;
+        a.step_of[k] = (steps && in) ? steps[k] : nullptr;
+        if (steps && in) GSX_CHECK_ARG(steps[k]);
         a.p[k] = in ? params[k] : nullptr; a.g[k] = in ? grads[k] : nullptr;
         a.m[k] = in ? exp_avg[k] : nullptr; a.v[k] = in ? exp_avg_sq[k] : nullptr;
         a.start[k + 1] = a.start[k] + (in ? numels[k] : 0);
         a.step_size[k] = in ? (float)((double)lrs[k] / bc1) : 0.f;
         a.lr[k] = in ? lrs[k] : 0.f;
-        if (in) GSX_CHECK_ARG(numels[k] >= 0 && (numels[k] == 0 || (params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k])));
+        if (in) GSX_CHECK_ARG(numels[k] >= 1 && params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k]);
     }
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.bc2_sqrt = (float)sqrt(bc2);
     const int64_t total = a.start[n_tensors];
-    if (total == 0) return GSX_OK;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 2048 * 4) blocks = 2048 * 4;
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_adam_multi(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                              float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1,
+                              float beta2, float eps, int64_t step_host, const int64_t *step_dev, void *stream) {
+    return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, lrs, beta1, beta2, eps, step_host,
+                       step_dev, nullptr, stream);
+}
+
+extern "C" int gsx_adam_multi_steps(int n_tensors, float *const *params, const float *const *grads,
+                                    float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numels,
+                                    const float *lrs, float beta1, float beta2, float eps,
+                                    const int64_t *const *steps, void *stream) {
+    GSX_CHECK_ARG(steps);
+    return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, lrs, beta1, beta2, eps, 0, nullptr, steps,
+                       stream);
+}
+
+extern "C" int gsx_counters_add(int n, int64_t *const *counters, int64_t delta, void *stream) {
+    GSX_CHECK_ARG(n >= 1 && n <= 16 && counters);
+    CounterArgs a;
+    a.n = n;
+    a.delta = delta;
+    for (int k = 0; k < 16; ++k) {
+        a.p[k] = k < n ? counters[k] : nullptr;
+        if (k < n) GSX_CHECK_ARG(counters[k]);
+    }
+    hipLaunchKernelGGL(counters_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }

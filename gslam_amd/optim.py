@@ -11,7 +11,8 @@ import torch
 
 from ._lib import check, lib, stream_ptr
 
-_MAX = 8
+_MAX = 32          # tensors per launch (csrc/misc.hip ADAM_MAX)
+_MAX_COUNTERS = 16  # device step counters bumped per gsx_counters_add launch
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -40,7 +41,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         # bucket by (betas, eps, step) so that every launch shares its scalar state
         buckets: dict = {}
-        bumped = set()
+        bumped: dict = {}
         for group in self.param_groups:
             live = [p for p in group["params"] if p.grad is not None]
             if not live:
@@ -58,8 +59,7 @@ class FusedAdam(torch.optim.Optimizer):
                         group["_step_dev"] = torch.full((1,), group["_host_step"] - 1, dtype=torch.int64, device=dev0)
                     step_dev = group["_step_dev"]
                 if id(step_dev) not in bumped:
-                    step_dev += 1
-                    bumped.add(id(step_dev))
+                    bumped[id(step_dev)] = step_dev
             for p in live:
                 st = self.state[p]
                 if not st:
@@ -67,20 +67,27 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32):
                     raise RuntimeError("FusedAdam needs contiguous float32 parameters on the GPU (no CPU fallback)")
-                key = (group["betas"], group["eps"], 0 if self.capturable else group["_host_step"], p.device,
-                       id(step_dev))
+                key = (group["betas"], group["eps"], 0 if self.capturable else group["_host_step"], p.device)
                 buckets.setdefault(key, []).append((p, p.grad.contiguous(), st, float(group["lr"]), step_dev))
-        for (betas, eps, step, dev, _sid), items in buckets.items():
+        if bumped:                                     # all device step counters of this update in one tiny launch
+            ctrs = list(bumped.values())
+            for i in range(0, len(ctrs), _MAX_COUNTERS):
+                part = ctrs[i:i + _MAX_COUNTERS]
+                check(lib.gsx_counters_add(len(part), (C.c_void_p * len(part))(*[t.data_ptr() for t in part]), 1,
+                                           stream_ptr(part[0].device)), "gsx_counters_add")
+        for (betas, eps, step, dev), items in buckets.items():
             for i in range(0, len(items), _MAX):
                 chunk = items[i:i + _MAX]
                 n = len(chunk)
                 arr = lambda xs: (C.c_void_p * n)(*xs)
-                check(lib.gsx_adam_multi(
-                    n, arr([c_[0].data_ptr() for c_ in chunk]), arr([c_[1].data_ptr() for c_ in chunk]),
-                    arr([c_[2]["exp_avg"].data_ptr() for c_ in chunk]),
-                    arr([c_[2]["exp_avg_sq"].data_ptr() for c_ in chunk]),
-                    (C.c_int64 * n)(*[c_[0].numel() for c_ in chunk]),
-                    (C.c_float * n)(*[c_[3] for c_ in chunk]),
-                    float(betas[0]), float(betas[1]), float(eps), int(step),
-                    chunk[0][4].data_ptr() if self.capturable else None, stream_ptr(dev)), "gsx_adam_multi")
+                common = (n, arr([c_[0].data_ptr() for c_ in chunk]), arr([c_[1].data_ptr() for c_ in chunk]),
+                          arr([c_[2]["exp_avg"].data_ptr() for c_ in chunk]),
+                          arr([c_[2]["exp_avg_sq"].data_ptr() for c_ in chunk]),
+                          (C.c_int64 * n)(*[c_[0].numel() for c_ in chunk]),
+                          (C.c_float * n)(*[c_[3] for c_ in chunk]), float(betas[0]), float(betas[1]), float(eps))
+                if self.capturable:
+                    check(lib.gsx_adam_multi_steps(*common, arr([c_[4].data_ptr() for c_ in chunk]), stream_ptr(dev)),
+                          "gsx_adam_multi_steps")
+                else:
+                    check(lib.gsx_adam_multi(*common, int(step), None, stream_ptr(dev)), "gsx_adam_multi")
         return loss

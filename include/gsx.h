@@ -207,13 +207,23 @@ int gsx_pose_zhou_bwd(int C, const float *const *Rt, const float *const *dR, con
                       const int *learnable, const float *v_viewmats, float *const *v_dR, float *const *v_dt,
                       void *stream);
 
-/* ---- fused Adam (torch.optim.Adam(fused=True) defaults; gslam/backend.py:565-602).  Up to 8 tensors per launch.
+/* ---- fused Adam (torch.optim.Adam(fused=True) defaults; gslam/backend.py:565-602).  Up to 32 tensors per launch
+ * (every numel >= 1).
  * step_dev: device int64 holding the 1-based step AFTER increment is step_dev[0]+1; kernel does not modify it
  * when step_host > 0 (then step_host is used).                                                                      */
 int gsx_adam_multi(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                    float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1, float beta2,
                    float eps, int64_t step_host, const int64_t *step_dev /*nullable device int64: overrides step_host*/,
                    void *stream);
+
+/* Same update with one device step counter PER TENSOR (steps: HOST array of n_tensors DEVICE int64 pointers; the
+ * counters hold the 1-based step of this update), so tensors that joined the optimiser at different times (poses of
+ * new keyframes, backend.py:665-670) update in the same launch.  gsx_counters_add bumps up to 16 such counters in one
+ * launch (what torch's capturable Adam does with one `step += 1` kernel per parameter). */
+int gsx_adam_multi_steps(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                         float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1, float beta2,
+                         float eps, const int64_t *const *steps, void *stream);
+int gsx_counters_add(int n, int64_t *const *counters, int64_t delta, void *stream);
 
 /* ---- device-resident tracking optimiser: the host logic of gslam/frontend.py:604-662 (10 torch.optim.Adam steps, then
  * ONE torch.optim.LBFGS(line_search_fn='strong_wolfe').step()) as a state machine advanced once per closure
