@@ -232,6 +232,53 @@ class BundleAdjuster:
         return last
 
 
+def optimize_poses_lbfgs(splats: GaussianSplattingData, window: List[Frame], conf: Optional[MapConfig] = None,
+                         max_eval: Optional[int] = None):
+    """``Backend.optimize_poses_lbfgs`` (gslam/backend.py:447-506): one strong-Wolfe L-BFGS step (history 10,
+    tolerance_change 1e-7, torch defaults lr = 1, max_iter = 20) over the poses of the window with the photometric
+    loss only; the pose of frame 0 stays fixed (:459-462), exposure parameters are not optimised (:463-464).  Every
+    closure is one C-camera render forward + backward through the fused loss kernel.  Returns the last loss."""
+    conf = conf or MapConfig()
+    cameras = [x.camera for x in window]
+    poses = [x.pose for x in window]
+    gt_imgs = create_batch(window, lambda x: x.img)
+    exposure = create_batch(window, lambda x: x.exposure_params).detach()
+    params = []
+    for x in window:
+        if x.index == 0:
+            continue
+        params.extend(list(x.pose.parameters()))
+    if not params:
+        return None
+    kw = {} if max_eval is None else {"max_eval": max_eval}
+    optimizer = torch.optim.LBFGS(params, history_size=10, line_search_fn='strong_wolfe', tolerance_change=1e-7, **kw)
+    last_loss = None
+    frozen = [p.requires_grad for p in splats.parameters()]      # only the poses move here
+
+    def closure():
+        nonlocal last_loss
+        if torch.is_grad_enabled():
+            optimizer.zero_grad()
+        outputs = splats(cameras, poses, render_depth=True, need_n_touched=False)
+        # photometric term alone (backend.py:484-492): the fused block with the SSIM / isotropic / TV weights at zero
+        _total, photometric = fused_mapping_loss(outputs, gt_imgs, exposure, None, ssim_weight=0.0, iso_weight=0.0,
+                                                 tv_weight=0.0, active_gs=conf.active_gs)
+        loss = _total
+        if loss.requires_grad:
+            loss.backward()
+        last_loss = loss.item()                                  # backend.py:501
+        return loss
+
+    for p in splats.parameters():
+        p.requires_grad_(False)
+    try:
+        optimizer.step(closure)
+    finally:
+        for p, r in zip(splats.parameters(), frozen):
+            p.requires_grad_(r)
+    return last_loss
+
+
 class GraphedBundleAdjuster:
     """A BA iteration over a FIXED window captured into HIP graphs and replayed: the ~45 launches of a step (pose
     chain, K1, binning, sort, K8, SSIM, loss, K9, K2, Adam, decay) cost one graph launch on the host.  Multi-GPU: two

@@ -139,3 +139,20 @@ def test_device_optimizer_tracks_like_host_optimizer(dev):
     for lh, ld in zip(res[False][1], res[True][1]):
         # near the optimum the line-search branches hang on float32 noise (tests/test_track_opt_cpu.py): same order only
         assert max(lh, ld) <= 10.0 * min(lh, ld) + 1e-4, (lh, ld)
+
+
+def test_optimize_poses_lbfgs(dev):
+    """gslam/backend.py:447-506: window pose refinement; frame 0 is not touched, the others move towards the truth."""
+    from gslam_amd.mapping import optimize_poses_lbfgs
+    m, cam, frame = _setup(dev)
+    window = [frame(0, 0), frame(2, 1), frame(4, 3)]          # (true pose index, starting pose index)
+    window[0].index = 0
+    before = [_pose_err(f) for f in window]
+    p0 = window[0].pose().detach().clone()
+    last = optimize_poses_lbfgs(m, window, max_eval=20)
+    torch.cuda.synchronize()
+    after = [_pose_err(f) for f in window]
+    assert last is not None and np.isfinite(last)
+    assert torch.equal(window[0].pose().detach(), p0)
+    assert after[1] < 0.6 * before[1] and after[2] < 0.6 * before[2], (before, after)
+    assert all(not p.requires_grad for p in m.parameters())   # frozen-map state restored as it was
