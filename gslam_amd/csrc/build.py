@@ -28,6 +28,7 @@ SOURCES = {
     "pose.hip": [],
     "misc.hip": [],
     "track_opt.hip": [],
+    "maintain.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result", "-DNDEBUG"]

@@ -129,6 +129,13 @@ class BundleAdjuster:
         self.total_step = 0
         self.last_outputs: Optional[RasterizationOutput] = None
 
+    def map_changed(self):
+        """call after gslam_amd.pruning / gslam_amd.insertion re-packed the map (new parameter tensors, new N): the
+        multi-GPU gradient bucket is rebuilt for the new size; captured graphs of the old map must be discarded."""
+        if self.bucket is not None:
+            self.bucket = gdist.GradBucket(self.splats)
+        self.last_outputs = None
+
     def step(self, window: List[Frame], regularize: bool = True, decay_opacity: bool = True):
         """window = ALL keyframes of the BA window (every rank passes the same list); this rank renders its shard.
         = render_backward() -> reduce() -> update(); the three phases are separately callable so that the two

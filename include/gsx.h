@@ -239,6 +239,19 @@ int gsx_track_opt_advance(void *state, int n_tensors, float *const *params, cons
                           const int *numels, const float *loss, void *stream);
 int gsx_track_opt_report(const void *state, float *out8, void *stream);
 
+/* ---- map maintenance: every per-Gaussian array re-packed in ONE launch.
+ * gsx_gather_rows: dst[k][r] = src[k][index[r]] for r < n_out, k < n_tensors (<= 32); the masked re-allocation of
+ *   gslam/pruning.py:24-47 (`splat_param[keep_mask]`, `value[keep_mask]` per parameter and Adam moment) and the
+ *   `_duplicate` / `_split` selections of gslam/insertion.py:66-96.  row_words: width of one row of tensor k in 4-byte
+ *   words (int64 ages = 2).  index: device int64 [n_out] (e.g. nonzero(keep_mask)); values are clamped to [0, n_src).
+ * gsx_concat_rows: dst[k] = [a[k] (n_a rows); b[k] (n_b rows)], b[k] == NULL meaning zero rows; the torch.cat pairs of
+ *   gslam/insertion.py:38-58 (`_add_new_splats`: parameters + zero Adam moments).
+ * src / dst / a / b / row_words are HOST arrays; the pointers in them are DEVICE pointers. */
+int gsx_gather_rows(int n_tensors, const void *const *src, void *const *dst, const int *row_words, const int64_t *index,
+                    int64_t n_out, int64_t n_src, void *stream);
+int gsx_concat_rows(int n_tensors, const void *const *a, int64_t n_a, const void *const *b, int64_t n_b,
+                    void *const *dst, const int *row_words, void *stream);
+
 /* ---- self tests of device primitives (wave64 reductions); returns 0 if all pass.  scratch: >= 64 KiB device ----- */
 int gsx_selftest(void *scratch, int64_t scratch_bytes, void *stream);
 
