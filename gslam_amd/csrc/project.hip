@@ -444,9 +444,16 @@ __global__ __launch_bounds__(256) void project_bwd_finish_kernel(const float *__
     const int c = blockIdx.x;
     const int k = threadIdx.x % 12, r = threadIdx.x / 12;
     if (r < 21) {
-        float acc = 0.f;
-        for (int b = r; b < n_blocks; b += 21) acc += partials[((int64_t)b * C + c) * 12 + k];
-        s_acc[r][k] = acc;
+        // eight independent accumulators: the loads of a trip are all in flight together (a 500 k map has ~2000
+        // block partials per camera; one dependent load per trip made this tiny kernel take 23 us)
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = r;
+        for (; b + 7 * 21 < n_blocks; b += 8 * 21) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += partials[((int64_t)(b + u * 21) * C + c) * 12 + k];
+        }
+        for (; b < n_blocks; b += 21) acc[0] += partials[((int64_t)b * C + c) * 12 + k];
+        s_acc[r][k] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
     __syncthreads();
     if (threadIdx.x < 16) {

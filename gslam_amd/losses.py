@@ -42,8 +42,8 @@ def _loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_i
         st = stream_ptr(dev)
         n_px = Cn * H * W
         sums = torch.empty(3, dtype=torch.float32, device=dev)
-        ssim_sum = torch.empty(1, dtype=torch.float32, device=dev)
-        iso_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        ssim_sum = torch.empty(1, dtype=torch.float32, device=dev) if w_ssim != 0.0 else None
+        iso_sum = None
         v_render = torch.empty_like(render)
         v_exposure = torch.empty_like(exposure)
         ssim_grad = None
@@ -60,8 +60,6 @@ def _loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_i
             one = _ones(dev)
             check(lib.gsx_ssim_bwd(ptr(render), ptr(gt), Cn, 3, H, W, s_r, s_g, 5, ptr(dm[0]), ptr(dm[1]), ptr(dm[2]),
                                    ptr(one), -w_ssim / numel_ssim, ptr(ssim_grad), st), "gsx_ssim_bwd")
-        else:
-            ssim_sum.zero_()
         denom = n_px * (3 if mode == 1 else 1)
         ws = workspace(lib.gsx_map_loss_workspace_bytes(Cn, H, W), dev, "map_loss")
         check(lib.gsx_map_loss(ptr(render), ptr(alphas.contiguous()) if alphas is not None else None, ptr(gt),
@@ -72,18 +70,25 @@ def _loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_i
         if w_iso != 0.0 and log_scales is not None:
             log_scales = log_scales.contiguous()
             v_scales = torch.empty_like(log_scales)
+            iso_sum = torch.empty(1, dtype=torch.float32, device=dev)
             N = log_scales.shape[0]
             ws = workspace(lib.gsx_isotropic_workspace_bytes(N), dev, "iso")
             check(lib.gsx_isotropic_loss(ptr(log_scales), ptr(vis_count.contiguous()), N, w_iso, ptr(iso_sum),
                                          ptr(v_scales), ptr(ws), ws.numel(), st), "gsx_isotropic_loss")
         # total / photometric from the raw sums, on device
         out2 = torch.empty(2, dtype=torch.float32, device=dev)
-        terms = (C.c_void_p * 5)(sums[0:1].data_ptr(), sums[1:2].data_ptr(), sums[2:3].data_ptr(), ssim_sum.data_ptr(),
-                                 iso_sum.data_ptr())
         pm = 1.0 / denom
-        c0 = (C.c_float * 5)(w_photo * pm, w_photo * pm, w_tv, -w_ssim / numel_ssim, w_iso)
-        c1 = (C.c_float * 5)(pm, pm, 0.0, 0.0, 0.0)
-        check(lib.gsx_combine_terms(5, terms, c0, c1, w_ssim, 0.0, ptr(out2), st), "gsx_combine_terms")
+        # (device scalar, weight in the total, weight in the photometric value); absent terms are simply not passed
+        parts = [(sums[0:1], w_photo * pm, pm), (sums[1:2], w_photo * pm, pm), (sums[2:3], w_tv, 0.0)]
+        if ssim_sum is not None:
+            parts.append((ssim_sum, -w_ssim / numel_ssim, 0.0))
+        if iso_sum is not None:
+            parts.append((iso_sum, w_iso, 0.0))
+        n = len(parts)
+        terms = (C.c_void_p * n)(*[p[0].data_ptr() for p in parts])
+        c0 = (C.c_float * n)(*[p[1] for p in parts])
+        c1 = (C.c_float * n)(*[p[2] for p in parts])
+        check(lib.gsx_combine_terms(n, terms, c0, c1, w_ssim, 0.0, ptr(out2), st), "gsx_combine_terms")
         return out2, v_render, v_exposure, v_scales
 
 
@@ -146,6 +151,15 @@ def mapping_loss_and_grads(outputs, gt_imgs: Tensor, exposure_params: Tensor, lo
                           -1 if outputs._betas_index is None else outputs._betas_index,
                           shard * (1.0 - ssim_weight), shard * ssim_weight, iso_scale * iso_weight, tv_weight,
                           0 if active_gs else 1)
+
+
+def tracking_loss_and_grads(outputs, gt_img: Tensor, exposure_params: Tensor):
+    """The tracking loss without the autograd node: (out2[loss, loss], v_render, v_exposure [2]); the caller seeds the
+    backward with ``torch.autograd.backward([outputs._render], [v_render])`` (no multiply-by-one kernels, no clones)."""
+    out2, v_render, v_exposure, _ = loss_and_grads(
+        outputs._render, None, gt_img[None] if gt_img.dim() == 3 else gt_img, exposure_params.reshape(1, 2), None, None,
+        -1 if outputs._depth_index is None else outputs._depth_index, outputs._betas_index, 1.0, 0.0, 0.0, 0.0, 2)
+    return out2, v_render, v_exposure.reshape(-1)
 
 
 def fused_tracking_loss(outputs, gt_img: Tensor, exposure_params: Tensor):

@@ -127,7 +127,7 @@ class GraphedTracker:
 
     def __init__(self, splats: GaussianSplattingData, camera, conf: Optional[TrackingConfig] = None,
                  device_optimizer: bool = True, max_eval: int = 25):
-        from .losses import fused_tracking_loss
+        from .losses import tracking_loss_and_grads
         from .primitives import PoseZhou
         from .rasterization import validate
         self.conf = conf or TrackingConfig()
@@ -138,7 +138,7 @@ class GraphedTracker:
         self.exposure = torch.zeros(2, device=dev, requires_grad=True)
         self.img = torch.zeros(H, W, 3, device=dev)
         self.params = [self.pose.dt, self.pose.dR, self.exposure]
-        self._loss_fn = fused_tracking_loss
+        self._loss_fn = tracking_loss_and_grads
         self.graph = None
         self.loss = None
         self._validate = validate
@@ -154,9 +154,11 @@ class GraphedTracker:
         for p in self.params:
             p.grad = None               # AccumulateGrad then adopts the fresh gradient tensor (no accumulate kernel)
         out = self.splats([self.camera], [self.pose], render_depth=True, need_n_touched=False)   # tracking never reads it
-        loss = self._loss_fn(out, self.img, self.exposure)
-        loss.backward()
-        loss = loss.detach()
+        # value and analytic gradient in one pass (csrc/loss.hip); the backward is seeded at the render tensor
+        out2, v_render, v_exposure = self._loss_fn(out, self.img, self.exposure)
+        torch.autograd.backward([out._render], [v_render])
+        self.exposure.grad = v_exposure
+        loss = out2[0:1]
         if advance:
             import ctypes as C
             from ._lib import check, lib, stream_ptr
