@@ -103,6 +103,48 @@ __device__ __forceinline__ void gsx_wave63_sum(float (&v)[N]) {
         asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v[k]));
 }
 
+// Reduce-scatter of N <= 12 per-lane values over the wavefront's four 16-lane rows (measured on MI355X: every DPP
+// instruction costs 4.2 SIMD cycles against 2.4 for a plain v_fma, tools/ubench/valu_rates.hip, so the 6 N DPP adds of a
+// full reduction of each value dominate the rasteriser backward).  Steps:
+//   1. quad butterflies (quad_perm xor 1, xor 2): every lane holds its quad's sum of every value        2 N ops
+//   2. scatter over the banks (4-lane groups) with row_shl / row_shr 4 and bank_mask, which selects the
+//      writing lanes for free: register j = values (2j | 2j+1) in (even | odd) banks                     ~N ops
+//   3. the same over bank pairs with row_shl / row_shr 8: register m = values 4m + bank                 ~N/2 ops
+// Afterwards, in every row, a lane of bank b holds in v[m] (m < (N+3)/4) that ROW's sum of value 4m + b; the caller
+// adds the four rows up in memory (one ds_add_f32 per m with the 16 lanes `lane % 4 == 0`).  3.5 N DPP ops instead
+// of 6 N and (N+3)/4 LDS instructions instead of N.  Slots 4m + b >= N hold garbage.
+template <int N>
+__device__ __forceinline__ void gsx_reduce_scatter(float (&v)[N]) {
+    static_assert(N >= 1 && N <= 12, "gsx_reduce_scatter: N <= 12");
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[k]));
+    if (N < 3) asm volatile("s_nop 1");
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v[k]));
+    asm volatile("s_nop 1");
+    constexpr int N1 = (N + 1) / 2;
+#pragma unroll
+    for (int j = 0; j < N1; ++j) {          // banks 0,2 <- value 2j summed over the bank pair; banks 1,3 <- value 2j+1
+        asm volatile("v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(v[2 * j]));
+        if (2 * j + 1 < N)
+            asm volatile("v_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(v[2 * j]) : "v"(v[2 * j + 1]));
+    }
+    asm volatile("s_nop 1");
+    constexpr int N2 = (N1 + 1) / 2;
+#pragma unroll
+    for (int m = 0; m < N2; ++m) {          // banks 0,1 <- register 2m summed over the row; banks 2,3 <- register 2m+1
+        asm volatile("v_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0x3" : "+v"(v[4 * m]));
+        if (2 * m + 1 < N1)
+            asm volatile("v_add_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc" : "+v"(v[4 * m]) : "v"(v[4 * m + 2]));
+    }
+    // compact: result register m lives in v[4m]
+#pragma unroll
+    for (int m = 1; m < N2; ++m) v[m] = v[4 * m];
+}
+
 // 48-byte splat record fetched through the scalar data cache into SGPRs (uniform address): the broadcast of a
 // Gaussian to all 64 pixel lanes costs no VALU instruction and no LDS traffic.
 typedef float gsx_f4 __attribute__((ext_vector_type(4)));

@@ -682,7 +682,9 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     const int variant = raster_variant(true, T);
     const bool v1 = (use_v1() || variant == 1) && !offsets_has_end;
     const char *bb = getenv("GSX_BWD_MODE");
-    const int bwd_mode = (bb && bb[0] == '0') ? 0 : 1;
+    // reduce-scatter (mode 2) wins while the chip is not full (-8..10 % at one camera); its four rows adding to one LDS
+    // address lose to the single-lane add (mode 1) once it is (+7 % at eight cameras): tools/ab_raster.py
+    const int bwd_mode = (bb && bb[0] >= '0' && bb[0] <= '2') ? bb[0] - '0' : (T < 4096 ? 2 : 1);
     const char *sb = getenv("GSX_BWD_SCALAR");
     const bool scalar_bwd = sb && sb[0] == '1';
 #define ARGS1 rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
@@ -690,7 +692,11 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
         if (variant >= 4 && !v1 && !v_abs) {                                                                        \
-            if (bwd_mode == 0)                                                                                      \
+            if (bwd_mode == 2)                                                                                      \
+                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 2>), dim3((unsigned)T), dim3(128), 0, st, rec, \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
+            else if (bwd_mode == 0)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 0>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
                                    alphas, last_ids, v_render, v_alphas, v_rec);                                    \

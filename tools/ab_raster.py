@@ -87,6 +87,11 @@ def run(N, C, W=640, H=480):
             fwd()
             res.setdefault(("fwd", ver), []).append(timed(fwd))
             res.setdefault(("bwd", ver), []).append(timed(bwd))
+    os.environ["GSX_RASTER"] = "4"
+    for mode in ("1", "2"):
+        os.environ["GSX_BWD_MODE"] = mode
+        res[("bwd", "4/mode" + mode)] = [timed(bwd), timed(bwd)]
+    os.environ.pop("GSX_BWD_MODE", None)
     os.environ.pop("GSX_RASTER", None)
     fwd()
     res[("fwd", "auto")] = [timed(fwd)]
