@@ -1,18 +1,20 @@
 // ssim.hip — K11/K12: fused SSIM loss, forward and backward.  Replaces rahul-goel/fused-ssim@30fb258c
 // `fused_ssim(img1, img2, padding, train)` (gslam/backend.py:13,303-307).  Maths: SURVEY.md §9.5.
 //
-// Mapping: one 256-thread workgroup per 16x16 output tile of one (batch, channel) plane.  The 26x26 input halo of
+// Mapping: one 256-thread workgroup per 32x16 output tile of one (batch, channel) plane.  The 42x26 input halo of
 // both images is staged in LDS once (zero padded), the 11-tap separable Gaussian runs horizontally into LDS
-// (5 moments) and vertically into registers.  Inputs are read through explicit (B,C,H,W) strides so the NHWC
+// (5 moments) and vertically into registers, both passes register-blocked.  Inputs are read through explicit (B,C,H,W) strides so the NHWC
 // renders of the rasteriser are consumed without a permute copy.  The map mean is reduced wave64 -> LDS -> one
 // partial per workgroup, then a single-block finishing kernel (deterministic, no atomics).
 #include "gsx_common.h"
 
 namespace {
 
-constexpr int TS = 16;           // output tile
+constexpr int TSX = 32;          // output tile: 32 x 16 pixels per 256-thread workgroup (2 outputs per thread in the
+constexpr int TSY = 16;          // vertical pass, 4 per active thread in the horizontal one)
 constexpr int HALO = 5;          // 11-tap window
-constexpr int IN = TS + 2 * HALO;  // 26
+constexpr int INX = TSX + 2 * HALO;  // 42
+constexpr int INY = TSY + 2 * HALO;  // 26
 
 __device__ __constant__ float c_win[11] = {1.0283800845e-03f, 7.5987581352e-03f, 3.6000772128e-02f, 1.0936068951e-01f,
                                            2.1300553771e-01f, 2.6601172486e-01f, 2.1300553771e-01f, 1.0936068951e-01f,
@@ -22,22 +24,25 @@ struct Strides {
     int64_t b, c, h, w;
 };
 
+// Register-blocked separable filter: a thread of the horizontal pass produces 4 adjacent outputs of one row from 14
+// inputs (3.5 LDS reads per output and moment pair instead of 11), a thread of the vertical pass 2 adjacent rows from
+// 12 (6 reads per output and moment instead of 11); the halo overhead of the 32 x 16 tile is 2.13x (16 x 16: 2.64x).
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__ img1, const float *__restrict__ img2,
                                                        int CH, int H, int W, Strides s1, Strides s2, int crop,
                                                        float *__restrict__ partials, float *__restrict__ dm_dmu1,
                                                        float *__restrict__ dm_ds1, float *__restrict__ dm_ds12) {
-    __shared__ float sx[IN][IN + 1];
-    __shared__ float sy[IN][IN + 1];
-    __shared__ float hz[5][IN][TS + 1];
+    __shared__ float sx[INY][INX + 1];
+    __shared__ float sy[INY][INX + 1];
+    __shared__ float hz[5][INY][TSX + 1];
     __shared__ float s_red[4];
     const int plane = blockIdx.z;
     const int b = plane / CH, ch = plane - b * CH;
-    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const int x0 = blockIdx.x * TSX, y0 = blockIdx.y * TSY;
     const int t = threadIdx.x;
     const float *p1 = img1 + b * s1.b + ch * s1.c;
     const float *p2 = img2 + b * s2.b + ch * s2.c;
-    for (int i = t; i < IN * IN; i += 256) {
-        const int ly = i / IN, lx = i - ly * IN;
+    for (int i = t; i < INY * INX; i += 256) {
+        const int ly = i / INX, lx = i - ly * INX;
         const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
         float a = 0.f, c = 0.f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
@@ -48,40 +53,67 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__
         sy[ly][lx] = c;
     }
     __syncthreads();
-    for (int i = t; i < IN * TS; i += 256) {
-        const int ly = i / TS, lx = i - ly * TS;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    if (t < INY * (TSX / 4)) {                 // 26 rows x 8 groups of 4 outputs = 208 threads
+        const int ly = t / (TSX / 4), lx = (t - ly * (TSX / 4)) * 4;
+        float a[14], c[14];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = c_win[k], a = sx[ly][lx + k], c = sy[ly][lx + k];
-            m1 += w * a; m2 += w * c; e11 += w * a * a; e22 += w * c * c; e12 += w * a * c;
+        for (int k = 0; k < 14; ++k) { a[k] = sx[ly][lx + k]; c[k] = sy[ly][lx + k]; }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float w = c_win[k], av = a[o + k], cv = c[o + k];
+                const float wa = w * av, wc = w * cv;
+                m1 += wa; m2 += wc; e11 += wa * av; e22 += wc * cv; e12 += wa * cv;
+            }
+            hz[0][ly][lx + o] = m1; hz[1][ly][lx + o] = m2; hz[2][ly][lx + o] = e11; hz[3][ly][lx + o] = e22;
+            hz[4][ly][lx + o] = e12;
         }
-        hz[0][ly][lx] = m1; hz[1][ly][lx] = m2; hz[2][ly][lx] = e11; hz[3][ly][lx] = e22; hz[4][ly][lx] = e12;
     }
     __syncthreads();
-    const int lx = t & 15, ly = t >> 4;
-    const int gx = x0 + lx, gy = y0 + ly;
-    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    const int lx = t & 31, ly = (t >> 5) * 2;  // two vertically adjacent outputs per thread
+    const int gx = x0 + lx;
+    float acc[2][5];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        const float w = c_win[k];
-        m1 += w * hz[0][ly + k][lx]; m2 += w * hz[1][ly + k][lx]; e11 += w * hz[2][ly + k][lx];
-        e22 += w * hz[3][ly + k][lx]; e12 += w * hz[4][ly + k][lx];
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc[o][m] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+        float v[5];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) v[m] = hz[m][ly + r][lx];
+        if (r < 11) {
+            const float w = c_win[r];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) acc[0][m] += w * v[m];
+        }
+        if (r >= 1) {
+            const float w = c_win[r - 1];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) acc[1][m] += w * v[m];
+        }
     }
     float val = 0.f;
-    if (gx < W && gy < H) {
-        const float s1q = e11 - m1 * m1, s2q = e22 - m2 * m2, s12 = e12 - m1 * m2;
-        const float A = 2.0f * m1 * m2 + GSX_SSIM_C1, B = 2.0f * s12 + GSX_SSIM_C2;
-        const float Cq = m1 * m1 + m2 * m2 + GSX_SSIM_C1, D = s1q + s2q + GSX_SSIM_C2;
-        const float m = (A * B) / (Cq * D);
-        const bool in_crop = gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;
-        if (in_crop) val = m;
-        if (dm_dmu1) {
-            const int64_t o = ((int64_t)plane * H + gy) * W + gx;
-            dm_dmu1[o] = (m2 * 2.0f * B) / (Cq * D) - (m2 * 2.0f * A) / (Cq * D) - (m1 * 2.0f * A * B) / (Cq * Cq * D) +
-                         (m1 * 2.0f * A * B) / (Cq * D * D);
-            dm_ds1[o] = (-A * B) / (Cq * D * D);
-            dm_ds12[o] = (2.0f * A) / (Cq * D);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int gy = y0 + ly + o;
+        if (gx < W && gy < H) {
+            const float m1 = acc[o][0], m2 = acc[o][1], e11 = acc[o][2], e22 = acc[o][3], e12 = acc[o][4];
+            const float s1q = e11 - m1 * m1, s2q = e22 - m2 * m2, s12 = e12 - m1 * m2;
+            const float A = 2.0f * m1 * m2 + GSX_SSIM_C1, B = 2.0f * s12 + GSX_SSIM_C2;
+            const float Cq = m1 * m1 + m2 * m2 + GSX_SSIM_C1, D = s1q + s2q + GSX_SSIM_C2;
+            const float m = (A * B) / (Cq * D);
+            const bool in_crop = gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;
+            if (in_crop) val += m;
+            if (dm_dmu1) {
+                const int64_t o_ = ((int64_t)plane * H + gy) * W + gx;
+                dm_dmu1[o_] = (m2 * 2.0f * B) / (Cq * D) - (m2 * 2.0f * A) / (Cq * D) - (m1 * 2.0f * A * B) / (Cq * Cq * D) +
+                              (m1 * 2.0f * A * B) / (Cq * D * D);
+                dm_ds1[o_] = (-A * B) / (Cq * D * D);
+                dm_ds12[o_] = (2.0f * A) / (Cq * D);
+            }
         }
     }
     const float tot = gsx_wave_sum(val);
@@ -111,14 +143,14 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float *__restrict__
                                                        const float *__restrict__ dm_ds12,
                                                        const float *__restrict__ scale, float scale_mul,
                                                        float *__restrict__ dL_dimg1) {
-    __shared__ float sm[3][IN][IN + 1];
-    __shared__ float hz[3][IN][TS + 1];
+    __shared__ float sm[3][INY][INX + 1];
+    __shared__ float hz[3][INY][TSX + 1];
     const int plane = blockIdx.z;
     const int b = plane / CH, ch = plane - b * CH;
-    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const int x0 = blockIdx.x * TSX, y0 = blockIdx.y * TSY;
     const int t = threadIdx.x;
-    for (int i = t; i < IN * IN; i += 256) {
-        const int ly = i / IN, lx = i - ly * IN;
+    for (int i = t; i < INY * INX; i += 256) {
+        const int ly = i / INX, lx = i - ly * INX;
         const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
         float a = 0.f, c = 0.f, d = 0.f;
         if (gx >= crop && gx < W - crop && gy >= crop && gy < H - crop) {  // dL/dmap is zero outside the crop
@@ -128,36 +160,48 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float *__restrict__
         sm[0][ly][lx] = a; sm[1][ly][lx] = c; sm[2][ly][lx] = d;
     }
     __syncthreads();
-    for (int i = t; i < IN * TS; i += 256) {
-        const int ly = i / TS, lx = i - ly * TS;
-        float a = 0.f, c = 0.f, d = 0.f;
+    if (t < INY * (TSX / 4)) {
+        const int ly = t / (TSX / 4), lx = (t - ly * (TSX / 4)) * 4;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = c_win[k];
-            a += w * sm[0][ly][lx + k]; c += w * sm[1][ly][lx + k]; d += w * sm[2][ly][lx + k];
+        for (int m = 0; m < 3; ++m) {
+            float in[14];
+#pragma unroll
+            for (int k = 0; k < 14; ++k) in[k] = sm[m][ly][lx + k];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) acc += c_win[k] * in[o + k];
+                hz[m][ly][lx + o] = acc;
+            }
         }
-        hz[0][ly][lx] = a; hz[1][ly][lx] = c; hz[2][ly][lx] = d;
     }
     __syncthreads();
-    const int lx = t & 15, ly = t >> 4;
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx >= W || gy >= H) return;
-    float a = 0.f, c = 0.f, d = 0.f;
+    const int lx = t & 31, ly = (t >> 5) * 2;
+    const int gx = x0 + lx;
+    float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        const float w = c_win[k];
-        a += w * hz[0][ly + k][lx]; c += w * hz[1][ly + k][lx]; d += w * hz[2][ly + k][lx];
+    for (int r = 0; r < 12; ++r) {
+        const float v0 = hz[0][ly + r][lx], v1 = hz[1][ly + r][lx], v2 = hz[2][ly + r][lx];
+        if (r < 11) { const float w = c_win[r]; acc[0][0] += w * v0; acc[0][1] += w * v1; acc[0][2] += w * v2; }
+        if (r >= 1) { const float w = c_win[r - 1]; acc[1][0] += w * v0; acc[1][1] += w * v1; acc[1][2] += w * v2; }
     }
-    const float x = img1[b * s1.b + ch * s1.c + gy * s1.h + gx * s1.w];
-    const float y = img2[b * s2.b + ch * s2.c + gy * s2.h + gx * s2.w];
     const float sc = scale[0] * scale_mul;
-    dL_dimg1[((int64_t)plane * H + gy) * W + gx] = sc * (a + 2.0f * x * c + y * d);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int gy = y0 + ly + o;
+        if (gx < W && gy < H) {
+            const float x = img1[b * s1.b + ch * s1.c + gy * s1.h + gx * s1.w];
+            const float y = img2[b * s2.b + ch * s2.c + gy * s2.h + gx * s2.w];
+            dL_dimg1[((int64_t)plane * H + gy) * W + gx] = sc * (acc[o][0] + 2.0f * x * acc[o][1] + y * acc[o][2]);
+        }
+    }
 }
 
 }  // namespace
 
 extern "C" int64_t gsx_ssim_workspace_bytes(int64_t B, int CH, int H, int W) {
-    const int64_t blocks = B * CH * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
+    const int64_t blocks = B * CH * ((H + TSY - 1) / TSY) * ((W + TSX - 1) / TSX);
     return gsx_align256(blocks * (int64_t)sizeof(float)) + 256;
 }
 
@@ -174,7 +218,7 @@ extern "C" int gsx_ssim_fwd(const float *img1, const float *img2, int64_t B, int
         return GSX_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, (unsigned)(B * CH));
+    const dim3 grid((W + TSX - 1) / TSX, (H + TSY - 1) / TSY, (unsigned)(B * CH));
     const Strides s1{strides1[0], strides1[1], strides1[2], strides1[3]};
     const Strides s2{strides2[0], strides2[1], strides2[2], strides2[3]};
     float *partials = (float *)workspace;
@@ -193,7 +237,7 @@ extern "C" int gsx_ssim_bwd(const float *img1, const float *img2, int64_t B, int
                             float *dL_dimg1, void *stream) {
     GSX_CHECK_ARG(img1 && img2 && strides1 && strides2 && dm_dmu1 && dm_dsigma1_sq && dm_dsigma12 && scale && dL_dimg1);
     GSX_CHECK_ARG(B >= 1 && CH >= 1 && H > 0 && W > 0 && crop >= 0 && B * CH < 65536);
-    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, (unsigned)(B * CH));
+    const dim3 grid((W + TSX - 1) / TSX, (H + TSY - 1) / TSY, (unsigned)(B * CH));
     const Strides s1{strides1[0], strides1[1], strides1[2], strides1[3]};
     const Strides s2{strides2[0], strides2[1], strides2[2], strides2[3]};
     hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img1, img2, CH, H, W, s1, s2, crop,
