@@ -1,0 +1,336 @@
+"""The mapping backend behind the reference's frontend <-> backend message API (gslam/backend.py:110-899), without
+its shell (rerun / viser logging, point-cloud dumps, CLI): keyframe selection, map initialisation and growth, the
+bundle-adjustment loop, pruning, window pose refinement and the SYNC / END_SYNC payloads.
+
+Messages are the reference's tuples (gslam_amd/messages.py):
+  in : (REQUEST_INIT, Frame) | (ADD_FRAME, Frame) | None
+  out: (SYNC, keyframes, depthmap [H,W], rgbs [H,W,3], splats (no-grad clone), pose_graph) | (END_SYNC, splats, keyframes)
+
+``Backend`` is a plain object with the reference's method names; ``run()`` is the reference's loop and works on any
+pair of queues with ``get / put / empty`` (``queue.Queue`` between threads of one process - one process per GPU, the
+frontend on another HIP stream - or ``torch.multiprocessing.Queue`` between processes as in main.py:61-95).
+Everything heavy is the HIP path: renders through gslam_amd.rasterization, BA steps through mapping.BundleAdjuster,
+map surgery through the one-launch kernels of insertion.py / pruning.py."""
+from __future__ import annotations
+
+import math
+import random
+import time
+from collections import defaultdict
+from copy import deepcopy
+from dataclasses import dataclass
+from itertools import combinations
+from typing import Dict, List, Optional
+
+import torch
+
+from .insertion import InsertFromDepthMap, InsertUsingImagePlaneGradients
+from .map import GaussianSplattingData
+from .mapping import BundleAdjuster, MapConfig as _CoreConfig, optimize_poses_lbfgs
+from .messages import BackendMessage, FrontendMessage
+from .primitives import Frame, PoseZhou
+from .pruning import PruneIllConditionedGaussians, PruneLargeGaussians, PruneLowOpacity, prune_using_mask
+from .rasterization import RasterizationOutput
+from .utils import StopOnPlateau
+
+
+def add_constraint(pose_graph, kf1: int, kf2: int):
+    """gslam/pose_graph.py:6-9"""
+    pose_graph[kf1].add(kf2)
+    pose_graph[kf2].add(kf1)
+    return pose_graph
+
+
+def remove_keyframe(pose_graph, kf_id: int):
+    """gslam/pose_graph.py:12-16"""
+    del pose_graph[kf_id]
+    for kf in pose_graph:
+        pose_graph[kf].discard(kf_id)
+    return pose_graph
+
+
+@dataclass
+class MapConfig(_CoreConfig):
+    """gslam/backend.py:43-107 (the fields the loop reads; the loss / optimiser ones are inherited)."""
+    initial_opacity: float = 0.3
+    initial_scale: float = 1.0
+    optim_window_random_keyframes: int = 2
+    opacity_pruning_threshold: float = 0.2
+    size_pruning_threshold: int = 256
+    enable_pgo: bool = False
+    kf_cov: float = 0.9
+    kf_oc: float = 0.99
+    kf_m: float = 0.15
+    kf_cos: float = math.cos(math.pi / 30)
+    use_gt_depths: bool = False
+    densify_every: int = 200            # backend.py:329 (`total_step % 200`)
+    sync_every: int = 5                 # backend.py:864 (`frame.index % 5`)
+
+
+class Backend:
+    def __init__(self, conf: MapConfig, queue, frontend_queue, backend_done_event=None, global_pause_event=None):
+        self.conf = conf
+        self.queue = queue
+        self.frontend_queue = frontend_queue
+        self.backend_done_event = backend_done_event
+        self.keyframes: Dict[int, Frame] = dict()
+        self.frames: List[Frame] = []
+        self.splats = GaussianSplattingData.empty(conf.device)
+        self.pruning_opacity = PruneLowOpacity(conf.opacity_pruning_threshold)
+        self.pruning_size = PruneLargeGaussians(conf.size_pruning_threshold)
+        self.insertion_depth_map = InsertFromDepthMap(0.1 * conf.initial_scale, 0.2 * conf.initial_scale, 0.1,
+                                                      conf.initial_opacity, False, global_pause_event=global_pause_event)
+        self.insertion_3dgs = InsertUsingImagePlaneGradients(0.0002, 0.01)
+        self.pruning_conditioning = PruneIllConditionedGaussians(3)
+        self.pose_graph = defaultdict(set)
+        self.total_step = 0
+        self.pause_map_optim = False
+        self.ba: Optional[BundleAdjuster] = None
+        self.last_outputs: Optional[RasterizationOutput] = None
+        self.last_kf_depthmap = self.last_kf_rgbs = None
+
+    # ---- optimisers: the six splat Adams + the pose Adam of backend.py:565-602 are one multi-tensor FusedAdam -------
+    @property
+    def splat_optimizers(self):
+        return None if self.ba is None else self.ba.optimizers
+
+    def initialize_optimizers(self):
+        self.ba = BundleAdjuster(self.splats, self.conf)
+
+    # ---- window selection (backend.py:193-247) -----------------------------------------------------------------------
+    def optimization_window(self) -> List[Frame]:
+        conf = self.conf
+        window_size_total = conf.optim_window_last_n_keyframes + conf.optim_window_random_keyframes
+        if conf.enable_pgo:
+            latest = sorted(self.keyframes.keys())[-1]
+            window = {latest}
+            neighbors = self.pose_graph[latest]
+            if 0 < len(neighbors) < window_size_total:
+                window.update(random.sample(sorted(neighbors), min(len(neighbors), window_size_total)))
+            elif 0 < len(neighbors):
+                window.update(list(neighbors))
+            for _ in range(window_size_total - len(window)):
+                if len(neighbors) == 0:
+                    break
+                nn = self.pose_graph[random.sample(sorted(neighbors), 1)[0]]
+                if len(nn) == 0:
+                    continue
+                pick = random.sample(sorted(nn), 1)[0]
+                if pick not in window:
+                    window.add(pick)
+        else:
+            n_last = min(len(self.keyframes), conf.optim_window_last_n_keyframes)
+            window = list(self.keyframes.keys())[-n_last:]          # (the reference's random part is min(0, .) = 0)
+        return [self.keyframes[i] for i in sorted(window)]
+
+    # ---- mapping (backend.py:249-407) --------------------------------------------------------------------------------
+    def optimize_map(self, n_iters: Optional[int] = None, prune: bool = True, regularize: bool = True):
+        conf = self.conf
+        n_iters = conf.num_iters_mapping if n_iters is None else n_iters
+        early_stopper = StopOnPlateau(3, 0.012)
+        window = self.optimization_window()
+        outputs = None
+        for _ in range(n_iters):
+            self.total_step += 1
+            window = self.optimization_window()
+            # render + loss + backward ...
+            total, photometric = self.ba.render_backward(window, regularize)
+            outputs = self.ba.last_outputs
+            if (self.total_step % conf.densify_every) == 0:
+                # densification by image-plane gradients; the gradients of this iteration belong to the old rows, so
+                # this iteration's update is dropped and the loop goes on with the grown map
+                self.insertion_3dgs.step(self.splats, self.splat_optimizers, outputs, None, None)
+                self.ba.map_changed()
+                self.ba.optimizers.zero_grad()
+                prune = False
+                continue
+            # ... + Adam + opacity decay
+            self.ba.reduce()
+            self.ba.update()
+            if early_stopper.stop(photometric.item()):
+                self.pause_map_optim = True
+                break
+        if outputs is None or outputs.depthmaps.shape[0] != len(window):
+            with torch.no_grad():
+                outputs = self.splats([f.camera for f in window], [f.pose for f in window], render_depth=True)
+        for f, d in zip(window, outputs.depthmaps):
+            f.est_depths = d.detach().clone()
+        if prune:
+            self._prune(outputs, len(window) >= 2)
+        self._render_last_keyframe()
+
+    def _prune(self, outputs: RasterizationOutput, visibility_ok: bool):
+        """size / opacity (/ conditioning) pruning, backend.py:364-392 and :409-437"""
+        conf = self.conf
+        n = self.splats.means.shape[0]
+        radii = outputs.radii[:, :n]
+        remove = torch.zeros(n, dtype=torch.bool, device=self.splats.means.device)
+        if conf.enable_visibility_pruning and visibility_ok and outputs.n_touched is not None:
+            k = conf.optim_window_last_n_keyframes
+            remove |= self.pruning_conditioning.step(self.splats, self.splat_optimizers, radii[:k],
+                                                     outputs.n_touched[:k, :n])
+        remove |= self.pruning_size.step(self.splats, self.splat_optimizers, torch.max(radii, dim=0).values)
+        remove |= self.pruning_opacity.step(self.splats, self.splat_optimizers)
+        if prune_using_mask(self.splats, self.splat_optimizers, ~remove) > 0:
+            self.ba.map_changed()
+
+    def _render_last_keyframe(self):
+        last_kf = list(self.keyframes.values())[-1]
+        with torch.no_grad():
+            outputs = self.splats([last_kf.camera], [last_kf.pose], True)
+        last_kf.visible_gaussians = outputs.radii.sum(dim=0) > 0
+        self.last_outputs = outputs
+        self.last_kf_depthmap = outputs.depthmaps[0]
+        self.last_kf_rgbs = outputs.rgbs[0]
+
+    def run_pruning(self):
+        last_kf = list(self.keyframes.values())[-1]
+        with torch.no_grad():
+            outputs = self.splats([last_kf.camera], [last_kf.pose], True)
+        self._prune(outputs, len(self.keyframes) >= 2)
+        self._render_last_keyframe()
+
+    def optimize_poses_lbfgs(self):
+        return optimize_poses_lbfgs(self.splats, self.optimization_window(), self.conf)
+
+    # ---- messages out (backend.py:508-552) ---------------------------------------------------------------------------
+    def sync(self):
+        self.frontend_queue.put((BackendMessage.SYNC, deepcopy(self.keyframes), self.last_kf_depthmap.detach(),
+                                 self.last_kf_rgbs.detach(), self.splats.no_grad_clone(), deepcopy(self.pose_graph)))
+
+    def end_sync(self):
+        self.frontend_queue.put((BackendMessage.END_SYNC, self.splats.clone(), deepcopy(self.keyframes)))
+
+    # ---- map life cycle (backend.py:604-670) -------------------------------------------------------------------------
+    def initialize(self, frame: Frame):
+        conf = self.conf
+        frame = frame.to(conf.device)
+        self.frames.append(frame.strip())
+        self.keyframes[frame.index] = frame
+        self.splats = GaussianSplattingData.empty(conf.device).to(conf.device)
+        self.initialize_optimizers()
+        self.pose_graph[frame.index] = set()
+        H, W, _ = frame.img.shape
+        mock_depth = torch.ones((1, H, W), device=conf.device)
+        mock_depth = (mock_depth + (torch.randn_like(mock_depth) - 0.5) * 0.3) * conf.initial_scale
+        mock_alphas = torch.ones((1, H, W, 1), device=conf.device) * 0.01
+        mock_outputs = RasterizationOutput(None, mock_alphas, mock_depth)
+        self.insertion_depth_map.step(self.splats, self.splat_optimizers, mock_outputs, frame, 5000,
+                                      keyframes=list(self.keyframes.values()),
+                                      gt_depthmap=frame.gt_depth if conf.use_gt_depths else None)
+        self.ba.map_changed()
+        # the reference never hands the first keyframe's pose to its pose optimiser (only add_keyframe does,
+        # backend.py:665-670): it stays fixed, here by not being trainable
+        for p in frame.pose.parameters():
+            p.requires_grad_(False)
+
+    def add_keyframe(self, frame: Frame):
+        conf = self.conf
+        with torch.no_grad():
+            outputs = self.splats([frame.camera], [frame.pose], render_depth=True)
+        outputs.depthmaps = outputs.depthmaps * conf.initial_scale
+        self.insertion_depth_map.step(self.splats, self.splat_optimizers, outputs, frame, N=100,
+                                      keyframes=list(self.keyframes.values()))
+        self.ba.map_changed()
+        new_frame = Frame(img=frame.img.clone(), timestamp=frame.timestamp, camera=frame.camera.clone(),
+                          pose=PoseZhou(frame.pose().detach()).to(conf.device), gt_pose=frame.gt_pose,
+                          gt_depth=frame.gt_depth, img_file=frame.img_file, index=frame.index, est_depths=outputs.depths,
+                          exposure_params=frame.exposure_params.detach().clone().requires_grad_(False))
+        self.keyframes[new_frame.index] = new_frame
+        self.ba.optimizers.add_pose(new_frame.pose)
+        if len(self.keyframes) >= 1:
+            add_constraint(self.pose_graph, *(list(self.keyframes.keys())[-2:]))
+
+    # ---- keyframe / loop-closure tests (backend.py:672-786) ----------------------------------------------------------
+    def to_add_pg_edge(self, previous_keyframe: Frame, new_frame: Frame):
+        inter = torch.logical_and(new_frame.visible_gaussians, previous_keyframe.visible_gaussians)
+        union = torch.logical_or(new_frame.visible_gaussians, previous_keyframe.visible_gaussians)
+        return (inter.sum() / union.sum()).item() > self.conf.kf_cov
+
+    def to_remove_keyframe(self, kf_i: Frame, kf_j: Frame):
+        inter = torch.logical_and(kf_j.visible_gaussians, kf_i.visible_gaussians)
+        oc = inter.sum() / min(kf_i.visible_gaussians.sum().item(), kf_j.visible_gaussians.sum().item())
+        return oc.item() > self.conf.kf_oc, oc.item()
+
+    @torch.no_grad()
+    def add_pgo_constraints(self):
+        for kf in self.keyframes.values():
+            kf.visible_gaussians = self.splats([kf.camera], [kf.pose]).radii.sum(dim=0) > 0
+        for i, j in combinations(sorted(self.keyframes), 2):
+            if i not in self.keyframes or j not in self.keyframes or j in self.pose_graph[i]:
+                continue
+            if self.to_add_pg_edge(self.keyframes[i], self.keyframes[j]):
+                add_constraint(self.pose_graph, i, j)
+        for kf in self.keyframes.values():
+            kf.visible_gaussians = None
+
+    @torch.no_grad()
+    def to_insert_keyframe(self, previous_keyframe: Frame, new_frame: Frame):
+        outputs = self.splats([new_frame.camera, previous_keyframe.camera], [new_frame.pose, previous_keyframe.pose],
+                              render_depth=True)
+        pose_difference = torch.linalg.inv(new_frame.pose()) @ previous_keyframe.pose()
+        translation = pose_difference[:3, 3].pow(2.0).sum().pow(0.5).item()
+        seen = outputs.alphas[..., 0] > 0.1
+        median_depth = outputs.depthmaps[seen].median() if bool(seen.any()) else outputs.depthmaps.median()
+        if translation > self.conf.kf_m * median_depth:
+            return True
+        cosine_sim = torch.nn.functional.cosine_similarity(new_frame.pose()[:3, 2], previous_keyframe.pose()[:3, 2],
+                                                           dim=0)
+        return bool(cosine_sim < self.conf.kf_cos)
+
+    # ---- the loop (backend.py:818-899) -------------------------------------------------------------------------------
+    def handle(self, message) -> bool:
+        """one message of the reference's `match`; returns False on the terminating None"""
+        if message is None:
+            return False
+        tag = message[0]
+        if tag == FrontendMessage.ADD_REFINED_DEPTHMAP:
+            raise NotImplementedError()
+        if tag == FrontendMessage.ADD_FRAME:
+            frame = deepcopy(message[1])
+            self.frames.append(frame.strip())
+            if len(self.keyframes) == 0:
+                self.initialize(frame)
+                return True
+            last_keyframe = self.keyframes[sorted(self.keyframes.keys())[-1]]
+            if self.to_insert_keyframe(last_keyframe, frame):
+                self.pause_map_optim = False
+                self.add_keyframe(frame)
+                self.optimize_map(1, prune=True, regularize=False)
+                if self.conf.enable_pgo:
+                    self.add_pgo_constraints()
+            if frame.index % self.conf.sync_every == 0:
+                self.sync()
+            return True
+        if tag == FrontendMessage.REQUEST_INIT:
+            frame = deepcopy(message[1])
+            self.frames.append(frame.strip())
+            self.pause_map_optim = False
+            self.initialize(frame)
+            self.optimize_map(self.conf.num_iters_initialization, False, True)
+            self.sync()
+            return True
+        return True                                              # unknown message: ignored like the reference (logged there)
+
+    def idle_step(self):
+        """what the reference does while its queue is empty (backend.py:836-844)"""
+        if self.pause_map_optim or len(self.keyframes) == 0:
+            return False
+        self.optimize_map()
+        if len(self.keyframes) > 1:
+            self.run_pruning()
+            self.optimize_poses_lbfgs()
+        return True
+
+    def run(self):
+        self.pause_map_optim = False
+        while True:
+            if self.queue.empty():
+                if not self.idle_step():
+                    time.sleep(0.03)
+                    continue
+            if not self.handle(self.queue.get()):
+                break
+        self.end_sync()
+        if self.backend_done_event is not None:
+            self.backend_done_event.set()

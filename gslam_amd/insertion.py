@@ -37,6 +37,11 @@ class InsertionStrategy(ABC):
         N = int(new_params['means'].shape[0])
         if N == 0:
             return 0
+        if splats.means.shape[0] == 0:
+            # first insertion into GaussianSplattingData.empty() (backend.py:604-637): the new rows ARE the map
+            new_values = {name: new_params[name].detach().to(p.dtype).clone() for name, p in splats.named_parameters()}
+            _rebuild(splats, optimizers, new_values, {})
+            return N
         a, b, slots = [], [], []
         for name, p in splats.named_parameters():
             a.append(p.data)

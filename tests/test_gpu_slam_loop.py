@@ -1,0 +1,96 @@
+"""The frontend / backend pair behind the reference's message API (gslam/frontend.py, gslam/backend.py) on a synthetic
+TUM-shape sequence: REQUEST_INIT -> SYNC -> tracked frames (ADD_FRAME) -> keyframes, BA, pruning, SYNC -> None ->
+END_SYNC.  Driven in lockstep in one thread through Backend.handle / idle_step (the same code Backend.run loops over).
+Run with -m gpu."""
+import queue
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_slam_loop_messages_and_tracking(dev):
+    from gslam_amd.backend import Backend, MapConfig
+    from gslam_amd.frontend import Frontend
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.messages import BackendMessage, FrontendMessage
+    from gslam_amd.primitives import Camera, Frame, PoseZhou
+    from gslam_amd.synthetic import make_intrinsics, make_scene, make_viewmat
+    from gslam_amd.tracking import TrackingConfig
+    torch.manual_seed(0)
+    W, H = 320, 240
+    K = make_intrinsics(W, H).to(dev)
+    cam = Camera(K, H, W)
+    sc = make_scene(30000, 3)
+    sc["scales"] = sc["scales"] + 0.6
+    world = GaussianSplattingData.from_dict(sc, dev)
+
+    def sensor_frame(i):
+        V = make_viewmat(i).to(dev)
+        V[:3, 3] *= 0.5                                    # gentle motion: 2.5 cm and 1 degree per frame
+        with torch.no_grad():
+            img = world([cam], [PoseZhou(V, is_learnable=False).to(dev)], render_depth=False).rgbs[0].clamp(0, 1)
+        return Frame(img=img.contiguous(), timestamp=i / 30.0, camera=cam, pose=None, gt_pose=V, index=i)
+
+    to_backend, to_frontend, sensor = queue.Queue(), queue.Queue(), queue.Queue()
+    conf = MapConfig(num_iters_initialization=60, num_iters_mapping=5, kf_m=0.02)
+    be = Backend(conf, to_backend, to_frontend)
+    fe = Frontend(TrackingConfig(), to_backend, to_frontend, sensor)
+
+    def pump_backend():
+        while not to_backend.empty():
+            assert be.handle(to_backend.get())
+        while not to_frontend.empty():
+            fe.handle_message_from_backend(to_frontend.get())
+
+    # frame 0: REQUEST_INIT -> the backend initialises a 5000-splat map from the mock depth map and SYNCs
+    fe.track(sensor_frame(0).to(dev))
+    assert fe.waiting_for_sync and to_backend.qsize() == 1
+    msg = to_backend.queue[0]
+    assert msg[0] == FrontendMessage.REQUEST_INIT and str(msg[0]) == "request_init"
+    pump_backend()
+    assert not fe.waiting_for_sync and fe.splats is not None and 0 in fe.keyframes
+    n_init = be.splats.means.shape[0]
+    assert 2000 < n_init <= 5000 and be.splats.ages.dtype == torch.int64
+    assert fe.splats.means.shape[0] == n_init and not fe.splats.means.requires_grad
+
+    # frames 1..12: tracked against the frontend's copy, shipped with ADD_FRAME; the backend adds keyframes, maps, syncs
+    n_sync = 0
+    for i in range(1, 13):
+        fe.track(sensor_frame(i).to(dev))
+        assert to_backend.queue[-1][0] == FrontendMessage.ADD_FRAME
+        before = to_frontend.qsize()
+        while not to_backend.empty():
+            assert be.handle(to_backend.get())
+        n_sync += to_frontend.qsize() - before
+        be.idle_step()
+        while not to_frontend.empty():
+            m = to_frontend.get()
+            assert m[0] == BackendMessage.SYNC and len(m) == 6
+            fe.handle_message_from_backend(m)
+    torch.cuda.synchronize()
+    assert n_sync >= 2                                      # frame.index % 5 == 0 (backend.py:864)
+    assert len(be.keyframes) >= 3 and len(fe.frames) == 13
+    assert all(k in be.pose_graph for k in be.keyframes)
+    assert all(torch.isfinite(torch.tensor(l)) for l in fe.last_losses)
+    # the map was optimised and pruned in place: still a consistent set of per-Gaussian arrays + Adam state
+    n = be.splats.means.shape[0]
+    for name, p in be.splats.named_parameters():
+        assert p.shape[0] == n, name
+    st = be.ba.optimizers.splat_opt.state[be.splats.means]
+    assert st["exp_avg"].shape[0] == n
+    # end of stream: None -> END_SYNC with the final map
+    to_backend.put(None)
+    assert not be.handle(to_backend.get())
+    be.end_sync()
+    m = to_frontend.get()
+    assert m[0] == BackendMessage.END_SYNC and len(m) == 3
+    fe.handle_message_from_backend(m)
+    assert fe.done and fe.splats.means.shape[0] == n
