@@ -323,14 +323,19 @@ class Backend:
         return True
 
     def run(self):
+        from ._sync import capture_lock
         self.pause_map_optim = False
         while True:
             if self.queue.empty():
-                if not self.idle_step():
+                with capture_lock:
+                    busy = self.idle_step()
+                if not busy:
                     time.sleep(0.03)
                     continue
-            if not self.handle(self.queue.get()):
-                break
+            message = self.queue.get()
+            with capture_lock:
+                if not self.handle(message):
+                    break
         self.end_sync()
         if self.backend_done_event is not None:
             self.backend_done_event.set()

@@ -164,32 +164,42 @@ def _packed_backgrounds(backgrounds: Optional[Tensor], C: int, with_depth: bool,
     return bg
 
 
-def _pool(dev) -> _IsectPool:
-    key = torch.device(dev).index
+def _pool(dev, sig=None) -> _IsectPool:
+    """one capacity manager per (device, problem shape (N, C, W, H)): a tracker (C = 1) and a bundle adjuster (C = 8) of
+    one process - possibly on two threads / streams - do not re-probe or overflow each other's buffers"""
+    key = (torch.device(dev).index, sig)
     p = _POOLS.get(key)
     if p is None:
+        if len(_POOLS) >= 64:                          # maps that keep changing size: forget the oldest shapes
+            for k in list(_POOLS.keys())[:32]:
+                if _POOLS[k]._graph_M is None:
+                    del _POOLS[k]
         p = _IsectPool(dev)
+        p.signature = sig
         _POOLS[key] = p
     return p
 
 
-def validate(device=None) -> bool:
+def validate(device=None, signature=None) -> bool:
     """Blocks until the last render's intersection count has arrived and returns True iff no sync-free render since
     the previous call overflowed its buffers.  On False the caller should re-run the affected iteration (the capacity
-    has already been grown)."""
+    has already been grown).  ``signature`` = (N, C, W, H) restricts the check to the renders of that shape."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    p = _pool(dev)
-    p.poll(block=True)
-    if p._graph_M is not None:                      # renders replayed from a HIP graph: status is sticky on the device
-        st = int(p.status.item())
-        p.last_M = int(p._graph_M.item())
-        if st & 1:
-            p.overflowed = True
-            p.capacity = int(p.last_M * p.GROW) + 4096
-            p.status.zero_()
-            p._graph_M = None                       # the captured graph is stale (capacity baked in): re-capture
-    bad = p.overflowed
-    p.overflowed = False
+    bad = False
+    for (di, sig_), p in list(_POOLS.items()):
+        if di != dev.index or (signature is not None and sig_ != tuple(signature)):
+            continue
+        p.poll(block=True)
+        if p._graph_M is not None:                  # renders replayed from a HIP graph: status is sticky on the device
+            st = int(p.status.item())
+            p.last_M = int(p._graph_M.item())
+            if st & 1:
+                p.overflowed = True
+                p.capacity = int(p.last_M * p.GROW) + 4096
+                p.status.zero_()
+                p._graph_M = None                   # the captured graph is stale (capacity baked in): re-capture
+        bad = bad or p.overflowed
+        p.overflowed = False
     return not bad
 
 
@@ -283,12 +293,12 @@ def rasterization(
         isect_offsets = ops.isect_offset_encode(isect_ids, C, tile_width, tile_height)
         raster_offsets, has_end = isect_offsets, False
     else:
-        pool = _pool(dev)
+        sig = (N, C, int(width), int(height))
+        pool = _pool(dev, sig)
         capturing = torch.cuda.is_current_stream_capturing()
         if not capturing:
             pool.poll()
-        sig = (N, C, int(width), int(height))
-        if pool.capacity == 0 or pool.signature != sig:
+        if pool.capacity == 0:
             # a new problem shape (first render, map grown / pruned, other resolution or window size): size the buffers
             # with ONE synchronous probe; between probes M only drifts with the poses and is tracked asynchronously
             if capturing:

@@ -179,18 +179,29 @@ class GraphedTracker:
             self.exposure.copy_(frame.exposure_params if prev_exposure is None else prev_exposure)
 
     def capture(self):
+        from ._sync import capture_lock
+        with capture_lock:
+            self._capture()
+
+    def _capture(self):
         # warm-up and capture run on the SAME side stream: autograd pins each leaf's AccumulateGrad node to the stream
         # it was first used on, and a capture on another stream would push the accumulation out of the graph
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        sig = (int(self.splats.means.shape[0]), 1, int(self.camera.width), int(self.camera.height))
         with torch.cuda.stream(side):
-            for _ in range(2):
-                self._closure_body()
-            assert self._validate(), "intersection capacity changed during warm-up; capture again"
+            for attempt in range(4):                    # a warm-up render that overflowed has grown the capacity
+                for _ in range(2):
+                    self._closure_body()
+                if self._validate(signature=sig):
+                    break
+            else:
+                raise RuntimeError("intersection capacity keeps changing during warm-up")
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
+        # thread_local: a backend thread of the same process may be allocating / synchronising on its own stream
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             self.loss = self._closure_body(advance=self.device_optimizer)
 
     def closure(self):

@@ -60,9 +60,9 @@ def test_graph_replays_are_idempotent(dev):
         l = tr.closure()
         torch.cuda.synchronize()
         vals.append((float(l), [g.clone() for g in (p.grad for p in tr.params)]))
-    assert R.validate(dev)
-    pool = R._pool(dev)
-    assert int(pool.status.item()) == 0
+    sig = (int(m.means.shape[0]), 1, cam.width, cam.height)
+    assert R.validate(dev, signature=sig)
+    assert int(R._pool(dev, sig).status.item()) == 0
     for v, gs in vals[1:]:
         assert abs(v - vals[0][0]) <= 1e-6 * max(1.0, abs(vals[0][0]))
         for a, b in zip(gs, vals[0][1]):
