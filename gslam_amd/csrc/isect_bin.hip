@@ -19,6 +19,8 @@
 //   4. tile_sort     : one workgroup per tile: merge sort by ranks (64-key rank-sorted runs, then log2(n/64) stable
 //                      rank-merge levels with binary searches) in an LDS window of up to 8192 keys; larger tiles
 //                      continue the merge levels in global memory; writes flatten_ids / isect_ids
+#include <stdlib.h>
+
 #include "gsx_common.h"
 
 namespace {
@@ -320,6 +322,122 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long l
     }
 }
 
+// ---- 4b. per-tile sort by counting (tiles of up to 2048 keys) ---------------------------------------------------------
+// The merge sort above is a chain of ~40 dependent LDS reads per key (binary searches); depth keys inside one tile are
+// spread over a narrow range, so a counting sort gets there with two LDS atomics per key and no search:
+//   1. min / max depth of the tile (block reduction) -> monotone map depth -> bucket in [0, NB)
+//   2. histogram (ds_add), exclusive scan over the NB buckets, scatter (returning ds_add) -> keys grouped by bucket
+//   3. exact rank inside the bucket by counting smaller (depth, id) keys among the bucket's members (1-2 on average)
+// The map is monotone in the float depth (subtract, multiply and float->int conversion are all monotone), so bucket
+// order never contradicts key order and step 3 makes the result the same total order the merge sort produces.  A tile
+// whose keys pile up in one bucket (same depth everywhere) falls back to the merge sort.
+constexpr int CNT_NB = 1024;          // buckets
+constexpr int CNT_MAXN = 2048;        // keys
+constexpr int CNT_MAX_BUCKET = 96;    // largest bucket the quadratic step 3 accepts
+
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned long long *__restrict__ entries,
+                                                                       const int32_t *__restrict__ offsets, int n_tiles,
+                                                                       int tile_n_bits, int64_t M_cap, uint32_t id_max,
+                                                                       int64_t *__restrict__ isect_ids,
+                                                                       int32_t *__restrict__ flatten_ids) {
+    __shared__ __attribute__((aligned(16))) unsigned long long s_a[CNT_MAXN];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_b[CNT_MAXN];
+    __shared__ int s_start[CNT_NB + 1];
+    __shared__ int s_cur[CNT_NB];
+    __shared__ unsigned int s_red[2 * (SORT_THREADS / 64)];
+    __shared__ int s_flag;
+    const int tile = blockIdx.x;
+    const int t = threadIdx.x;
+    const int64_t start = max((int64_t)0, min((int64_t)offsets[tile], M_cap));
+    const int64_t end = max((int64_t)0, min((int64_t)offsets[tile + 1], M_cap));
+    const int n = (int)(end - start);
+    if (n <= 0 || n > CNT_MAXN) return;                      // larger tiles: the merge-sort launch
+    const int c = tile / n_tiles, tl = tile - c * n_tiles;
+    const long long hi_part = ((long long)c << (32 + tile_n_bits)) | ((long long)tl << 32);
+    unsigned long long *seg = entries + start;
+    // 1. load + min / max of the depth bits (positive floats: same order as the values)
+    unsigned int dmin = 0xffffffffu, dmax = 0u;
+    for (int i = t; i < n; i += SORT_THREADS) {
+        const unsigned long long k = seg[i];
+        s_a[i] = k;
+        const unsigned int d = (unsigned int)(k >> 32);
+        dmin = min(dmin, d); dmax = max(dmax, d);
+    }
+    for (int i = t; i < CNT_NB; i += SORT_THREADS) s_cur[i] = 0;
+    if (t == 0) s_flag = 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dmin = min(dmin, (unsigned int)__shfl_xor((int)dmin, off, 64));
+        dmax = max(dmax, (unsigned int)__shfl_xor((int)dmax, off, 64));
+    }
+    if ((t & 63) == 0) { s_red[t >> 6] = dmin; s_red[SORT_THREADS / 64 + (t >> 6)] = dmax; }
+    __syncthreads();
+    dmin = 0xffffffffu; dmax = 0u;
+#pragma unroll
+    for (int w = 0; w < SORT_THREADS / 64; ++w) { dmin = min(dmin, s_red[w]); dmax = max(dmax, s_red[SORT_THREADS / 64 + w]); }
+    const float fmin_ = __uint_as_float(dmin), fmax_ = __uint_as_float(dmax);
+    const float range = fmax_ - fmin_;
+    const float scale = (range > 0.0f) ? (float)(CNT_NB - 1) / range : 0.0f;
+    auto bucket_of = [&](unsigned long long k) -> int {
+        const float d = __uint_as_float((unsigned int)(k >> 32));
+        const int b = (int)((d - fmin_) * scale);
+        return min(max(b, 0), CNT_NB - 1);
+    };
+    // 2. histogram
+    for (int i = t; i < n; i += SORT_THREADS) atomicAdd(&s_cur[bucket_of(s_a[i])], 1);
+    __syncthreads();
+    // exclusive scan of the NB counts: 2 buckets per thread + wave scan + wave totals
+    {
+        const int b0 = 2 * t;
+        const int c0 = (b0 < CNT_NB) ? s_cur[b0] : 0, c1 = (b0 + 1 < CNT_NB) ? s_cur[b0 + 1] : 0;
+        if (max(c0, c1) > CNT_MAX_BUCKET) s_flag = 1;        // benign race: any writer sets the same value
+        int v = c0 + c1;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(incl, off, 64);
+            if ((t & 63) >= off) incl += u;
+        }
+        __shared__ int s_wtot[SORT_THREADS / 64];
+        if ((t & 63) == 63) s_wtot[t >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (t >> 6); ++w) base += s_wtot[w];
+        const int excl = base + incl - v;
+        if (b0 < CNT_NB) { s_start[b0] = excl; s_cur[b0] = excl; }
+        if (b0 + 1 < CNT_NB) { s_start[b0 + 1] = excl + c0; s_cur[b0 + 1] = excl + c0; }
+        if (t == 0) s_start[CNT_NB] = n;
+    }
+    __syncthreads();
+    if (s_flag) {                                            // degenerate depth distribution: merge sort in the same LDS
+        const unsigned long long *sorted = lds_sort(seg, n, s_a, s_b);
+        for (int i = t; i < n; i += SORT_THREADS) {
+            const unsigned long long k = sorted[i];
+            flatten_ids[start + i] = (int32_t)min((uint32_t)k, id_max);
+            if (isect_ids) isect_ids[start + i] = hi_part | (long long)(k >> 32);
+        }
+        return;
+    }
+    // scatter into buckets
+    for (int i = t; i < n; i += SORT_THREADS) {
+        const unsigned long long k = s_a[i];
+        const int pos = atomicAdd(&s_cur[bucket_of(k)], 1);
+        s_b[pos] = k;
+    }
+    __syncthreads();
+    // 3. exact position inside the bucket, and out
+    for (int i = t; i < n; i += SORT_THREADS) {
+        const unsigned long long k = s_b[i];
+        const int b = bucket_of(k);
+        const int bs = s_start[b], be = s_start[b + 1];
+        int rank = 0;
+        for (int j = bs; j < be; ++j) rank += (s_b[j] < k) ? 1 : 0;
+        const int64_t o = start + bs + rank;
+        flatten_ids[o] = (int32_t)min((uint32_t)k, id_max);
+        if (isect_ids) isect_ids[o] = hi_part | (long long)(k >> 32);
+    }
+}
+
 int bit_length(uint32_t v) {
     int n = 0;
     while (v) { ++n; v >>= 1; }
@@ -394,9 +512,14 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
         const int small_cap = 2048, big_cap = 8192;
         const uint32_t id_max = (uint32_t)(C * N - 1);
         const int tnb = bit_length((uint32_t)n_tiles);
-        hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), (size_t)(2 * small_cap * 8), st,
-                           entries, scratch, offsets, (int)n_tiles, tnb, M_cap, small_cap, 0, small_cap, id_max,
-                           isect_ids, flatten_ids);
+        const char *ts = getenv("GSX_TILE_SORT");
+        if (ts && ts[0] == 'm')                              // A/B: the merge sort for the small class as well
+            hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), (size_t)(2 * small_cap * 8), st,
+                               entries, scratch, offsets, (int)n_tiles, tnb, M_cap, small_cap, 0, small_cap, id_max,
+                               isect_ids, flatten_ids);
+        else
+            hipLaunchKernelGGL(tile_sort_count_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, offsets,
+                               (int)n_tiles, tnb, M_cap, id_max, isect_ids, flatten_ids);
         GSX_CHECK_LAUNCH();
         if (M_cap > small_cap) {
             const size_t lds_bytes = (size_t)(2 * big_cap * 8);     // 128 KiB of the CU's 160 KiB
