@@ -10,15 +10,19 @@
 // reference's isect_tiles is gone).  HBM traffic per intersection: 8 B written + 8 B read + 4 B written (+8 B if
 // isect_ids are materialised) against >= 24 B x 6 digit passes for the 44-47 live key bits of the global sort.
 //
-//   1. tile_diff     : each Gaussian adds +-1 at the 4 corners of its tile rectangle in an LDS 2-D difference grid
-//                      (O(1) per Gaussian whatever its size), flushed with coalesced int atomics
-//   2. tile_offsets  : 2-D prefix sum -> per-tile counts -> exclusive scan -> offsets[T+1], cursors, M (one block)
-//   3. emit_binned   : per workgroup: LDS per-tile counts, ONE global atomic per touched tile to reserve a range,
-//                      LDS cursors to place 8-byte entries (depth_bits<<32 | flatten_id); rectangles larger than 16
-//                      tiles are walked cooperatively by the whole wavefront
-//   4. tile_sort     : one workgroup per tile: merge sort by ranks (64-key rank-sorted runs, then log2(n/64) stable
-//                      rank-merge levels with binary searches) in an LDS window of up to 8192 keys; larger tiles
-//                      continue the merge levels in global memory; writes flatten_ids / isect_ids
+//   1. count_matrix  : per workgroup (1024+ Gaussians): per-tile counts in LDS -> one row of a [workgroups][tiles]
+//                      matrix (rectangles larger than 16 tiles are walked cooperatively by the whole wavefront)
+//   2. column_scan   : one thread per tile: exclusive scan down the workgroup dimension (each workgroup's base inside
+//                      the tile) and the tile's total; tile_scan: exclusive scan of the totals -> offsets[T+1], M
+//   3. place         : LDS cursors start at offsets[tile] + base[workgroup][tile]; 8-byte entries
+//                      (depth_bits<<32 | flatten_id) go straight to their tile's range.  No global atomic anywhere
+//                      (the first version reserved ranges with one contended atomic per ~3 entries and needed a
+//                      difference-grid pass for the totals; kept behind GSX_BIN_ATOMIC=1 for A/B runs).  What bounds
+//                      this step now is the 8-byte granularity of the scattered stores.
+//   4. tile_sort     : one workgroup per tile.  Tiles of up to 2048 keys: counting sort on a monotone depth -> bucket
+//                      map plus an exact in-bucket rank (two LDS atomics per key, no search).  Larger tiles (and
+//                      degenerate depth distributions): merge sort by ranks in an LDS window of up to 8192 keys,
+//                      continued through global memory beyond that.  Writes flatten_ids / isect_ids
 #include <stdlib.h>
 
 #include "gsx_common.h"
@@ -175,6 +179,111 @@ __device__ __forceinline__ void walk_rects(const Rect &r, int tile_w, unsigned i
             const int yy = k / bw, xx = k - yy * bw;
             op((by0 + yy) * tile_w + bx0 + xx, blo, bhi);
         }
+    }
+}
+
+// ---- 3b. binning without global atomics --------------------------------------------------------------------------
+// emit_binned_kernel reserves a range per (workgroup, touched tile) with a global atomic; a workgroup of 1024 random
+// Gaussians touches most tiles with ~3 entries each, so that is one contended atomic per ~3 entries (3.5 M atomics on
+// 9600 addresses at 500 k x 8 cameras: 188 us, the largest kernel of the sort).  Here the per-(workgroup, tile) counts
+// go to a matrix instead, a column scan turns them into each workgroup's base inside every tile and into the per-tile
+// totals (which makes the difference-grid pass unnecessary), and the placement pass starts its LDS cursors from
+// offsets[tile] + base[workgroup][tile]: plain coalesced stores and loads, no global atomic anywhere.
+constexpr int GB_MAX = 640;           // workgroups per camera (the matrix in the workspace is sized for this)
+
+__global__ __launch_bounds__(BIN_THREADS) void count_matrix_kernel(const float *__restrict__ means2d,
+                                                                   const int32_t *__restrict__ radii, int64_t N,
+                                                                   int tile_w, int tile_h, int items,
+                                                                   int32_t *__restrict__ cnt /*[C][gblocks][n_tiles]*/) {
+    extern __shared__ int s_cnt[];  // [n_tiles]
+    const int c = blockIdx.y;
+    const int n_tiles = tile_w * tile_h;
+    for (int i = threadIdx.x; i < n_tiles; i += BIN_THREADS) s_cnt[i] = 0;
+    __syncthreads();
+    for (int it = 0; it < items; ++it) {
+        const int64_t g = ((int64_t)blockIdx.x * items + it) * BIN_THREADS + threadIdx.x;
+        const Rect r = load_rect(means2d, radii, (int64_t)c * N + g, tile_w, tile_h, g < N);
+        walk_rects(r, tile_w, 0u, 0u, [&](int tile, unsigned int, unsigned int) { atomicAdd(&s_cnt[tile], 1); });
+    }
+    __syncthreads();
+    int32_t *row = cnt + ((int64_t)c * gridDim.x + blockIdx.x) * n_tiles;
+    for (int i = threadIdx.x; i < n_tiles; i += BIN_THREADS) row[i] = s_cnt[i];
+}
+
+// one thread per (camera, tile): exclusive scan down the workgroup dimension (in place), total into counts[]
+__global__ __launch_bounds__(256) void column_scan_kernel(int32_t *__restrict__ cnt, int gblocks, int n_tiles, int T,
+                                                          int32_t *__restrict__ counts /*[T]*/) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T) return;
+    const int c = i / n_tiles, tl = i - c * n_tiles;
+    int32_t *col = cnt + (int64_t)c * gblocks * n_tiles + tl;
+    int run = 0;
+    int b = 0;
+    for (; b + 8 <= gblocks; b += 8) {      // eight loads in flight per trip
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(b + u) * n_tiles];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { col[(int64_t)(b + u) * n_tiles] = run; run += v[u]; }
+    }
+    for (; b < gblocks; ++b) { const int v = col[(int64_t)b * n_tiles]; col[(int64_t)b * n_tiles] = run; run += v; }
+    counts[i] = run;
+}
+
+// exclusive scan of the T per-tile counts held in offsets[] -> offsets[T+1], M, overflow status (one workgroup)
+__global__ __launch_bounds__(1024) void tile_scan_kernel(int T, int64_t M_cap, int32_t *__restrict__ offsets,
+                                                         int64_t *__restrict__ M_dev, int32_t *__restrict__ status) {
+    __shared__ long long s_scan[1024];
+    const int t = threadIdx.x;
+    const int per = (T + 1023) / 1024;
+    const int lo = min(T, t * per), hi = min(T, lo + per);
+    long long sum = 0;
+    for (int i = lo; i < hi; ++i) sum += max(offsets[i], 0);
+    s_scan[t] = sum;
+    for (int off = 1; off < 1024; off <<= 1) {
+        __syncthreads();
+        const long long add = (t >= off) ? s_scan[t - off] : 0;
+        __syncthreads();
+        s_scan[t] += add;
+    }
+    __syncthreads();
+    long long run = s_scan[t] - sum;
+    const long long total = s_scan[1023];
+    for (int i = lo; i < hi; ++i) {
+        const int cnt = max(offsets[i], 0);
+        offsets[i] = (int32_t)min(run, (long long)0x7fffffff);
+        run += cnt;
+    }
+    if (t == 0) {
+        offsets[T] = (int32_t)min(total, (long long)0x7fffffff);
+        M_dev[0] = total;
+        if (total > M_cap || total > 0x7fffffffLL) atomicOr(status, 1);
+    }
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void place_kernel(const float *__restrict__ means2d,
+                                                            const int32_t *__restrict__ radii,
+                                                            const float *__restrict__ depths, int64_t N, int tile_w,
+                                                            int tile_h, int items, int64_t M_cap,
+                                                            const int32_t *__restrict__ offsets,
+                                                            const int32_t *__restrict__ cnt,
+                                                            unsigned long long *__restrict__ entries) {
+    extern __shared__ int s_cur[];  // [n_tiles]: this workgroup's absolute write cursor per tile
+    const int c = blockIdx.y;
+    const int n_tiles = tile_w * tile_h;
+    const int32_t *row = cnt + ((int64_t)c * gridDim.x + blockIdx.x) * n_tiles;
+    for (int i = threadIdx.x; i < n_tiles; i += BIN_THREADS) s_cur[i] = offsets[(int64_t)c * n_tiles + i] + row[i];
+    __syncthreads();
+    for (int it = 0; it < items; ++it) {
+        const int64_t g = ((int64_t)blockIdx.x * items + it) * BIN_THREADS + threadIdx.x;
+        const int64_t idx = (int64_t)c * N + g;
+        const Rect r = load_rect(means2d, radii, idx, tile_w, tile_h, g < N);
+        const bool has = (r.x1 > r.x0) && (r.y1 > r.y0);
+        const unsigned int klo = (unsigned int)idx, khi = has ? __float_as_uint(depths[idx]) : 0u;
+        walk_rects(r, tile_w, klo, khi, [&](int tile, unsigned int lo, unsigned int hi) {
+            const int pos = atomicAdd(&s_cur[tile], 1);
+            if ((uint64_t)(uint32_t)pos < (uint64_t)M_cap) entries[pos] = ((unsigned long long)hi << 32) | lo;
+        });
     }
 }
 
@@ -445,7 +554,7 @@ int bit_length(uint32_t v) {
 }
 
 struct BinLayout {
-    int64_t diff_off, cursor_off, entries_off, scratch_off, total;
+    int64_t diff_off, cursor_off, entries_off, scratch_off, matrix_off, total;
 };
 
 BinLayout bin_layout(int64_t C, int tile_w, int tile_h, int64_t M_cap) {
@@ -456,7 +565,8 @@ BinLayout bin_layout(int64_t C, int tile_w, int tile_h, int64_t M_cap) {
     L.cursor_off = gsx_align256(C * G * 4);
     L.entries_off = L.cursor_off + gsx_align256(T * 4);
     L.scratch_off = L.entries_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);
-    L.total = L.scratch_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8) + 256;
+    L.matrix_off = L.scratch_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);
+    L.total = L.matrix_off + gsx_align256(T * (int64_t)GB_MAX * 4) + 256;     // [C][<= GB_MAX workgroups][tiles] counts
     return L;
 }
 
@@ -490,20 +600,54 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
     int32_t *cursor = (int32_t *)(ws + L.cursor_off);
     unsigned long long *entries = (unsigned long long *)(ws + L.entries_off);
     unsigned long long *scratch = (unsigned long long *)(ws + L.scratch_off);
-    if (!gsx_zero_async(diff, C * G, st)) return GSX_E_LAUNCH;
-    const unsigned gblocks = (unsigned)((N + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
-    if (N > 0) {
-        hipLaunchKernelGGL(tile_diff_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(G * 4), st, means2d,
-                           radii, N, tile_w, tile_h, diff);
+    const char *bm = getenv("GSX_BIN_ATOMIC");
+    if (bm && bm[0] == '1') {                       // A/B: the difference grid + global-atomic binning
+        if (!gsx_zero_async(diff, C * G, st)) return GSX_E_LAUNCH;
+        const unsigned gblocks = (unsigned)((N + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
+        if (N > 0) {
+            hipLaunchKernelGGL(tile_diff_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(G * 4), st,
+                               means2d, radii, N, tile_w, tile_h, diff);
+            GSX_CHECK_LAUNCH();
+        }
+        hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), (size_t)(G * 4), st, diff, (int)C, tile_w, tile_h,
+                           M_cap, offsets, cursor, M_dev, status);
         GSX_CHECK_LAUNCH();
+        if (N > 0 && M_cap > 0) {
+            hipLaunchKernelGGL(emit_binned_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4),
+                               st, means2d, radii, depths, N, tile_w, tile_h, M_cap, cursor, entries);
+            GSX_CHECK_LAUNCH();
+        }
+    } else {
+        // count matrix -> column scan -> tile scan -> placement; the Gaussians of a workgroup grow with N so that the
+        // matrix never has more than GB_MAX rows per camera
+        int32_t *cnt = (int32_t *)(ws + L.matrix_off);
+        int64_t items = BIN_ITEMS;
+        while ((N + BIN_THREADS * items - 1) / (BIN_THREADS * items) > GB_MAX) items *= 2;
+        // fatter workgroups while the grid still covers the chip twice: the 8-byte entries of a workgroup land in
+        // longer runs per tile, which the L2 merges into fuller lines before they go out to HBM
+        const char *bi = getenv("GSX_BIN_ITEMS");
+        if (bi) items = atoi(bi) > 0 ? atoi(bi) : items;
+        else while (items < 32 && C * ((N + BIN_THREADS * items * 2 - 1) / (BIN_THREADS * items * 2)) >= 512) items *= 2;
+        const unsigned gblocks = (unsigned)((N + BIN_THREADS * items - 1) / (BIN_THREADS * items));
+        if (N > 0) {
+            hipLaunchKernelGGL(count_matrix_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4),
+                               st, means2d, radii, N, tile_w, tile_h, (int)items, cnt);
+            GSX_CHECK_LAUNCH();
+            hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, cnt, (int)gblocks,
+                               (int)n_tiles, (int)T, offsets);
+            GSX_CHECK_LAUNCH();
+        } else {
+            if (!gsx_zero_async(offsets, T, st)) return GSX_E_LAUNCH;
+        }
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, (int)T, M_cap, offsets, M_dev, status);
+        GSX_CHECK_LAUNCH();
+        if (N > 0 && M_cap > 0) {
+            hipLaunchKernelGGL(place_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4), st,
+                               means2d, radii, depths, N, tile_w, tile_h, (int)items, M_cap, offsets, cnt, entries);
+            GSX_CHECK_LAUNCH();
+        }
     }
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), (size_t)(G * 4), st, diff, (int)C, tile_w, tile_h, M_cap,
-                       offsets, cursor, M_dev, status);
-    GSX_CHECK_LAUNCH();
     if (N > 0 && M_cap > 0) {
-        hipLaunchKernelGGL(emit_binned_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4), st,
-                           means2d, radii, depths, N, tile_w, tile_h, M_cap, cursor, entries);
-        GSX_CHECK_LAUNCH();
         // Tile sizes are only known on the device (sync-free), so the sort runs as up to two launches over all tiles,
         // each taking one size class and leaving the rest (an early exit): tiles of up to 2048 keys sort in a 32 KiB
         // LDS window at full occupancy (4 workgroups of 8 wavefronts per CU); larger tiles get an 8192-key window
