@@ -395,10 +395,12 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long l
                                                                  const int32_t *__restrict__ offsets, int n_tiles,
                                                                  int tile_n_bits, int64_t M_cap, int cap,
                                                                  int n_lo, int n_hi, uint32_t id_max,
+                                                                 const int32_t *__restrict__ only_flagged,
                                                                  int64_t *__restrict__ isect_ids,
                                                                  int32_t *__restrict__ flatten_ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
     const int tile = blockIdx.x;
+    if (only_flagged && only_flagged[tile] == 0) return;    // the counting sort already did this tile
     const int64_t start = max((int64_t)0, min((int64_t)offsets[tile], M_cap));
     const int64_t end = max((int64_t)0, min((int64_t)offsets[tile + 1], M_cap));
     const int n = (int)(end - start);
@@ -547,6 +549,128 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
     }
 }
 
+// ---- 4c. counting sort for tiles of more than 2048 keys ---------------------------------------------------------------
+// Same three steps, with the keys streamed from global memory (L2) instead of staged in LDS, so that the tile size is
+// unbounded and the LDS footprint stays at 48 KiB (3 workgroups per CU):
+//   1. min / max depth, 2. histogram over 4096 buckets + scan, scatter into the scratch copy grouped by bucket,
+//   3. the grouped keys come back through a 2048-key LDS window cut at bucket boundaries; exact rank inside the bucket.
+// Every pass is a coalesced stream over the tile's keys; the merge sort it replaces walked log2(n / 8192) levels of
+// dependent binary searches through L2 (6.1 ms of a 13 ms render at 5M Gaussians / 1080p).  A tile with a bucket of
+// more than BIG_MAX_BUCKET keys is flagged and left to the merge-sort launch that follows.
+constexpr int BIG_NB = 4096;
+constexpr int BIG_WIN = 2048;
+constexpr int BIG_MAX_BUCKET = 256;
+
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_big_kernel(
+    const unsigned long long *__restrict__ entries, unsigned long long *__restrict__ scratch,
+    const int32_t *__restrict__ offsets, int n_tiles, int tile_n_bits, int64_t M_cap, int n_lo, uint32_t id_max,
+    int32_t *__restrict__ degenerate, int64_t *__restrict__ isect_ids, int32_t *__restrict__ flatten_ids) {
+    __shared__ __attribute__((aligned(16))) unsigned long long s_win[BIG_WIN];
+    __shared__ int s_start[BIG_NB + 1];
+    __shared__ int s_cur[BIG_NB];
+    __shared__ unsigned int s_red[2 * (SORT_THREADS / 64)];
+    __shared__ int s_wtot[SORT_THREADS / 64];
+    __shared__ int s_flag;
+    constexpr int PER = BIG_NB / SORT_THREADS;               // buckets per thread in the scan
+    const int tile = blockIdx.x;
+    const int t = threadIdx.x;
+    const int64_t start = max((int64_t)0, min((int64_t)offsets[tile], M_cap));
+    const int64_t end = max((int64_t)0, min((int64_t)offsets[tile + 1], M_cap));
+    const int n = (int)(end - start);
+    if (n <= n_lo) {                                         // the LDS counting sort took this tile
+        if (t == 0) degenerate[tile] = 0;
+        return;
+    }
+    const int c = tile / n_tiles, tl = tile - c * n_tiles;
+    const long long hi_part = ((long long)c << (32 + tile_n_bits)) | ((long long)tl << 32);
+    const unsigned long long *seg = entries + start;
+    unsigned long long *grp = scratch + start;
+    unsigned int dmin = 0xffffffffu, dmax = 0u;
+    for (int i = t; i < n; i += SORT_THREADS) {
+        const unsigned int d = (unsigned int)(seg[i] >> 32);
+        dmin = min(dmin, d); dmax = max(dmax, d);
+    }
+    for (int i = t; i < BIG_NB; i += SORT_THREADS) s_cur[i] = 0;
+    if (t == 0) s_flag = 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dmin = min(dmin, (unsigned int)__shfl_xor((int)dmin, off, 64));
+        dmax = max(dmax, (unsigned int)__shfl_xor((int)dmax, off, 64));
+    }
+    if ((t & 63) == 0) { s_red[t >> 6] = dmin; s_red[SORT_THREADS / 64 + (t >> 6)] = dmax; }
+    __syncthreads();
+    dmin = 0xffffffffu; dmax = 0u;
+#pragma unroll
+    for (int w = 0; w < SORT_THREADS / 64; ++w) { dmin = min(dmin, s_red[w]); dmax = max(dmax, s_red[SORT_THREADS / 64 + w]); }
+    const float fmin_ = __uint_as_float(dmin), fmax_ = __uint_as_float(dmax);
+    const float range = fmax_ - fmin_;
+    const float scale = (range > 0.0f) ? (float)(BIG_NB - 1) / range : 0.0f;
+    auto bucket_of = [&](unsigned long long k) -> int {
+        const float d = __uint_as_float((unsigned int)(k >> 32));
+        const int b = (int)((d - fmin_) * scale);
+        return min(max(b, 0), BIG_NB - 1);
+    };
+    for (int i = t; i < n; i += SORT_THREADS) atomicAdd(&s_cur[bucket_of(seg[i])], 1);
+    __syncthreads();
+    {   // exclusive scan of the bucket counts: PER consecutive buckets per thread + wave scan + wave totals
+        int cnt[PER];
+        int v = 0, big = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { cnt[j] = s_cur[PER * t + j]; v += cnt[j]; big = max(big, cnt[j]); }
+        if (big > BIG_MAX_BUCKET) s_flag = 1;                // benign race: any writer sets the same value
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(incl, off, 64);
+            if ((t & 63) >= off) incl += u;
+        }
+        if ((t & 63) == 63) s_wtot[t >> 6] = incl;
+        __syncthreads();
+        int run = incl - v;
+        for (int w = 0; w < (t >> 6); ++w) run += s_wtot[w];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { s_start[PER * t + j] = run; s_cur[PER * t + j] = run; run += cnt[j]; }
+        if (t == 0) s_start[BIG_NB] = n;
+    }
+    __syncthreads();
+    if (s_flag) {                                            // degenerate depth distribution: the merge launch sorts it
+        if (t == 0) degenerate[tile] = 1;
+        return;
+    }
+    if (t == 0) degenerate[tile] = 0;
+    for (int i = t; i < n; i += SORT_THREADS) {
+        const unsigned long long k = seg[i];
+        grp[atomicAdd(&s_cur[bucket_of(k)], 1)] = k;
+    }
+    __syncthreads();                                         // the grouped keys are read back by other lanes below
+    int b0 = 0;
+    while (b0 < BIG_NB) {
+        const int ws = s_start[b0];
+        if (ws >= n) break;                                  // only empty buckets are left
+        int lo = b0 + 1, hi = BIG_NB;                        // largest b1 with s_start[b1] - ws <= BIG_WIN (>= b0 + 1)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_start[mid] - ws <= BIG_WIN) lo = mid; else hi = mid - 1;
+        }
+        const int b1 = lo;
+        const int len = s_start[b1] - ws;
+        for (int i = t; i < len; i += SORT_THREADS) s_win[i] = grp[ws + i];
+        __syncthreads();
+        for (int i = t; i < len; i += SORT_THREADS) {
+            const unsigned long long k = s_win[i];
+            const int b = bucket_of(k);
+            const int bs = s_start[b] - ws, be = s_start[b + 1] - ws;
+            int rank = 0;
+            for (int j = bs; j < be; ++j) rank += (s_win[j] < k) ? 1 : 0;
+            const int64_t o = start + ws + bs + rank;
+            flatten_ids[o] = (int32_t)min((uint32_t)k, id_max);
+            if (isect_ids) isect_ids[o] = hi_part | (long long)(k >> 32);
+        }
+        __syncthreads();
+        b0 = b1;
+    }
+}
+
 int bit_length(uint32_t v) {
     int n = 0;
     while (v) { ++n; v >>= 1; }
@@ -660,21 +784,30 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
         if (ts && ts[0] == 'm')                              // A/B: the merge sort for the small class as well
             hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), (size_t)(2 * small_cap * 8), st,
                                entries, scratch, offsets, (int)n_tiles, tnb, M_cap, small_cap, 0, small_cap, id_max,
-                               isect_ids, flatten_ids);
+                               (const int32_t *)nullptr, isect_ids, flatten_ids);
         else
             hipLaunchKernelGGL(tile_sort_count_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, offsets,
                                (int)n_tiles, tnb, M_cap, id_max, isect_ids, flatten_ids);
         GSX_CHECK_LAUNCH();
         if (M_cap > small_cap) {
-            const size_t lds_bytes = (size_t)(2 * big_cap * 8);     // 128 KiB of the CU's 160 KiB
+            // larger tiles: the streaming counting sort; what it flags as degenerate (and, under GSX_TILE_SORT=merge,
+            // every large tile) goes to the merge sort with an 8192-key LDS window (128 KiB of the CU's 160 KiB)
+            const bool merge_all = ts && ts[0] == 'm';
+            if (!merge_all) {
+                hipLaunchKernelGGL(tile_sort_count_big_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries,
+                                   scratch, offsets, (int)n_tiles, tnb, M_cap, small_cap, id_max, cursor, isect_ids,
+                                   flatten_ids);
+                GSX_CHECK_LAUNCH();
+            }
+            const size_t lds_bytes = (size_t)(2 * big_cap * 8);
             if (hipFuncSetAttribute((const void *)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes) != hipSuccess) {
                 gsx_set_error("gsx_isect_bin_sort: cannot raise the dynamic LDS limit to %zu bytes", lds_bytes);
                 return GSX_E_LAUNCH;
             }
             hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), lds_bytes, st, entries, scratch,
-                               offsets, (int)n_tiles, tnb, M_cap, big_cap, small_cap, 0x7fffffff, id_max, isect_ids,
-                               flatten_ids);
+                               offsets, (int)n_tiles, tnb, M_cap, big_cap, small_cap, 0x7fffffff, id_max,
+                               merge_all ? (const int32_t *)nullptr : (const int32_t *)cursor, isect_ids, flatten_ids);
         }
         GSX_CHECK_LAUNCH();
     }

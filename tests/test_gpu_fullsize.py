@@ -112,6 +112,27 @@ def test_hot_tile_exceeds_lds_window(dev, oracle32):
     assert np.bincount((oids >> 32) & 2047).max() > 8192            # really beyond the largest LDS window
 
 
+def test_hot_tile_degenerate_depths(dev, oracle32):
+    """large tiles whose depths defeat the counting sort (thousands of equal depths, or all but one key in one bucket):
+    flagged on the device and sorted by the merge launch; mixed with ordinary large tiles in the same call"""
+    from gslam_amd import ops
+    g = torch.Generator().manual_seed(6)
+    n = 24000
+    m2d = torch.rand(1, n, 2, generator=g) * torch.tensor([640.0, 480.0])
+    m2d[0, :6000] = torch.tensor([200.0, 200.0]) + torch.rand(6000, 2, generator=g) * 4.0     # equal depths
+    m2d[0, 6000:12000] = torch.tensor([400.0, 100.0]) + torch.rand(6000, 2, generator=g) * 4.0  # one far outlier
+    m2d[0, 12000:18000] = torch.tensor([100.0, 400.0]) + torch.rand(6000, 2, generator=g) * 4.0  # well spread
+    radii = torch.full((1, n), 3, dtype=torch.int32)
+    dep = torch.rand(1, n, generator=g) * 5 + 0.5
+    dep[0, :6000] = 2.5
+    dep[0, 6000:12000] = 1.0 + torch.rand(6000, generator=g) * 1e-3
+    dep[0, 6000] = 5000.0
+    tpg, ids, flat = ops.isect_tiles(m2d.to(dev), radii.to(dev), dep.to(dev), 16, 40, 30)
+    otpg, oids, oflat = oracle32.isect_tiles(m2d.numpy(), radii.numpy(), dep.numpy(), 16, 40, 30)
+    assert np.array_equal(ids.cpu().numpy(), oids) and np.array_equal(flat.cpu().numpy(), oflat)
+    assert np.sort(np.bincount((oids >> 32) & 2047))[-3] > 2048      # three tiles beyond the LDS counting sort
+
+
 @pytest.mark.parametrize("n,c,W,H,ch", [(500_000, 1, 640, 480, 5), (200_000, 8, 640, 480, 5),
                                          (5_000_000, 1, 1920, 1080, 3)])
 def test_raster_properties_full_size(dev, n, c, W, H, ch):

@@ -1,0 +1,87 @@
+"""Render forward + backward time and algorithmic HBM rate at the BASELINE.json configurations (SURVEY.md 8d byte
+model: B_fwd = 92 C N + 92 M + 28 P, B_bwd = 136 C N + 40 N + 48 M + 32 P at CH = 5; SH-3 adds N 192 + C N 12 each
+way), one GPU.  Configs 2-5; config 4's 8 keyframes are what ONE GPU would render without sharding.
+
+    python tools/bench_configs.py
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gslam_amd.rasterization import rasterization, validate  # noqa: E402
+from gslam_amd.rendering import rasterization as gs_rasterization  # noqa: E402
+from gslam_amd.synthetic import make_cameras, make_scene  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def run(name, N, C, W, H, sh=False):
+    sc = make_scene(N, 0, sh_degree=3 if sh else None)
+    p = {k: v.to(dev).requires_grad_(v.is_floating_point()) for k, v in sc.items()}
+    viewmats, Ks = make_cameras(C, W, H)
+    viewmats, Ks = viewmats.to(dev), Ks.to(dev)
+    bg = torch.zeros(C, 3, device=dev)
+    state = {}
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        if sh:
+            render, alphas, info = gs_rasterization(p["means"], p["quats"], torch.exp(p["scales"]),
+                                                    torch.sigmoid(p["opacities"]), p["sh_coeffs"], viewmats, Ks, W, H,
+                                                    sh_degree=3, packed=False, backgrounds=bg)
+            (render.sum() + alphas.sum()).backward()
+            state["M"] = int(info["flatten_ids"].shape[0])
+        else:
+            out = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], viewmats, Ks, W, H,
+                                packed=False, render_mode="RGB+D", log_uncertainties=p["log_uncertainties"],
+                                backgrounds=bg)
+            (out._render.sum() + out.alphas.sum()).backward()
+            state["out"] = out
+
+    step()
+    validate(dev)
+    step()
+    if not sh:
+        state["M"] = int(state["out"].flatten_ids.shape[0])
+    ms = timed(step, 6 if N >= 2_000_000 else 10)
+    M, P, CH = state["M"], C * W * H, 3 if sh else 5
+    b = (C * N * 92 + M * (72 + 4 * CH) + P * (4 * CH + 8)) + (C * N * (116 + 4 * CH) + N * 40 + M * (28 + 4 * CH) +
+                                                              P * (4 * CH + 12))
+    if sh:
+        b += 2 * (N * 192 + C * N * 12) + N * 192
+    print(json.dumps({"config": name, "gaussians": N, "cameras": C, "size": f"{W}x{H}", "intersections": M,
+                      "fwd_bwd_ms": round(ms, 3), "algorithmic_MB": round(b / 1e6, 1),
+                      "algorithmic_GBps": round(b / ms / 1e6, 1), "frac_of_8TBps": round(b / ms / 1e6 / 8000.0, 4)}),
+          flush=True)
+    del p, state
+    torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    run("2: 100k, 640x480, 1 camera", 100_000, 1, 640, 480)
+    run("3: 500k, 640x480, 1 camera (tracking closure)", 500_000, 1, 640, 480)
+    run("3: 500k, 640x480, 8 cameras (BA window)", 500_000, 8, 640, 480)
+    run("4: 2M, 640x480, 1 camera (one GPU's share of the sharded BA)", 2_000_000, 1, 640, 480)
+    run("4: 2M, 640x480, 8 cameras (unsharded)", 2_000_000, 8, 640, 480)
+    run("5: 5M SH-3, 1920x1080, 1 camera", 5_000_000, 1, 1920, 1080, sh=True)
