@@ -78,19 +78,46 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
     dx[15] = SH_C3_6 * (3.0f * xx - 3.0f * yy); dy[15] = SH_C3_6 * -6.0f * x * y;
 }
 
-// one thread per Gaussian, looping cameras: the 192-byte coefficient row (degree 3) is read once per Gaussian
-__global__ __launch_bounds__(256) void sh_fwd_kernel(int deg, const float *__restrict__ dirs,
-                                                     const float *__restrict__ coeffs,
-                                                     const int32_t *__restrict__ radii, int64_t N, int C, int Kc,
-                                                     float *__restrict__ colors) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
-    const int nb = (deg + 1) * (deg + 1);
-    float co[16 * 3];
-    for (int k = 0; k < nb; ++k) {
-        co[3 * k] = coeffs[(g * Kc + k) * 3]; co[3 * k + 1] = coeffs[(g * Kc + k) * 3 + 1];
-        co[3 * k + 2] = coeffs[(g * Kc + k) * 3 + 2];
+// One thread per Gaussian, looping cameras, so the 192-byte coefficient row (degree 3) is read once per Gaussian.
+// The rows of a workgroup's 256 Gaussians are one contiguous block of coeffs: it is copied global -> LDS with
+// consecutive lanes on consecutive floats (full 128-byte lines), each lane then picks its own row out of LDS (row
+// stride padded to an odd word count: no bank conflicts), and the backward's coefficient gradients leave the same
+// way.  DEG is a template parameter so that basis, coefficients and accumulators are registers, not scratch.
+constexpr int SH_BLOCK = 256;
+
+template <int DEG>
+__device__ __forceinline__ void sh_stage_in(const float *__restrict__ coeffs, int64_t g0, int rows, int Kc,
+                                            float *s_rows) {
+    constexpr int NBC = (DEG + 1) * (DEG + 1) * 3, PITCH = NBC | 1;
+    const float *src = coeffs + g0 * Kc * 3;
+    const int total = rows * Kc * 3;
+    if (Kc * 3 == NBC) {
+        for (int i = threadIdx.x; i < total; i += SH_BLOCK) s_rows[(i / NBC) * PITCH + (i % NBC)] = src[i];
+    } else {
+        const int rl = Kc * 3;
+        for (int i = threadIdx.x; i < total; i += SH_BLOCK) {
+            const int r = i / rl, col = i - r * rl;
+            if (col < NBC) s_rows[r * PITCH + col] = src[i];
+        }
     }
+}
+
+template <int DEG>
+__global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(const float *__restrict__ dirs,
+                                                          const float *__restrict__ coeffs,
+                                                          const int32_t *__restrict__ radii, int64_t N, int C, int Kc,
+                                                          float *__restrict__ colors) {
+    constexpr int NB = (DEG + 1) * (DEG + 1), NBC = NB * 3, PITCH = NBC | 1;
+    __shared__ float s_rows[SH_BLOCK * PITCH];
+    const int64_t g0 = (int64_t)blockIdx.x * SH_BLOCK;
+    const int rows = (int)min((int64_t)SH_BLOCK, N - g0);
+    sh_stage_in<DEG>(coeffs, g0, rows, Kc, s_rows);
+    __syncthreads();
+    const int64_t g = g0 + threadIdx.x;
+    if (g >= N) return;
+    float co[NBC];
+#pragma unroll
+    for (int k = 0; k < NBC; ++k) co[k] = s_rows[threadIdx.x * PITCH + k];
     for (int c = 0; c < C; ++c) {
         const int64_t idx = (int64_t)c * N + g;
         float o0 = 0.f, o1 = 0.f, o2 = 0.f;
@@ -100,31 +127,32 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(int deg, const float *__res
             const float inv = n > 0.f ? 1.0f / n : 0.f;
             x *= inv; y *= inv; z *= inv;
             float B[16];
-            sh_basis(deg, x, y, z, B);
-            for (int k = 0; k < nb; ++k) { o0 += B[k] * co[3 * k]; o1 += B[k] * co[3 * k + 1]; o2 += B[k] * co[3 * k + 2]; }
+            sh_basis(DEG, x, y, z, B);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { o0 += B[k] * co[3 * k]; o1 += B[k] * co[3 * k + 1]; o2 += B[k] * co[3 * k + 2]; }
             o0 = fmaxf(0.f, o0 + 0.5f); o1 = fmaxf(0.f, o1 + 0.5f); o2 = fmaxf(0.f, o2 + 0.5f);
         }
         colors[3 * idx] = o0; colors[3 * idx + 1] = o1; colors[3 * idx + 2] = o2;
     }
 }
 
-__global__ __launch_bounds__(256) void sh_bwd_kernel(int deg, const float *__restrict__ dirs,
-                                                     const float *__restrict__ coeffs,
-                                                     const int32_t *__restrict__ radii,
-                                                     const float *__restrict__ v_colors, int64_t N, int C, int Kc,
-                                                     float *__restrict__ v_coeffs, float *__restrict__ v_dirs) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
-    const int nb = (deg + 1) * (deg + 1);
-    float co[16 * 3], vco[16 * 3];
-    for (int k = 0; k < 16; ++k) {
-        const bool in = k < nb;
-        for (int ch = 0; ch < 3; ++ch) {
-            co[3 * k + ch] = in ? coeffs[(g * Kc + k) * 3 + ch] : 0.f;
-            vco[3 * k + ch] = 0.f;
-        }
-    }
-    for (int c = 0; c < C; ++c) {
+template <int DEG>
+__global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(const float *__restrict__ dirs,
+                                                          const float *__restrict__ coeffs,
+                                                          const int32_t *__restrict__ radii,
+                                                          const float *__restrict__ v_colors, int64_t N, int C, int Kc,
+                                                          float *__restrict__ v_coeffs, float *__restrict__ v_dirs) {
+    constexpr int NB = (DEG + 1) * (DEG + 1), NBC = NB * 3, PITCH = NBC | 1;
+    __shared__ float s_rows[SH_BLOCK * PITCH];
+    const int64_t g0 = (int64_t)blockIdx.x * SH_BLOCK;
+    const int rows = (int)min((int64_t)SH_BLOCK, N - g0);
+    sh_stage_in<DEG>(coeffs, g0, rows, Kc, s_rows);
+    __syncthreads();
+    const int64_t g = g0 + threadIdx.x;
+    float co[NBC], vco[NBC];
+#pragma unroll
+    for (int k = 0; k < NBC; ++k) { co[k] = s_rows[threadIdx.x * PITCH + k]; vco[k] = 0.f; }
+    for (int c = 0; c < C && g < N; ++c) {
         const int64_t idx = (int64_t)c * N + g;
         float vdx = 0.f, vdy = 0.f, vdz = 0.f;
         if (!radii || radii[idx] > 0) {
@@ -133,15 +161,17 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int deg, const float *__res
             const float inv = n > 0.f ? 1.0f / n : 0.f;
             const float x = dx_ * inv, y = dy_ * inv, z = dz_ * inv;
             float B[16], bx[16], by[16], bz[16];
-            sh_basis(deg, x, y, z, B);
-            sh_basis_grad(deg, x, y, z, bx, by, bz);
+            sh_basis(DEG, x, y, z, B);
+            sh_basis_grad(DEG, x, y, z, bx, by, bz);
             float vx = 0.f, vy = 0.f, vz = 0.f;
+#pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 float acc = 0.f;
-                for (int k = 0; k < nb; ++k) acc += B[k] * co[3 * k + ch];
-                if (!(acc + 0.5f > 0.f)) continue;
-                const float vc = v_colors[3 * idx + ch];
-                for (int k = 0; k < nb; ++k) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) acc += B[k] * co[3 * k + ch];
+                const float vc = (acc + 0.5f > 0.f) ? v_colors[3 * idx + ch] : 0.f;      // clamped channels pass nothing
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
                     vco[3 * k + ch] += B[k] * vc;
                     const float cv = co[3 * k + ch] * vc;
                     vx += bx[k] * cv; vy += by[k] * cv; vz += bz[k] * cv;
@@ -152,8 +182,21 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int deg, const float *__res
         }
         if (v_dirs) { v_dirs[3 * idx] = vdx; v_dirs[3 * idx + 1] = vdy; v_dirs[3 * idx + 2] = vdz; }
     }
-    for (int k = 0; k < Kc; ++k)
-        for (int ch = 0; ch < 3; ++ch) v_coeffs[(g * Kc + k) * 3 + ch] = (k < nb) ? vco[3 * k + ch] : 0.f;
+    __syncthreads();                                         // every lane has taken its row: reuse the block for output
+#pragma unroll
+    for (int k = 0; k < NBC; ++k) s_rows[threadIdx.x * PITCH + k] = vco[k];
+    __syncthreads();
+    float *dst = v_coeffs + g0 * Kc * 3;
+    const int total = rows * Kc * 3;
+    if (Kc * 3 == NBC) {
+        for (int i = threadIdx.x; i < total; i += SH_BLOCK) dst[i] = s_rows[(i / NBC) * PITCH + (i % NBC)];
+    } else {
+        const int rl = Kc * 3;
+        for (int i = threadIdx.x; i < total; i += SH_BLOCK) {
+            const int r = i / rl, col = i - r * rl;
+            dst[i] = (col < NBC) ? s_rows[r * PITCH + col] : 0.f;       // bands above the active degree get no gradient
+        }
+    }
 }
 
 // ---- fused multi-tensor Adam --------------------------------------------------------------------------------------
@@ -237,8 +280,14 @@ extern "C" int gsx_sh_fwd(int degree, const float *dirs, const float *coeffs, co
     GSX_CHECK_ARG(degree >= 0 && degree <= 3 && dirs && coeffs && colors && N >= 0 && C >= 1);
     GSX_CHECK_ARG((degree + 1) * (degree + 1) <= Kc);
     if (N == 0) return GSX_OK;
-    hipLaunchKernelGGL(sh_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, degree, dirs,
-                       coeffs, radii, N, (int)C, Kc, colors);
+    const dim3 grid((unsigned)((N + SH_BLOCK - 1) / SH_BLOCK)), block(SH_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    switch (degree) {
+    case 0: hipLaunchKernelGGL(sh_fwd_kernel<0>, grid, block, 0, st, dirs, coeffs, radii, N, (int)C, Kc, colors); break;
+    case 1: hipLaunchKernelGGL(sh_fwd_kernel<1>, grid, block, 0, st, dirs, coeffs, radii, N, (int)C, Kc, colors); break;
+    case 2: hipLaunchKernelGGL(sh_fwd_kernel<2>, grid, block, 0, st, dirs, coeffs, radii, N, (int)C, Kc, colors); break;
+    default: hipLaunchKernelGGL(sh_fwd_kernel<3>, grid, block, 0, st, dirs, coeffs, radii, N, (int)C, Kc, colors); break;
+    }
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }
@@ -249,8 +298,18 @@ extern "C" int gsx_sh_bwd(int degree, const float *dirs, const float *coeffs, co
     GSX_CHECK_ARG(degree >= 0 && degree <= 3 && dirs && coeffs && v_colors && v_coeffs && N >= 0 && C >= 1);
     GSX_CHECK_ARG((degree + 1) * (degree + 1) <= Kc);
     if (N == 0) return GSX_OK;
-    hipLaunchKernelGGL(sh_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, degree, dirs,
-                       coeffs, radii, v_colors, N, (int)C, Kc, v_coeffs, v_dirs);
+    const dim3 grid((unsigned)((N + SH_BLOCK - 1) / SH_BLOCK)), block(SH_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+#define GSX_SH_BWD(D)                                                                                                  \
+    hipLaunchKernelGGL(sh_bwd_kernel<D>, grid, block, 0, st, dirs, coeffs, radii, v_colors, N, (int)C, Kc, v_coeffs,   \
+                       v_dirs)
+    switch (degree) {
+    case 0: GSX_SH_BWD(0); break;
+    case 1: GSX_SH_BWD(1); break;
+    case 2: GSX_SH_BWD(2); break;
+    default: GSX_SH_BWD(3); break;
+    }
+#undef GSX_SH_BWD
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }
