@@ -210,24 +210,46 @@ __global__ __launch_bounds__(BIN_THREADS) void count_matrix_kernel(const float *
     for (int i = threadIdx.x; i < n_tiles; i += BIN_THREADS) row[i] = s_cnt[i];
 }
 
-// one thread per (camera, tile): exclusive scan down the workgroup dimension (in place), total into counts[]
-__global__ __launch_bounds__(256) void column_scan_kernel(int32_t *__restrict__ cnt, int gblocks, int n_tiles, int T,
-                                                          int32_t *__restrict__ counts /*[T]*/) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= T) return;
-    const int c = i / n_tiles, tl = i - c * n_tiles;
+// exclusive scan down the workgroup dimension of the count matrix (in place), column totals into counts[].
+// A workgroup takes 64 adjacent tile columns of one camera (one 256-byte row segment per wavefront load) and splits the
+// rows over its 16 wavefronts: each lane holds its <= GB_MAX / 16 rows in registers (all loads in flight at once), the
+// wavefronts exchange their column sums through LDS, and the rows go back as exclusive prefixes.  One thread per
+// column walking all rows serially was a 23 us latency chain at 500 k Gaussians (489 rows, 19 wavefronts in flight).
+constexpr int CS_GROUPS = 16;
+constexpr int CS_ROWS = GB_MAX / CS_GROUPS;                 // rows per wavefront, at most
+
+__global__ __launch_bounds__(64 * CS_GROUPS) void column_scan_kernel(int32_t *__restrict__ cnt, int gblocks,
+                                                                     int n_tiles, int32_t *__restrict__ counts /*[T]*/) {
+    __shared__ int s_tot[CS_GROUPS][64];
+    const int c = blockIdx.y;
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int tl = blockIdx.x * 64 + lane;
+    const bool in = tl < n_tiles;
+    const int rpg = (gblocks + CS_GROUPS - 1) / CS_GROUPS;
+    const int r0 = rg * rpg, r1 = min(gblocks, r0 + rpg);
     int32_t *col = cnt + (int64_t)c * gblocks * n_tiles + tl;
-    int run = 0;
-    int b = 0;
-    for (; b + 8 <= gblocks; b += 8) {      // eight loads in flight per trip
-        int v[8];
+    int v[CS_ROWS];
+    int sum = 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(b + u) * n_tiles];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { col[(int64_t)(b + u) * n_tiles] = run; run += v[u]; }
+    for (int u = 0; u < CS_ROWS; ++u) {
+        v[u] = (in && r0 + u < r1) ? col[(int64_t)(r0 + u) * n_tiles] : 0;
+        sum += v[u];
     }
-    for (; b < gblocks; ++b) { const int v = col[(int64_t)b * n_tiles]; col[(int64_t)b * n_tiles] = run; run += v; }
-    counts[i] = run;
+    s_tot[rg][lane] = sum;
+    __syncthreads();
+    int run = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < CS_GROUPS; ++w) {
+        const int tw = s_tot[w][lane];
+        run += (w < rg) ? tw : 0;
+        total += tw;
+    }
+#pragma unroll
+    for (int u = 0; u < CS_ROWS; ++u) {
+        if (in && r0 + u < r1) col[(int64_t)(r0 + u) * n_tiles] = run;
+        run += v[u];
+    }
+    if (in && rg == 0) counts[(int64_t)c * n_tiles + tl] = total;
 }
 
 // exclusive scan of the T per-tile counts held in offsets[] -> offsets[T+1], M, overflow status (one workgroup)
@@ -395,12 +417,10 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long l
                                                                  const int32_t *__restrict__ offsets, int n_tiles,
                                                                  int tile_n_bits, int64_t M_cap, int cap,
                                                                  int n_lo, int n_hi, uint32_t id_max,
-                                                                 const int32_t *__restrict__ only_flagged,
                                                                  int64_t *__restrict__ isect_ids,
                                                                  int32_t *__restrict__ flatten_ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
     const int tile = blockIdx.x;
-    if (only_flagged && only_flagged[tile] == 0) return;    // the counting sort already did this tile
     const int64_t start = max((int64_t)0, min((int64_t)offsets[tile], M_cap));
     const int64_t end = max((int64_t)0, min((int64_t)offsets[tile + 1], M_cap));
     const int n = (int)(end - start);
@@ -433,49 +453,113 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long l
     }
 }
 
-// ---- 4b. per-tile sort by counting (tiles of up to 2048 keys) ---------------------------------------------------------
+// ---- 4b. per-tile sort by counting ------------------------------------------------------------------------------------
 // The merge sort above is a chain of ~40 dependent LDS reads per key (binary searches); depth keys inside one tile are
 // spread over a narrow range, so a counting sort gets there with two LDS atomics per key and no search:
 //   1. min / max depth of the tile (block reduction) -> monotone map depth -> bucket in [0, NB)
 //   2. histogram (ds_add), exclusive scan over the NB buckets, scatter (returning ds_add) -> keys grouped by bucket
 //   3. exact rank inside the bucket by counting smaller (depth, id) keys among the bucket's members (1-2 on average)
 // The map is monotone in the float depth (subtract, multiply and float->int conversion are all monotone), so bucket
-// order never contradicts key order and step 3 makes the result the same total order the merge sort produces.  A tile
-// whose keys pile up in one bucket (same depth everywhere) falls back to the merge sort.
-constexpr int CNT_NB = 1024;          // buckets
-constexpr int CNT_MAXN = 2048;        // keys
-constexpr int CNT_MAX_BUCKET = 96;    // largest bucket the quadratic step 3 accepts
+// order never contradicts key order and step 3 makes the result the same total order the merge sort produces.
+//
+// One launch, one workgroup per tile, two regimes chosen by the tile's size (known only on the device):
+//   * up to 2048 keys: keys staged in LDS, 1024 buckets;
+//   * more: keys streamed from global memory (L2), 4096 buckets, scatter into the scratch copy grouped by bucket, then
+//     the grouped keys come back through a 2048-key LDS window cut at bucket boundaries for step 3.  Every pass is a
+//     coalesced stream, the tile size is unbounded.  (The merge sort it replaced walked log2(n / 8192) levels of
+//     dependent binary searches through L2: 6.1 ms of a 13 ms render at 5M Gaussians / 1080p.)
+// A tile whose keys pile up in one bucket (same depth everywhere) falls back to the merge sort inside the same LDS.
+// After the scatter a bucket's cursor is its end, which is the next bucket's start: no separate start array, and the
+// kernel stays at 36 KiB of LDS (4 workgroups of 8 wavefronts per CU).
+constexpr int CNT_NB = 1024;          // buckets, keys staged in LDS
+constexpr int CNT_MAXN = 2048;        // largest tile of the LDS regime = LDS window of the streaming regime
+constexpr int CNT_MAX_BUCKET = 96;    // largest bucket the quadratic step 3 accepts (LDS regime)
+constexpr int BIG_NB = 4096;          // buckets, streaming regime
+constexpr int BIG_MAX_BUCKET = 256;
+
+// exclusive scan of s_cur[0..NB) in place (NB = PER * SORT_THREADS); returns true if some count exceeds `limit`
+template <int NB>
+__device__ __forceinline__ bool bucket_scan(int *s_cur, int *s_wtot, int limit) {
+    constexpr int PER = NB / SORT_THREADS;
+    const int t = threadIdx.x;
+    int cnt[PER];
+    int v = 0, big = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { cnt[j] = s_cur[PER * t + j]; v += cnt[j]; big = max(big, cnt[j]); }
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(incl, off, 64);
+        if ((t & 63) >= off) incl += u;
+    }
+    if ((t & 63) == 63) s_wtot[t >> 6] = incl;
+    const int any_big = __syncthreads_or(big > limit);
+    int run = incl - v;
+    for (int w = 0; w < (t >> 6); ++w) run += s_wtot[w];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { s_cur[PER * t + j] = run; run += cnt[j]; }
+    __syncthreads();
+    return any_big != 0;
+}
+
+// merge sort of one tile with a `cap`-key LDS window (2 * cap keys of LDS at s_mem): chunks sorted in LDS and written
+// back in place, remaining levels through global memory.  Returns where the sorted keys are (LDS or global).
+__device__ __forceinline__ const unsigned long long *merge_sort_tile(unsigned long long *seg, unsigned long long *scr,
+                                                                     int n, unsigned long long *s_mem, int cap) {
+    if (n <= cap) return lds_sort(seg, n, s_mem, s_mem + cap);
+    for (int cb = 0; cb < n; cb += cap) {
+        const int len = min(cap, n - cb);
+        const unsigned long long *res = lds_sort(seg + cb, len, s_mem, s_mem + cap);
+        for (int i = threadIdx.x; i < len; i += SORT_THREADS) seg[cb + i] = res[i];
+    }
+    __syncthreads();
+    unsigned long long *src = seg, *dst = scr;
+    for (int run = cap; run < n; run <<= 1) {
+        merge_level(src, dst, n, run);
+        __syncthreads();
+        unsigned long long *t = src; src = dst; dst = t;
+    }
+    return src;
+}
 
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned long long *__restrict__ entries,
+                                                                       unsigned long long *__restrict__ scratch,
                                                                        const int32_t *__restrict__ offsets, int n_tiles,
                                                                        int tile_n_bits, int64_t M_cap, uint32_t id_max,
                                                                        int64_t *__restrict__ isect_ids,
                                                                        int32_t *__restrict__ flatten_ids) {
-    __shared__ __attribute__((aligned(16))) unsigned long long s_a[CNT_MAXN];
-    __shared__ __attribute__((aligned(16))) unsigned long long s_b[CNT_MAXN];
-    __shared__ int s_start[CNT_NB + 1];
-    __shared__ int s_cur[CNT_NB];
+    // 36 KiB: [a | b | 1024 cursors] in the LDS regime, [window | 4096 cursors] in the streaming one
+    __shared__ __attribute__((aligned(16))) unsigned long long s_keys[2 * CNT_MAXN + CNT_NB / 2];
     __shared__ unsigned int s_red[2 * (SORT_THREADS / 64)];
-    __shared__ int s_flag;
+    __shared__ int s_wtot[SORT_THREADS / 64];
     const int tile = blockIdx.x;
     const int t = threadIdx.x;
     const int64_t start = max((int64_t)0, min((int64_t)offsets[tile], M_cap));
     const int64_t end = max((int64_t)0, min((int64_t)offsets[tile + 1], M_cap));
     const int n = (int)(end - start);
-    if (n <= 0 || n > CNT_MAXN) return;                      // larger tiles: the merge-sort launch
+    if (n <= 0) return;
     const int c = tile / n_tiles, tl = tile - c * n_tiles;
     const long long hi_part = ((long long)c << (32 + tile_n_bits)) | ((long long)tl << 32);
     unsigned long long *seg = entries + start;
-    // 1. load + min / max of the depth bits (positive floats: same order as the values)
+    unsigned long long *grp = scratch + start;
+    auto emit = [&](int64_t o, unsigned long long k) {
+        flatten_ids[o] = (int32_t)min((uint32_t)k, id_max);  // never hand an out-of-range gather index on
+        if (isect_ids) isect_ids[o] = hi_part | (long long)(k >> 32);
+    };
+    const bool small = n <= CNT_MAXN;
+    unsigned long long *s_a = s_keys, *s_b = s_keys + CNT_MAXN;
+    int *s_cur = reinterpret_cast<int *>(small ? s_keys + 2 * CNT_MAXN : s_keys + CNT_MAXN);
+    static_assert(BIG_NB * 4 <= (CNT_MAXN + CNT_NB / 2) * 8, "streaming-regime cursors must fit behind the window");
+    const int nb = small ? CNT_NB : BIG_NB;
+    // 1. min / max of the depth bits (positive floats: same order as the values); the LDS regime stages the keys
     unsigned int dmin = 0xffffffffu, dmax = 0u;
     for (int i = t; i < n; i += SORT_THREADS) {
         const unsigned long long k = seg[i];
-        s_a[i] = k;
+        if (small) s_a[i] = k;
         const unsigned int d = (unsigned int)(k >> 32);
         dmin = min(dmin, d); dmax = max(dmax, d);
     }
-    for (int i = t; i < CNT_NB; i += SORT_THREADS) s_cur[i] = 0;
-    if (t == 0) s_flag = 0;
+    for (int i = t; i < nb; i += SORT_THREADS) s_cur[i] = 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         dmin = min(dmin, (unsigned int)__shfl_xor((int)dmin, off, 64));
@@ -488,183 +572,67 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
     for (int w = 0; w < SORT_THREADS / 64; ++w) { dmin = min(dmin, s_red[w]); dmax = max(dmax, s_red[SORT_THREADS / 64 + w]); }
     const float fmin_ = __uint_as_float(dmin), fmax_ = __uint_as_float(dmax);
     const float range = fmax_ - fmin_;
-    const float scale = (range > 0.0f) ? (float)(CNT_NB - 1) / range : 0.0f;
+    const float scale = (range > 0.0f) ? (float)(nb - 1) / range : 0.0f;
     auto bucket_of = [&](unsigned long long k) -> int {
         const float d = __uint_as_float((unsigned int)(k >> 32));
         const int b = (int)((d - fmin_) * scale);
-        return min(max(b, 0), CNT_NB - 1);
+        return min(max(b, 0), nb - 1);
     };
-    // 2. histogram
-    for (int i = t; i < n; i += SORT_THREADS) atomicAdd(&s_cur[bucket_of(s_a[i])], 1);
+    // 2. histogram, scan
+    if (small) for (int i = t; i < n; i += SORT_THREADS) atomicAdd(&s_cur[bucket_of(s_a[i])], 1);
+    else for (int i = t; i < n; i += SORT_THREADS) atomicAdd(&s_cur[bucket_of(seg[i])], 1);
     __syncthreads();
-    // exclusive scan of the NB counts: 2 buckets per thread + wave scan + wave totals
-    {
-        const int b0 = 2 * t;
-        const int c0 = (b0 < CNT_NB) ? s_cur[b0] : 0, c1 = (b0 + 1 < CNT_NB) ? s_cur[b0 + 1] : 0;
-        if (max(c0, c1) > CNT_MAX_BUCKET) s_flag = 1;        // benign race: any writer sets the same value
-        int v = c0 + c1;
-        int incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int u = __shfl_up(incl, off, 64);
-            if ((t & 63) >= off) incl += u;
-        }
-        __shared__ int s_wtot[SORT_THREADS / 64];
-        if ((t & 63) == 63) s_wtot[t >> 6] = incl;
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < (t >> 6); ++w) base += s_wtot[w];
-        const int excl = base + incl - v;
-        if (b0 < CNT_NB) { s_start[b0] = excl; s_cur[b0] = excl; }
-        if (b0 + 1 < CNT_NB) { s_start[b0 + 1] = excl + c0; s_cur[b0 + 1] = excl + c0; }
-        if (t == 0) s_start[CNT_NB] = n;
+    const bool degenerate = small ? bucket_scan<CNT_NB>(s_cur, s_wtot, CNT_MAX_BUCKET)
+                                  : bucket_scan<BIG_NB>(s_cur, s_wtot, BIG_MAX_BUCKET);
+    if (degenerate) {                                        // same depth everywhere: merge sort in the same LDS
+        const unsigned long long *sorted = merge_sort_tile(seg, grp, n, s_keys, CNT_MAXN);
+        for (int i = t; i < n; i += SORT_THREADS) emit(start + i, sorted[i]);
+        return;
     }
-    __syncthreads();
-    if (s_flag) {                                            // degenerate depth distribution: merge sort in the same LDS
-        const unsigned long long *sorted = lds_sort(seg, n, s_a, s_b);
+    auto bucket_start = [&](int b) -> int { return b ? s_cur[b - 1] : 0; };    // valid once the scatter is done
+    if (small) {
         for (int i = t; i < n; i += SORT_THREADS) {
-            const unsigned long long k = sorted[i];
-            flatten_ids[start + i] = (int32_t)min((uint32_t)k, id_max);
-            if (isect_ids) isect_ids[start + i] = hi_part | (long long)(k >> 32);
+            const unsigned long long k = s_a[i];
+            s_b[atomicAdd(&s_cur[bucket_of(k)], 1)] = k;
         }
-        return;
-    }
-    // scatter into buckets
-    for (int i = t; i < n; i += SORT_THREADS) {
-        const unsigned long long k = s_a[i];
-        const int pos = atomicAdd(&s_cur[bucket_of(k)], 1);
-        s_b[pos] = k;
-    }
-    __syncthreads();
-    // 3. exact position inside the bucket, and out
-    for (int i = t; i < n; i += SORT_THREADS) {
-        const unsigned long long k = s_b[i];
-        const int b = bucket_of(k);
-        const int bs = s_start[b], be = s_start[b + 1];
-        int rank = 0;
-        for (int j = bs; j < be; ++j) rank += (s_b[j] < k) ? 1 : 0;
-        const int64_t o = start + bs + rank;
-        flatten_ids[o] = (int32_t)min((uint32_t)k, id_max);
-        if (isect_ids) isect_ids[o] = hi_part | (long long)(k >> 32);
-    }
-}
-
-// ---- 4c. counting sort for tiles of more than 2048 keys ---------------------------------------------------------------
-// Same three steps, with the keys streamed from global memory (L2) instead of staged in LDS, so that the tile size is
-// unbounded and the LDS footprint stays at 48 KiB (3 workgroups per CU):
-//   1. min / max depth, 2. histogram over 4096 buckets + scan, scatter into the scratch copy grouped by bucket,
-//   3. the grouped keys come back through a 2048-key LDS window cut at bucket boundaries; exact rank inside the bucket.
-// Every pass is a coalesced stream over the tile's keys; the merge sort it replaces walked log2(n / 8192) levels of
-// dependent binary searches through L2 (6.1 ms of a 13 ms render at 5M Gaussians / 1080p).  A tile with a bucket of
-// more than BIG_MAX_BUCKET keys is flagged and left to the merge-sort launch that follows.
-constexpr int BIG_NB = 4096;
-constexpr int BIG_WIN = 2048;
-constexpr int BIG_MAX_BUCKET = 256;
-
-__global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_big_kernel(
-    const unsigned long long *__restrict__ entries, unsigned long long *__restrict__ scratch,
-    const int32_t *__restrict__ offsets, int n_tiles, int tile_n_bits, int64_t M_cap, int n_lo, uint32_t id_max,
-    int32_t *__restrict__ degenerate, int64_t *__restrict__ isect_ids, int32_t *__restrict__ flatten_ids) {
-    __shared__ __attribute__((aligned(16))) unsigned long long s_win[BIG_WIN];
-    __shared__ int s_start[BIG_NB + 1];
-    __shared__ int s_cur[BIG_NB];
-    __shared__ unsigned int s_red[2 * (SORT_THREADS / 64)];
-    __shared__ int s_wtot[SORT_THREADS / 64];
-    __shared__ int s_flag;
-    constexpr int PER = BIG_NB / SORT_THREADS;               // buckets per thread in the scan
-    const int tile = blockIdx.x;
-    const int t = threadIdx.x;
-    const int64_t start = max((int64_t)0, min((int64_t)offsets[tile], M_cap));
-    const int64_t end = max((int64_t)0, min((int64_t)offsets[tile + 1], M_cap));
-    const int n = (int)(end - start);
-    if (n <= n_lo) {                                         // the LDS counting sort took this tile
-        if (t == 0) degenerate[tile] = 0;
-        return;
-    }
-    const int c = tile / n_tiles, tl = tile - c * n_tiles;
-    const long long hi_part = ((long long)c << (32 + tile_n_bits)) | ((long long)tl << 32);
-    const unsigned long long *seg = entries + start;
-    unsigned long long *grp = scratch + start;
-    unsigned int dmin = 0xffffffffu, dmax = 0u;
-    for (int i = t; i < n; i += SORT_THREADS) {
-        const unsigned int d = (unsigned int)(seg[i] >> 32);
-        dmin = min(dmin, d); dmax = max(dmax, d);
-    }
-    for (int i = t; i < BIG_NB; i += SORT_THREADS) s_cur[i] = 0;
-    if (t == 0) s_flag = 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        dmin = min(dmin, (unsigned int)__shfl_xor((int)dmin, off, 64));
-        dmax = max(dmax, (unsigned int)__shfl_xor((int)dmax, off, 64));
-    }
-    if ((t & 63) == 0) { s_red[t >> 6] = dmin; s_red[SORT_THREADS / 64 + (t >> 6)] = dmax; }
-    __syncthreads();
-    dmin = 0xffffffffu; dmax = 0u;
-#pragma unroll
-    for (int w = 0; w < SORT_THREADS / 64; ++w) { dmin = min(dmin, s_red[w]); dmax = max(dmax, s_red[SORT_THREADS / 64 + w]); }
-    const float fmin_ = __uint_as_float(dmin), fmax_ = __uint_as_float(dmax);
-    const float range = fmax_ - fmin_;
-    const float scale = (range > 0.0f) ? (float)(BIG_NB - 1) / range : 0.0f;
-    auto bucket_of = [&](unsigned long long k) -> int {
-        const float d = __uint_as_float((unsigned int)(k >> 32));
-        const int b = (int)((d - fmin_) * scale);
-        return min(max(b, 0), BIG_NB - 1);
-    };
-    for (int i = t; i < n; i += SORT_THREADS) atomicAdd(&s_cur[bucket_of(seg[i])], 1);
-    __syncthreads();
-    {   // exclusive scan of the bucket counts: PER consecutive buckets per thread + wave scan + wave totals
-        int cnt[PER];
-        int v = 0, big = 0;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) { cnt[j] = s_cur[PER * t + j]; v += cnt[j]; big = max(big, cnt[j]); }
-        if (big > BIG_MAX_BUCKET) s_flag = 1;                // benign race: any writer sets the same value
-        int incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int u = __shfl_up(incl, off, 64);
-            if ((t & 63) >= off) incl += u;
-        }
-        if ((t & 63) == 63) s_wtot[t >> 6] = incl;
         __syncthreads();
-        int run = incl - v;
-        for (int w = 0; w < (t >> 6); ++w) run += s_wtot[w];
-#pragma unroll
-        for (int j = 0; j < PER; ++j) { s_start[PER * t + j] = run; s_cur[PER * t + j] = run; run += cnt[j]; }
-        if (t == 0) s_start[BIG_NB] = n;
-    }
-    __syncthreads();
-    if (s_flag) {                                            // degenerate depth distribution: the merge launch sorts it
-        if (t == 0) degenerate[tile] = 1;
+        // 3. exact position inside the bucket, and out
+        for (int i = t; i < n; i += SORT_THREADS) {
+            const unsigned long long k = s_b[i];
+            const int b = bucket_of(k);
+            const int bs = bucket_start(b), be = s_cur[b];
+            int rank = 0;
+            for (int j = bs; j < be; ++j) rank += (s_b[j] < k) ? 1 : 0;
+            emit(start + bs + rank, k);
+        }
         return;
     }
-    if (t == 0) degenerate[tile] = 0;
     for (int i = t; i < n; i += SORT_THREADS) {
         const unsigned long long k = seg[i];
         grp[atomicAdd(&s_cur[bucket_of(k)], 1)] = k;
     }
     __syncthreads();                                         // the grouped keys are read back by other lanes below
+    unsigned long long *s_win = s_keys;
     int b0 = 0;
     while (b0 < BIG_NB) {
-        const int ws = s_start[b0];
+        const int ws = bucket_start(b0);
         if (ws >= n) break;                                  // only empty buckets are left
-        int lo = b0 + 1, hi = BIG_NB;                        // largest b1 with s_start[b1] - ws <= BIG_WIN (>= b0 + 1)
+        int lo = b0 + 1, hi = BIG_NB;                        // largest b1 with start(b1) - ws <= window (>= b0 + 1)
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (s_start[mid] - ws <= BIG_WIN) lo = mid; else hi = mid - 1;
+            if (s_cur[mid - 1] - ws <= CNT_MAXN) lo = mid; else hi = mid - 1;
         }
         const int b1 = lo;
-        const int len = s_start[b1] - ws;
+        const int len = s_cur[b1 - 1] - ws;
         for (int i = t; i < len; i += SORT_THREADS) s_win[i] = grp[ws + i];
         __syncthreads();
         for (int i = t; i < len; i += SORT_THREADS) {
             const unsigned long long k = s_win[i];
             const int b = bucket_of(k);
-            const int bs = s_start[b] - ws, be = s_start[b + 1] - ws;
+            const int bs = bucket_start(b) - ws, be = s_cur[b] - ws;
             int rank = 0;
             for (int j = bs; j < be; ++j) rank += (s_win[j] < k) ? 1 : 0;
-            const int64_t o = start + ws + bs + rank;
-            flatten_ids[o] = (int32_t)min((uint32_t)k, id_max);
-            if (isect_ids) isect_ids[o] = hi_part | (long long)(k >> 32);
+            emit(start + ws + bs + rank, k);
         }
         __syncthreads();
         b0 = b1;
@@ -757,8 +725,8 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
             hipLaunchKernelGGL(count_matrix_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4),
                                st, means2d, radii, N, tile_w, tile_h, (int)items, cnt);
             GSX_CHECK_LAUNCH();
-            hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, cnt, (int)gblocks,
-                               (int)n_tiles, (int)T, offsets);
+            hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((n_tiles + 63) / 64), (unsigned)C),
+                               dim3(64 * CS_GROUPS), 0, st, cnt, (int)gblocks, (int)n_tiles, offsets);
             GSX_CHECK_LAUNCH();
         } else {
             if (!gsx_zero_async(offsets, T, st)) return GSX_E_LAUNCH;
@@ -772,42 +740,32 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
         }
     }
     if (N > 0 && M_cap > 0) {
-        // Tile sizes are only known on the device (sync-free), so the sort runs as up to two launches over all tiles,
-        // each taking one size class and leaving the rest (an early exit): tiles of up to 2048 keys sort in a 32 KiB
-        // LDS window at full occupancy (4 workgroups of 8 wavefronts per CU); larger tiles get an 8192-key window
-        // (128 KiB, one workgroup per CU) and, beyond that, merge levels through global memory.  The second launch is
-        // skipped when the capacity says no tile can be that large.
+        // Tile sizes are only known on the device (sync-free): one launch over all tiles, each workgroup picks its
+        // regime from its tile's size.  GSX_TILE_SORT=merge (A/B): the merge sort in two size classes instead, tiles of
+        // up to 2048 keys in a 32 KiB LDS window, larger ones in an 8192-key window (128 KiB) + global merge levels.
         const int small_cap = 2048, big_cap = 8192;
         const uint32_t id_max = (uint32_t)(C * N - 1);
         const int tnb = bit_length((uint32_t)n_tiles);
         const char *ts = getenv("GSX_TILE_SORT");
-        if (ts && ts[0] == 'm')                              // A/B: the merge sort for the small class as well
+        if (ts && ts[0] == 'm') {
             hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), (size_t)(2 * small_cap * 8), st,
                                entries, scratch, offsets, (int)n_tiles, tnb, M_cap, small_cap, 0, small_cap, id_max,
-                               (const int32_t *)nullptr, isect_ids, flatten_ids);
-        else
-            hipLaunchKernelGGL(tile_sort_count_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, offsets,
-                               (int)n_tiles, tnb, M_cap, id_max, isect_ids, flatten_ids);
-        GSX_CHECK_LAUNCH();
-        if (M_cap > small_cap) {
-            // larger tiles: the streaming counting sort; what it flags as degenerate (and, under GSX_TILE_SORT=merge,
-            // every large tile) goes to the merge sort with an 8192-key LDS window (128 KiB of the CU's 160 KiB)
-            const bool merge_all = ts && ts[0] == 'm';
-            if (!merge_all) {
-                hipLaunchKernelGGL(tile_sort_count_big_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries,
-                                   scratch, offsets, (int)n_tiles, tnb, M_cap, small_cap, id_max, cursor, isect_ids,
-                                   flatten_ids);
-                GSX_CHECK_LAUNCH();
+                               isect_ids, flatten_ids);
+            GSX_CHECK_LAUNCH();
+            if (M_cap > small_cap) {
+                const size_t lds_bytes = (size_t)(2 * big_cap * 8);
+                if (hipFuncSetAttribute((const void *)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes) != hipSuccess) {
+                    gsx_set_error("gsx_isect_bin_sort: cannot raise the dynamic LDS limit to %zu bytes", lds_bytes);
+                    return GSX_E_LAUNCH;
+                }
+                hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), lds_bytes, st, entries,
+                                   scratch, offsets, (int)n_tiles, tnb, M_cap, big_cap, small_cap, 0x7fffffff, id_max,
+                                   isect_ids, flatten_ids);
             }
-            const size_t lds_bytes = (size_t)(2 * big_cap * 8);
-            if (hipFuncSetAttribute((const void *)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes) != hipSuccess) {
-                gsx_set_error("gsx_isect_bin_sort: cannot raise the dynamic LDS limit to %zu bytes", lds_bytes);
-                return GSX_E_LAUNCH;
-            }
-            hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), lds_bytes, st, entries, scratch,
-                               offsets, (int)n_tiles, tnb, M_cap, big_cap, small_cap, 0x7fffffff, id_max,
-                               merge_all ? (const int32_t *)nullptr : (const int32_t *)cursor, isect_ids, flatten_ids);
+        } else {
+            hipLaunchKernelGGL(tile_sort_count_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, scratch,
+                               offsets, (int)n_tiles, tnb, M_cap, id_max, isect_ids, flatten_ids);
         }
         GSX_CHECK_LAUNCH();
     }
