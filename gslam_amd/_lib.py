@@ -22,7 +22,7 @@ PROTOTYPES = {
     "gsx_record_stride": (i32, [i32]),
     "gsx_read_i64": (i32, [vp, C.POINTER(i64), vp]),
     "gsx_project_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp,
-                              i32, i32, vp, vp, vp, vp, vp, vp]),
+                              i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "gsx_project_bwd_workspace_bytes": (i64, [i64, i64]),
     "gsx_project_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, vp, i64, vp, vp, i64, vp,
                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
@@ -47,6 +47,10 @@ PROTOTYPES = {
     "gsx_map_loss": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp, vp, i64, vp]),
     "gsx_isotropic_workspace_bytes": (i64, [i64]),
     "gsx_isotropic_loss": (i32, [vp, vp, i64, f32, vp, vp, vp, i64, vp]),
+    "gsx_isotropic_loss_acc": (i32, [vp, vp, i64, f32, vp, vp, vp, i64, vp]),
+    "gsx_ssim_partials": (i64, [i64, i32, i32, i32]),
+    "gsx_loss_finish": (i32, [vp, i64, i32, i32, vp, i64, vp, i64, C.POINTER(f32), C.POINTER(f32), f32, f32, vp, vp, vp,
+                              vp]),
     "gsx_combine_terms": (i32, [i32, C.POINTER(vp), C.POINTER(f32), C.POINTER(f32), f32, f32, vp, vp]),
     "gsx_opacity_decay": (i32, [vp, vp, i64, i32, f32, vp]),
     "gsx_warp_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
@@ -59,6 +63,9 @@ PROTOTYPES = {
                              C.POINTER(f32), f32, f32, f32, i64, vp, vp]),
     "gsx_adam_multi_steps": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
                                    C.POINTER(f32), f32, f32, f32, C.POINTER(vp), vp]),
+    "gsx_adam_multi_steps_decay": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                         C.POINTER(i64), C.POINTER(f32), f32, f32, f32, C.POINTER(vp), i32, vp, i32, f32,
+                                         vp]),
     "gsx_counters_add": (i32, [i32, C.POINTER(vp), i64, vp]),
     "gsx_track_opt_state_bytes": (i64, []),
     "gsx_track_opt_init": (i32, [vp, i32, i32, f32, C.c_double, i32, i32, i32, C.c_double, C.c_double, vp]),

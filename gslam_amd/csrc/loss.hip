@@ -152,6 +152,7 @@ __global__ __launch_bounds__(LB) void map_loss_finish_kernel(const float *__rest
 }
 
 // isotropic regulariser (backend.py:287-296): sum over visible Gaussians of sum_j |exp(s_j) - exp(mean(s))|, mean detached
+template <bool ACC>
 __global__ __launch_bounds__(LB) void isotropic_kernel(const float *__restrict__ log_scales,
                                                        const int32_t *__restrict__ vis_count, int64_t N, float weight,
                                                        float *__restrict__ partials, float *__restrict__ v_log_scales) {
@@ -167,7 +168,13 @@ __global__ __launch_bounds__(LB) void isotropic_kernel(const float *__restrict__
             term = fabsf(e0 - m) + fabsf(e1 - m) + fabsf(e2 - m);
             v0 = weight * sgn(e0 - m) * e0; v1 = weight * sgn(e1 - m) * e1; v2 = weight * sgn(e2 - m) * e2;
         }
-        v_log_scales[3 * g] = v0; v_log_scales[3 * g + 1] = v1; v_log_scales[3 * g + 2] = v2;
+        if (ACC) {
+            if (v0 != 0.f || v1 != 0.f || v2 != 0.f) {
+                v_log_scales[3 * g] += v0; v_log_scales[3 * g + 1] += v1; v_log_scales[3 * g + 2] += v2;
+            }
+        } else {
+            v_log_scales[3 * g] = v0; v_log_scales[3 * g + 1] = v1; v_log_scales[3 * g + 2] = v2;
+        }
     }
     const float tot = gsx_wave_sum(term);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = tot;
@@ -206,6 +213,58 @@ __global__ void combine_kernel(CombineArgs a, float *out) {
     out[1] = o1;
 }
 
+// Finishing kernel of a whole loss block: every producer above leaves one partial row per workgroup, and the separate
+// one-workgroup reductions (map_loss_finish, the SSIM and isotropic partial sums, combine) each cost a ~4.5 us launch
+// of their own in the replayed step.  Here the 16 wavefronts of one workgroup take the reductions round-robin
+// (3 photometric sums, 2 exposure gradients per camera, SSIM, isotropic), then lane 0 forms the two linear forms.
+struct FinishArgs {
+    const float *map_part;   // [C * bpc][NPART]
+    const float *ssim_part;  // [n_ssim] or null
+    const float *iso_part;   // [n_iso] or null
+    float *sums5;            // raw sums: photometric, log-beta, tv, ssim, iso (nullable)
+    float *v_exposure;       // [C, 2] (nullable)
+    float *out2;
+    int C, bpc;
+    int64_t n_ssim, n_iso;
+    float c0[5], c1[5], bias0, bias1;
+};
+constexpr int FIN_WAVES = 16;
+
+__global__ __launch_bounds__(64 * FIN_WAVES) void loss_finish_kernel(FinishArgs a) {
+    __shared__ float s_sum[5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 5) s_sum[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int n_jobs = 5 + 2 * a.C;
+    for (int j = wave; j < n_jobs; j += FIN_WAVES) {
+        float acc = 0.f;
+        if (j < 3) {
+            const int64_t rows = (int64_t)a.C * a.bpc;
+            for (int64_t i = lane; i < rows; i += 64) acc += a.map_part[i * NPART + j];
+        } else if (j == 3) {
+            if (a.ssim_part) for (int64_t i = lane; i < a.n_ssim; i += 64) acc += a.ssim_part[i];
+        } else if (j == 4) {
+            if (a.iso_part) for (int64_t i = lane; i < a.n_iso; i += 64) acc += a.iso_part[i];
+        } else {
+            const int c = (j - 5) >> 1, k = 3 + ((j - 5) & 1);
+            for (int i = lane; i < a.bpc; i += 64) acc += a.map_part[((int64_t)c * a.bpc + i) * NPART + k];
+        }
+        const float tot = gsx_wave_sum(acc);
+        if (lane == 0) {
+            if (j < 5) s_sum[j] = tot;
+            else if (a.v_exposure) a.v_exposure[j - 5] = tot;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float o0 = a.bias0, o1 = a.bias1;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { o0 += a.c0[k] * s_sum[k]; o1 += a.c1[k] * s_sum[k]; }
+        a.out2[0] = o0; a.out2[1] = o1;
+    }
+    if (threadIdx.x < 5 && a.sums5) a.sums5[threadIdx.x] = s_sum[threadIdx.x];
+}
+
 __global__ __launch_bounds__(LB) void opacity_decay_kernel(float *__restrict__ logit_opac,
                                                            const int32_t *__restrict__ vis_count, int64_t N,
                                                            int min_count, float decay) {
@@ -224,7 +283,7 @@ extern "C" int gsx_map_loss(const float *render, const float *alphas, const floa
                             int H, int W, int CH, int depth_index, int beta_index, int mode, float w_photo, float w_tv,
                             float mask_thresh, const float *ssim_grad, float *sums, float *v_render, float *v_exposure,
                             void *workspace, int64_t workspace_bytes, void *stream) {
-    GSX_CHECK_ARG(render && gt && exposure && sums && v_render && C >= 1 && H > 0 && W > 0 && CH >= 3);
+    GSX_CHECK_ARG(render && gt && exposure && v_render && C >= 1 && H > 0 && W > 0 && CH >= 3);
     GSX_CHECK_ARG(mode >= 0 && mode <= 2);
     GSX_CHECK_ARG(mode == 1 || (beta_index >= 3 && beta_index < CH));
     GSX_CHECK_ARG(w_tv == 0.f || (alphas && depth_index >= 3 && depth_index < CH));
@@ -242,6 +301,7 @@ extern "C" int gsx_map_loss(const float *render, const float *alphas, const floa
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(map_loss_kernel, dim3(blocks, (unsigned)C), dim3(LB), 0, st, A);
     GSX_CHECK_LAUNCH();
+    if (!sums) return GSX_OK;                                // deferred: gsx_loss_finish reads the partial rows
     hipLaunchKernelGGL(map_loss_finish_kernel, dim3(1), dim3(LB), 0, st, (const float *)workspace, (int)C, (int)blocks,
                        sums, v_exposure);
     GSX_CHECK_LAUNCH();
@@ -252,13 +312,13 @@ extern "C" int64_t gsx_isotropic_workspace_bytes(int64_t N) {
     return gsx_align256(((N + LB - 1) / LB) * (int64_t)sizeof(float)) + 256;
 }
 
-extern "C" int gsx_isotropic_loss(const float *log_scales, const int32_t *vis_count, int64_t N, float weight,
-                                  float *sum_out, float *v_log_scales, void *workspace, int64_t workspace_bytes,
-                                  void *stream) {
-    GSX_CHECK_ARG(log_scales && vis_count && sum_out && v_log_scales && N >= 0);
+static int isotropic_launch(const float *log_scales, const int32_t *vis_count, int64_t N, float weight, float *sum_out,
+                            float *v_log_scales, bool accumulate, void *workspace, int64_t workspace_bytes,
+                            void *stream) {
+    GSX_CHECK_ARG(log_scales && vis_count && v_log_scales && N >= 0);
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) {
-        if (!gsx_zero_async(sum_out, 1, st)) return GSX_E_LAUNCH;
+        if (sum_out && !gsx_zero_async(sum_out, 1, st)) return GSX_E_LAUNCH;
         return GSX_OK;
     }
     if (!workspace || workspace_bytes < gsx_isotropic_workspace_bytes(N)) {
@@ -266,10 +326,51 @@ extern "C" int gsx_isotropic_loss(const float *log_scales, const int32_t *vis_co
         return GSX_E_WORKSPACE;
     }
     const unsigned blocks = (unsigned)((N + LB - 1) / LB);
-    hipLaunchKernelGGL(isotropic_kernel, dim3(blocks), dim3(LB), 0, st, log_scales, vis_count, N, weight,
-                       (float *)workspace, v_log_scales);
+    if (accumulate)
+        hipLaunchKernelGGL(isotropic_kernel<true>, dim3(blocks), dim3(LB), 0, st, log_scales, vis_count, N, weight,
+                           (float *)workspace, v_log_scales);
+    else
+        hipLaunchKernelGGL(isotropic_kernel<false>, dim3(blocks), dim3(LB), 0, st, log_scales, vis_count, N, weight,
+                           (float *)workspace, v_log_scales);
     GSX_CHECK_LAUNCH();
+    if (!sum_out) return GSX_OK;                             // deferred: gsx_loss_finish reads the partials
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(LB), 0, st, (const float *)workspace, (int64_t)blocks, sum_out);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_isotropic_loss(const float *log_scales, const int32_t *vis_count, int64_t N, float weight,
+                                  float *sum_out, float *v_log_scales, void *workspace, int64_t workspace_bytes,
+                                  void *stream) {
+    return isotropic_launch(log_scales, vis_count, N, weight, sum_out, v_log_scales, false, workspace, workspace_bytes,
+                            stream);
+}
+
+extern "C" int gsx_isotropic_loss_acc(const float *log_scales, const int32_t *vis_count, int64_t N, float weight,
+                                      float *sum_out, float *v_log_scales, void *workspace, int64_t workspace_bytes,
+                                      void *stream) {
+    return isotropic_launch(log_scales, vis_count, N, weight, sum_out, v_log_scales, true, workspace, workspace_bytes,
+                            stream);
+}
+
+extern "C" int gsx_loss_finish(const void *map_loss_ws, int64_t C, int H, int W, const void *ssim_ws,
+                               int64_t ssim_partials, const void *iso_ws, int64_t N, const float *coef0,
+                               const float *coef1, float bias0, float bias1, float *sums5, float *v_exposure,
+                               float *out2, void *stream) {
+    GSX_CHECK_ARG(map_loss_ws && C >= 1 && C < 65536 && H > 0 && W > 0 && coef0 && coef1 && out2);
+    GSX_CHECK_ARG(ssim_partials >= 0 && N >= 0);
+    FinishArgs a;
+    a.map_part = (const float *)map_loss_ws;
+    a.ssim_part = ssim_partials > 0 ? (const float *)ssim_ws : nullptr;
+    a.iso_part = N > 0 ? (const float *)iso_ws : nullptr;
+    GSX_CHECK_ARG(ssim_partials == 0 || ssim_ws);
+    a.sums5 = sums5; a.v_exposure = v_exposure; a.out2 = out2;
+    a.C = (int)C; a.bpc = (int)(((int64_t)H * W + LB - 1) / LB);
+    a.n_ssim = ssim_partials; a.n_iso = iso_ws ? (N + LB - 1) / LB : 0;
+    if (!iso_ws) a.iso_part = nullptr;
+    for (int k = 0; k < 5; ++k) { a.c0[k] = coef0[k]; a.c1[k] = coef1[k]; }
+    a.bias0 = bias0; a.bias1 = bias1;
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64 * FIN_WAVES), 0, (hipStream_t)stream, a);
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }

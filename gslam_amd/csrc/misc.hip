@@ -215,6 +215,12 @@ struct AdamArgs {
     int per_tensor;
     int count;
     float beta1, beta2, eps, bc2_sqrt;
+    // optional post-update decay of one tensor: p *= decay where decay_mask[j] > decay_min (the opacity decay of
+    // gslam/backend.py:356-359 folded into the update that precedes it: one launch and one pass over the tensor less)
+    int decay_k;
+    int decay_min;
+    float decay;
+    const int32_t *decay_mask;
 };
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
@@ -247,7 +253,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
         v = a.beta2 * v + (1.0f - a.beta2) * grad * grad;
         const float denom = sqrtf(v) / bc2_sqrt + a.eps;
         const float step_size = a.step_dev ? a.lr[k] / bc1 : a.step_size[k];
-        a.p[k][j] -= (step_size * m) / denom;
+        float p = a.p[k][j] - (step_size * m) / denom;
+        if (k == a.decay_k && a.decay_mask[j] > a.decay_min) p *= a.decay;
+        a.p[k][j] = p;
         a.m[k][j] = m;
         a.v[k][j] = v;
     }
@@ -316,8 +324,11 @@ extern "C" int gsx_sh_bwd(int degree, const float *dirs, const float *coeffs, co
 
 static int adam_launch(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                        float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1, float beta2,
-                       float eps, int64_t step_host, const int64_t *step_dev, const int64_t *const *steps, void *stream) {
+                       float eps, int64_t step_host, const int64_t *step_dev, const int64_t *const *steps, void *stream,
+                       int decay_tensor = -1, const int32_t *decay_mask = nullptr, int decay_min = 0,
+                       float decay = 1.0f) {
     GSX_CHECK_ARG(n_tensors >= 1 && n_tensors <= ADAM_MAX && params && grads && exp_avg && exp_avg_sq && numels && lrs);
+    GSX_CHECK_ARG(decay_tensor < n_tensors && (decay_tensor < 0 || decay_mask));
     GSX_CHECK_ARG(step_host >= 1 || step_dev || steps);
     AdamArgs a;
     a.count = n_tensors;
@@ -338,6 +349,7 @@ static int adam_launch(int n_tensors, float *const *params, const float *const *
         if (in) GSX_CHECK_ARG(numels[k] >= 1 && params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k]);
     }
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.bc2_sqrt = (float)sqrt(bc2);
+    a.decay_k = decay_tensor < 0 ? -1 : decay_tensor; a.decay_mask = decay_mask; a.decay_min = decay_min; a.decay = decay;
     const int64_t total = a.start[n_tensors];
     int64_t blocks = (total + 255) / 256;
     if (blocks > 2048 * 4) blocks = 2048 * 4;
@@ -360,6 +372,16 @@ extern "C" int gsx_adam_multi_steps(int n_tensors, float *const *params, const f
     GSX_CHECK_ARG(steps);
     return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, lrs, beta1, beta2, eps, 0, nullptr, steps,
                        stream);
+}
+
+extern "C" int gsx_adam_multi_steps_decay(int n_tensors, float *const *params, const float *const *grads,
+                                          float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numels,
+                                          const float *lrs, float beta1, float beta2, float eps,
+                                          const int64_t *const *steps, int decay_tensor, const int32_t *decay_mask,
+                                          int decay_min_count, float decay, void *stream) {
+    GSX_CHECK_ARG(steps);
+    return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, lrs, beta1, beta2, eps, 0, nullptr, steps,
+                       stream, decay_tensor, decay_mask, decay_min_count, decay);
 }
 
 extern "C" int gsx_counters_add(int n, int64_t *const *counters, int64_t delta, void *stream) {

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     float *__restrict__ means2d, float *__restrict__ depths, float *__restrict__ conics, float *__restrict__ comps,
     int32_t *__restrict__ tiles_per_gauss, int tile_w, int tile_h, const float *__restrict__ logit_opacities,
     const float *__restrict__ logit_colors, const float *__restrict__ log_unc, float *__restrict__ rec,
-    int32_t *__restrict__ vis_count) {
+    int32_t *__restrict__ vis_count, float *__restrict__ v_rec_clear) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     int n_vis = 0;
@@ -242,6 +242,10 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             reinterpret_cast<float4 *>(r)[0] = a;
             reinterpret_cast<float4 *>(r)[1] = b4;
             reinterpret_cast<float4 *>(r)[2] = c4;
+            if (v_rec_clear) {                               // the backward's accumulation rows, cleared while we are here
+                float4 *z = reinterpret_cast<float4 *>(v_rec_clear + idx * RS);
+                z[0] = z[1] = z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
     if (vis_count) vis_count[g] = n_vis;
@@ -519,8 +523,10 @@ extern "C" int gsx_project_fwd(const float *means, const float *quats, const flo
                                float far_plane, float radius_clip, int flags, int32_t *radii, float *means2d,
                                float *depths, float *conics, float *comps, int32_t *tiles_per_gauss, int tile_w,
                                int tile_h, const float *logit_opacities, const float *logit_colors,
-                               const float *log_uncertainties, float *rec, int32_t *vis_count, void *stream) {
+                               const float *log_uncertainties, float *rec, int32_t *vis_count, float *v_rec_clear,
+                               void *stream) {
     GSX_CHECK_ARG(N >= 0 && C >= 1 && W > 0 && H > 0);
+    GSX_CHECK_ARG(!v_rec_clear || rec);
     GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && radii && means2d && depths && conics);
     if (rec) {
         GSX_CHECK_ARG(logit_opacities && logit_colors);
@@ -535,12 +541,12 @@ extern "C" int gsx_project_fwd(const float *means, const float *quats, const flo
         hipLaunchKernelGGL((project_fwd_kernel<12>), dim3(blocks), dim3(threads), 0, st, means, quats, scales,
                            viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, radius_clip, flags, radii,
                            means2d, depths, conics, comps, tiles_per_gauss, tile_w, tile_h, logit_opacities,
-                           logit_colors, log_uncertainties, rec, vis_count);
+                           logit_colors, log_uncertainties, rec, vis_count, v_rec_clear);
     else
         hipLaunchKernelGGL((project_fwd_kernel<0>), dim3(blocks), dim3(threads), 0, st, means, quats, scales,
                            viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, radius_clip, flags, radii,
                            means2d, depths, conics, comps, tiles_per_gauss, tile_w, tile_h, logit_opacities,
-                           logit_colors, log_uncertainties, rec, vis_count);
+                           logit_colors, log_uncertainties, rec, vis_count, v_rec_clear);
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }

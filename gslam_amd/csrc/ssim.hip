@@ -205,11 +205,15 @@ extern "C" int64_t gsx_ssim_workspace_bytes(int64_t B, int CH, int H, int W) {
     return gsx_align256(blocks * (int64_t)sizeof(float)) + 256;
 }
 
+extern "C" int64_t gsx_ssim_partials(int64_t B, int CH, int H, int W) {
+    return B * CH * ((H + TSY - 1) / TSY) * ((W + TSX - 1) / TSX);
+}
+
 extern "C" int gsx_ssim_fwd(const float *img1, const float *img2, int64_t B, int CH, int H, int W,
                             const int64_t *strides1, const int64_t *strides2, int crop, float *out_sum,
                             float *dm_dmu1, float *dm_dsigma1_sq, float *dm_dsigma12, void *workspace,
                             int64_t workspace_bytes, void *stream) {
-    GSX_CHECK_ARG(img1 && img2 && strides1 && strides2 && out_sum && B >= 1 && CH >= 1 && H > 0 && W > 0);
+    GSX_CHECK_ARG(img1 && img2 && strides1 && strides2 && B >= 1 && CH >= 1 && H > 0 && W > 0);
     GSX_CHECK_ARG(crop >= 0 && H > 2 * crop && W > 2 * crop);
     GSX_CHECK_ARG((dm_dmu1 == nullptr) == (dm_dsigma1_sq == nullptr) && (dm_dmu1 == nullptr) == (dm_dsigma12 == nullptr));
     GSX_CHECK_ARG(B * CH < 65536);
@@ -225,6 +229,7 @@ extern "C" int gsx_ssim_fwd(const float *img1, const float *img2, int64_t B, int
     hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, st, img1, img2, CH, H, W, s1, s2, crop, partials, dm_dmu1,
                        dm_dsigma1_sq, dm_dsigma12);
     GSX_CHECK_LAUNCH();
+    if (!out_sum) return GSX_OK;                             // deferred: gsx_loss_finish sums the gsx_ssim_partials() floats
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, partials,
                        (int64_t)grid.x * grid.y * grid.z, out_sum);
     GSX_CHECK_LAUNCH();

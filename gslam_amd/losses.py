@@ -20,76 +20,83 @@ from .ssim import _strides
 
 
 def loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo, w_ssim, w_iso,
-                   w_tv, mode):
+                   w_tv, mode, backward_fn=None, iso_grad_fn=None):
     """Raw fused block (no autograd): returns (out2, v_render, v_exposure, v_log_scales) where out2[0] = total =
     w_photo * photometric + w_ssim * (1 - ssim) + w_iso * isotropic + w_tv * tv and out2[1] = photometric, all on the
-    device; the v_* are d total / d input."""
+    device; the v_* are d total / d input.
+
+    backward_fn(v_render): called as soon as the gradient of the render exists (the caller's render backward), before the
+    isotropic term; iso_grad_fn() then returns the [N,3] gradient tensor the isotropic term is ADDED to in place (the
+    returned v_log_scales is None in that case).  v_exposure is filled by the finishing launch at the end."""
     with torch.no_grad():
         render, gt = render.detach().contiguous(), gt.contiguous()
         exposure = exposure.detach()
         if log_scales is not None:
             log_scales = log_scales.detach()
         return _loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo,
-                               w_ssim, w_iso, w_tv, mode)
+                               w_ssim, w_iso, w_tv, mode, backward_fn, iso_grad_fn)
 
 
 def _loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo, w_ssim, w_iso,
-                    w_tv, mode):
-    if True:
-        exposure = exposure.contiguous()
-        Cn, H, W, CH = render.shape
-        dev = render.device
-        st = stream_ptr(dev)
-        n_px = Cn * H * W
-        sums = torch.empty(3, dtype=torch.float32, device=dev)
-        ssim_sum = torch.empty(1, dtype=torch.float32, device=dev) if w_ssim != 0.0 else None
-        iso_sum = None
-        v_render = torch.empty_like(render)
-        v_exposure = torch.empty_like(exposure)
-        ssim_grad = None
-        numel_ssim = Cn * 3 * (H - 10) * (W - 10)
-        if w_ssim != 0.0:
-            # fused_ssim(outputs.rgbs NCHW-view, gt NCHW-view, 'valid') straight on the NHWC buffers (backend.py:303-307)
-            s_r = (C.c_int64 * 4)(H * W * CH, 1, W * CH, CH)
-            s_g = (C.c_int64 * 4)(H * W * 3, 1, W * 3, 3)
-            dm = torch.empty(3, Cn, 3, H, W, dtype=torch.float32, device=dev)
-            ws = workspace(lib.gsx_ssim_workspace_bytes(Cn, 3, H, W), dev, "ssim")
-            check(lib.gsx_ssim_fwd(ptr(render), ptr(gt), Cn, 3, H, W, s_r, s_g, 5, ptr(ssim_sum), ptr(dm[0]), ptr(dm[1]),
-                                   ptr(dm[2]), ptr(ws), ws.numel(), st), "gsx_ssim_fwd")
-            ssim_grad = torch.empty(Cn, 3, H, W, dtype=torch.float32, device=dev)
-            one = _ones(dev)
-            check(lib.gsx_ssim_bwd(ptr(render), ptr(gt), Cn, 3, H, W, s_r, s_g, 5, ptr(dm[0]), ptr(dm[1]), ptr(dm[2]),
-                                   ptr(one), -w_ssim / numel_ssim, ptr(ssim_grad), st), "gsx_ssim_bwd")
-        denom = n_px * (3 if mode == 1 else 1)
-        ws = workspace(lib.gsx_map_loss_workspace_bytes(Cn, H, W), dev, "map_loss")
-        check(lib.gsx_map_loss(ptr(render), ptr(alphas.contiguous()) if alphas is not None else None, ptr(gt),
-                               ptr(exposure), Cn, H, W, CH, depth_index, beta_index, mode, w_photo / denom, w_tv, 0.4,
-                               ptr(ssim_grad), ptr(sums), ptr(v_render), ptr(v_exposure), ptr(ws), ws.numel(), st),
-              "gsx_map_loss")
-        v_scales = None
-        if w_iso != 0.0 and log_scales is not None:
-            log_scales = log_scales.contiguous()
+                    w_tv, mode, backward_fn=None, iso_grad_fn=None):
+    exposure = exposure.contiguous()
+    Cn, H, W, CH = render.shape
+    dev = render.device
+    st = stream_ptr(dev)
+    n_px = Cn * H * W
+    v_render = torch.empty_like(render)
+    v_exposure = torch.empty_like(exposure)
+    ssim_grad = None
+    ssim_ws, n_ssim = None, 0
+    numel_ssim = Cn * 3 * (H - 10) * (W - 10)
+    # every producer leaves its per-workgroup partial sums in its workspace; one launch finishes them all at the end
+    if w_ssim != 0.0:
+        # fused_ssim(outputs.rgbs NCHW-view, gt NCHW-view, 'valid') straight on the NHWC buffers (backend.py:303-307)
+        s_r = (C.c_int64 * 4)(H * W * CH, 1, W * CH, CH)
+        s_g = (C.c_int64 * 4)(H * W * 3, 1, W * 3, 3)
+        dm = torch.empty(3, Cn, 3, H, W, dtype=torch.float32, device=dev)
+        ssim_ws = workspace(lib.gsx_ssim_workspace_bytes(Cn, 3, H, W), dev, "ssim")
+        n_ssim = lib.gsx_ssim_partials(Cn, 3, H, W)
+        check(lib.gsx_ssim_fwd(ptr(render), ptr(gt), Cn, 3, H, W, s_r, s_g, 5, None, ptr(dm[0]), ptr(dm[1]),
+                               ptr(dm[2]), ptr(ssim_ws), ssim_ws.numel(), st), "gsx_ssim_fwd")
+        ssim_grad = torch.empty(Cn, 3, H, W, dtype=torch.float32, device=dev)
+        one = _ones(dev)
+        check(lib.gsx_ssim_bwd(ptr(render), ptr(gt), Cn, 3, H, W, s_r, s_g, 5, ptr(dm[0]), ptr(dm[1]), ptr(dm[2]),
+                               ptr(one), -w_ssim / numel_ssim, ptr(ssim_grad), st), "gsx_ssim_bwd")
+    denom = n_px * (3 if mode == 1 else 1)
+    map_ws = workspace(lib.gsx_map_loss_workspace_bytes(Cn, H, W), dev, "map_loss")
+    check(lib.gsx_map_loss(ptr(render), ptr(alphas.contiguous()) if alphas is not None else None, ptr(gt),
+                           ptr(exposure), Cn, H, W, CH, depth_index, beta_index, mode, w_photo / denom, w_tv, 0.4,
+                           ptr(ssim_grad), None, ptr(v_render), None, ptr(map_ws), map_ws.numel(), st),
+          "gsx_map_loss")
+    if backward_fn is not None:
+        backward_fn(v_render)
+    v_scales = None
+    iso_ws, n_iso = None, 0
+    if w_iso != 0.0 and log_scales is not None:
+        log_scales = log_scales.contiguous()
+        n_iso = log_scales.shape[0]
+        iso_ws = workspace(lib.gsx_isotropic_workspace_bytes(n_iso), dev, "iso")
+        into = iso_grad_fn() if iso_grad_fn is not None else None
+        if into is not None:
+            if not (into.is_contiguous() and into.shape == log_scales.shape and into.dtype == torch.float32):
+                raise RuntimeError("iso_grad_fn must return a contiguous float32 [N,3] gradient")
+            check(lib.gsx_isotropic_loss_acc(ptr(log_scales), ptr(vis_count.contiguous()), n_iso, w_iso, None,
+                                             ptr(into), ptr(iso_ws), iso_ws.numel(), st), "gsx_isotropic_loss_acc")
+        else:
             v_scales = torch.empty_like(log_scales)
-            iso_sum = torch.empty(1, dtype=torch.float32, device=dev)
-            N = log_scales.shape[0]
-            ws = workspace(lib.gsx_isotropic_workspace_bytes(N), dev, "iso")
-            check(lib.gsx_isotropic_loss(ptr(log_scales), ptr(vis_count.contiguous()), N, w_iso, ptr(iso_sum),
-                                         ptr(v_scales), ptr(ws), ws.numel(), st), "gsx_isotropic_loss")
-        # total / photometric from the raw sums, on device
-        out2 = torch.empty(2, dtype=torch.float32, device=dev)
-        pm = 1.0 / denom
-        # (device scalar, weight in the total, weight in the photometric value); absent terms are simply not passed
-        parts = [(sums[0:1], w_photo * pm, pm), (sums[1:2], w_photo * pm, pm), (sums[2:3], w_tv, 0.0)]
-        if ssim_sum is not None:
-            parts.append((ssim_sum, -w_ssim / numel_ssim, 0.0))
-        if iso_sum is not None:
-            parts.append((iso_sum, w_iso, 0.0))
-        n = len(parts)
-        terms = (C.c_void_p * n)(*[p[0].data_ptr() for p in parts])
-        c0 = (C.c_float * n)(*[p[1] for p in parts])
-        c1 = (C.c_float * n)(*[p[2] for p in parts])
-        check(lib.gsx_combine_terms(n, terms, c0, c1, w_ssim, 0.0, ptr(out2), st), "gsx_combine_terms")
-        return out2, v_render, v_exposure, v_scales
+            check(lib.gsx_isotropic_loss(ptr(log_scales), ptr(vis_count.contiguous()), n_iso, w_iso, None,
+                                         ptr(v_scales), ptr(iso_ws), iso_ws.numel(), st), "gsx_isotropic_loss")
+    # total / photometric from the raw sums (photometric, log-beta, tv, ssim, isotropic), on the device
+    out2 = torch.empty(2, dtype=torch.float32, device=dev)
+    pm = 1.0 / denom
+    c0 = (C.c_float * 5)(w_photo * pm, w_photo * pm, w_tv, -w_ssim / numel_ssim if n_ssim else 0.0,
+                         w_iso if iso_ws is not None else 0.0)
+    c1 = (C.c_float * 5)(pm, pm, 0.0, 0.0, 0.0)
+    check(lib.gsx_loss_finish(ptr(map_ws), Cn, H, W, ptr(ssim_ws) if n_ssim else None, n_ssim,
+                              ptr(iso_ws) if iso_ws is not None else None, n_iso, c0, c1, w_ssim if n_ssim else 0.0,
+                              0.0, None, ptr(v_exposure), ptr(out2), st), "gsx_loss_finish")
+    return out2, v_render, v_exposure, v_scales
 
 
 class _FusedMappingLoss(torch.autograd.Function):
@@ -141,16 +148,19 @@ def fused_mapping_loss(outputs, gt_imgs: Tensor, exposure_params: Tensor, log_sc
 
 def mapping_loss_and_grads(outputs, gt_imgs: Tensor, exposure_params: Tensor, log_scales: Tensor, *, ssim_weight: float,
                            iso_weight: float, tv_weight: float, active_gs: bool = True, shard: float = 1.0,
-                           iso_scale: float = 1.0, vis_count: Optional[Tensor] = None):
+                           iso_scale: float = 1.0, vis_count: Optional[Tensor] = None, backward_fn=None,
+                           iso_grad_fn=None):
     """Same numbers as fused_mapping_loss without the autograd node: (out2[total, photometric], v_render, v_exposure,
-    v_log_scales).  The caller seeds the backward with ``torch.autograd.backward([outputs._render], [v_render])``."""
+    v_log_scales).  The caller seeds the backward with ``torch.autograd.backward([outputs._render], [v_render])``, or
+    passes it as ``backward_fn`` (see loss_and_grads) to have the isotropic term added into the scale gradient in
+    place."""
     if vis_count is None:
         vis_count = outputs._vis_count
     return loss_and_grads(outputs._render, outputs.alphas, gt_imgs, exposure_params, log_scales, vis_count,
                           -1 if outputs._depth_index is None else outputs._depth_index,
                           -1 if outputs._betas_index is None else outputs._betas_index,
                           shard * (1.0 - ssim_weight), shard * ssim_weight, iso_scale * iso_weight, tv_weight,
-                          0 if active_gs else 1)
+                          0 if active_gs else 1, backward_fn, iso_grad_fn)
 
 
 def tracking_loss_and_grads(outputs, gt_img: Tensor, exposure_params: Tensor):

@@ -17,7 +17,7 @@ from . import dist as gdist
 from ._lib import check, lib, ptr, stream_ptr
 from .losses import fused_mapping_loss, mapping_loss_and_grads
 from .map import GaussianSplattingData
-from .optim import FusedAdam
+from .optim import FusedAdam, step_all
 from .primitives import Frame
 from .rasterization import RasterizationOutput
 from .ssim import fused_ssim
@@ -105,10 +105,11 @@ class MapOptimizers:
         if self.pose_opt is not None:
             self.pose_opt.zero_grad(set_to_none=True)
 
-    def step(self):
-        self.splat_opt.step()
-        if self.pose_opt is not None:
-            self.pose_opt.step()
+    def step(self, decay=None) -> bool:
+        """one launch for the step counters, one multi-tensor launch per (betas, eps) class for splats and poses
+        together; returns whether ``decay`` (see optim.step_all) was applied by the update"""
+        opts = [self.splat_opt] + ([self.pose_opt] if self.pose_opt is not None else [])
+        return step_all(opts, decay)
 
 
 class BundleAdjuster:
@@ -161,17 +162,21 @@ class BundleAdjuster:
         exposure = create_batch(mine, lambda f: f.exposure_params)
         outputs = self.splats(cameras, poses, render_depth=True, need_n_touched=self.need_n_touched)
         vis_count = outputs._vis_count                                  # = (radii > 0).sum(0), from K1
-        outputs.means2d.retain_grad()                                   # backend.py:326
+        # backend.py:326 means2d.retain_grad(): the rasteriser's backward hands the same values over as a view of its
+        # gradient records (no copy kernel)
+        outputs.means2d._gsx_share_grad = True
         if self.fused_loss:
-            # value and analytic gradient in one pass (csrc/loss.hip); the backward is seeded at the render tensor.
+            # value and analytic gradient in one pass (csrc/loss.hip); the backward is seeded at the render tensor and
+            # runs as soon as that gradient exists, so that the isotropic term can be added into scales.grad in place.
             # Multi-GPU: the isotropic term needs the window-wide visibility, so it moves behind the all-reduce.
             out2, v_render, v_exposure, v_scales = mapping_loss_and_grads(
                 outputs, gt_imgs, exposure, self.splats.scales, ssim_weight=conf.ssim_weight,
                 iso_weight=0.0 if multi else conf.isotropic_regularization_weight,
                 tv_weight=conf.depth_regularization_weight if regularize else 0.0, active_gs=conf.active_gs,
-                shard=len(mine) / float(len(window)), vis_count=vis_count)
+                shard=len(mine) / float(len(window)), vis_count=vis_count,
+                backward_fn=lambda v: torch.autograd.backward([outputs._render], [v]),
+                iso_grad_fn=lambda: self.splats.scales.grad)
             total, photometric = out2[0], out2[1]
-            torch.autograd.backward([outputs._render], [v_render])
             if v_scales is not None:
                 self.splats.scales.grad.add_(v_scales)
             for i, f in enumerate(mine):
@@ -203,17 +208,17 @@ class BundleAdjuster:
             if w != 0.0:                                                # identical on every rank (replicated map)
                 sc = self.splats.scales
                 N = sc.shape[0]
-                v_scales = torch.empty_like(sc)
-                iso_sum = torch.empty(1, dtype=torch.float32, device=sc.device)
                 from .ops import workspace
                 ws = workspace(lib.gsx_isotropic_workspace_bytes(N), sc.device, "iso")
-                check(lib.gsx_isotropic_loss(ptr(sc.data), ptr(vis_count), N, w, ptr(iso_sum), ptr(v_scales), ptr(ws),
-                                             ws.numel(), stream_ptr(sc.device)), "gsx_isotropic_loss")
-                sc.grad.add_(v_scales)
-        self.optimizers.step()
-        if decay_opacity:
-            with torch.no_grad():                                       # backend.py:356-359
-                op = self.splats.opacities
+                check(lib.gsx_isotropic_loss_acc(ptr(sc.data), ptr(vis_count), N, w, None, ptr(sc.grad), ptr(ws),
+                                                 ws.numel(), stream_ptr(sc.device)), "gsx_isotropic_loss_acc")
+        # backend.py:356-359: opacities of Gaussians seen by more than one camera decay after the update; the masked
+        # multiply rides in the Adam launch when that launch is device-stepped (graph-capturable)
+        op = self.splats.opacities
+        decay = (op, vis_count.contiguous(), 1, conf.opacity_decay) if (decay_opacity and op.grad is not None) else None
+        done = self.optimizers.step(decay) and decay is not None
+        if decay_opacity and not done:
+            with torch.no_grad():
                 check(lib.gsx_opacity_decay(ptr(op.data), ptr(vis_count), op.shape[0], 1, conf.opacity_decay,
                                             stream_ptr(op.device)), "gsx_opacity_decay")
 

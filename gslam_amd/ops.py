@@ -63,7 +63,11 @@ class _Projection(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, viewmats, Ks, logit_opac, logit_colors, log_unc, width, height, eps2d,
-                near_plane, far_plane, radius_clip, calc_comp, flags, want_rec, want_tiles, want_vis=False):
+                near_plane, far_plane, radius_clip, calc_comp, flags, want_rec, want_tiles, want_vis=False,
+                v_rec_clear=None):
+        """v_rec_clear: an (uninitialised) [C,N,12] buffer the kernel clears on the way: the rasteriser's backward
+        accumulates its gradient records into it (pass the same tensor to _RasterizeRecords), which saves the separate
+        zero-fill launch in front of every backward."""
         means, quats, scales = _f32c(means, "means"), _f32c(quats, "quats"), _f32c(scales, "scales")
         viewmats, Ks = _f32c(viewmats, "viewmats"), _f32c(Ks, "Ks")
         N, Cn = means.shape[0], viewmats.shape[0]
@@ -85,7 +89,8 @@ class _Projection(torch.autograd.Function):
         check(lib.gsx_project_fwd(ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), N, Cn, width, height,
                                   eps2d, near_plane, far_plane, radius_clip, flags, ptr(radii), ptr(means2d),
                                   ptr(depths), ptr(conics), ptr(comps), ptr(tiles), tile_w, tile_h, ptr(logit_opac),
-                                  ptr(logit_colors), ptr(log_unc), ptr(rec), ptr(vis), stream_ptr(dev)), "gsx_project_fwd")
+                                  ptr(logit_colors), ptr(log_unc), ptr(rec), ptr(vis),
+                                  ptr(v_rec_clear) if want_rec else None, stream_ptr(dev)), "gsx_project_fwd")
         ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii,
                               logit_opac if want_rec else None, logit_colors if want_rec else None,
                               log_unc if want_rec else None)
@@ -101,7 +106,7 @@ class _Projection(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, v_rec, _v_tiles, _v_vis):
         if v_means2d is None and v_depths is None and v_conics is None and v_comps is None and v_rec is None:
-            return (None,) * 19
+            return (None,) * 20
         means, quats, scales, viewmats, Ks, radii, logit_opac, logit_colors, log_unc = ctx.saved_tensors
         width, height, eps2d, near_plane, far_plane, flags, want_rec, calc_comp = ctx.cfg
         N, Cn = means.shape[0], viewmats.shape[0]
@@ -142,7 +147,7 @@ class _Projection(torch.autograd.Function):
                                   ptr(logit_colors), ptr(log_unc), ptr(v_rec) if want_rec else None, ptr(v_means),
                                   ptr(v_quats), ptr(v_scales), ptr(v_view), ptr(v_lo), ptr(v_lc), ptr(v_lu), ptr(ws),
                                   ws.numel(), stream_ptr(dev)), "gsx_project_bwd")
-        return (v_means, v_quats, v_scales, v_view, None, v_lo, v_lc, v_lu) + (None,) * 11
+        return (v_means, v_quats, v_scales, v_view, None, v_lo, v_lc, v_lu) + (None,) * 12
 
 
 def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optional[Tensor], scales: Optional[Tensor],
@@ -278,8 +283,10 @@ class _RasterizeRecords(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rec, means2d, conics, backgrounds, offsets, flatten_ids, ch, width, height, vis_min_T, absgrad,
-                has_end=False, want_touched=True):
-        """has_end: ``offsets`` is the flat int32 [T+1] array of gsx_isect_bin_sort and ``flatten_ids`` a
+                has_end=False, want_touched=True, v_rec_buf=None):
+        """v_rec_buf: a [C,N,RS] buffer already cleared by the projection forward (see _Projection) for the backward's
+        gradient records; used once, a second backward through the same node allocates its own.
+        has_end: ``offsets`` is the flat int32 [T+1] array of gsx_isect_bin_sort and ``flatten_ids`` a
         capacity-sized buffer (sync-free path); otherwise the gsplat layout ([C,tile_h,tile_w] offsets, exact M).
         want_touched=False skips the per-Gaussian touched-pixel counts (n_touched comes back as None)."""
         rec = _f32c(rec, "rec")
@@ -301,7 +308,8 @@ class _RasterizeRecords(torch.autograd.Function):
         ctx.save_for_backward(rec, bg, offsets, flatten_ids, alphas, last_ids)
         ctx.set_materialize_grads(False)
         ctx.cfg = (ch, width, height, absgrad, has_end)
-        ctx.means2d_ref = means2d if absgrad else None
+        ctx.means2d_ref = means2d
+        ctx.v_rec_buf = v_rec_buf if (v_rec_buf is not None and tuple(v_rec_buf.shape) == (Cn, N, RS)) else None
         if n_touched is not None:
             ctx.mark_non_differentiable(n_touched, last_ids)
         else:
@@ -316,11 +324,13 @@ class _RasterizeRecords(torch.autograd.Function):
         dev = rec.device
         tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
         if v_render is None and v_alphas is None:
-            return (None,) * 13
+            return (None,) * 14
         v_render = torch.zeros_like(alphas).expand(-1, -1, -1, ch).contiguous() if v_render is None \
             else v_render.contiguous()
         v_alphas = None if v_alphas is None else v_alphas.contiguous()      # NULL = zero gradient (kernel-side)
-        v_rec = torch.zeros(Cn, N, RS, dtype=torch.float32, device=dev)
+        v_rec, ctx.v_rec_buf = ctx.v_rec_buf, None
+        if v_rec is None:
+            v_rec = torch.zeros(Cn, N, RS, dtype=torch.float32, device=dev)
         v_abs = torch.zeros(Cn, N, 2, dtype=torch.float32, device=dev) if absgrad else None
         check(lib.gsx_raster_bwd(ptr(rec), ch, ptr(bg), ptr(offsets), ptr(flatten_ids), flatten_ids.shape[0],
                                  1 if has_end else 0, Cn, width, height, tile_w, tile_h, ptr(alphas), ptr(last_ids),
@@ -328,10 +338,13 @@ class _RasterizeRecords(torch.autograd.Function):
                                  ptr(v_alphas), ptr(v_rec), ptr(v_abs), stream_ptr(dev)), "gsx_raster_bwd")
         if absgrad and ctx.means2d_ref is not None:
             ctx.means2d_ref.absgrad = v_abs  # same side channel as gsplat (absgrad is off in gslam, rasterization.py:63)
+        if getattr(ctx.means2d_ref, "_gsx_share_grad", False):
+            # what means2d.retain_grad() would give (gslam/backend.py:326), as a view of v_rec instead of a copy kernel
+            ctx.means2d_ref.grad = v_rec[..., 0:2]
         v_bg = None
         if bg is not None and ctx.needs_input_grad[3]:
             v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
-        return v_rec, v_rec[..., 0:2], v_rec[..., 2:5], v_bg, None, None, None, None, None, None, None, None, None
+        return (v_rec, v_rec[..., 0:2], v_rec[..., 2:5], v_bg) + (None,) * 10
 
 
 class _PackRecords(torch.autograd.Function):

@@ -39,9 +39,12 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        # bucket by (betas, eps, step) so that every launch shares its scalar state
-        buckets: dict = {}
-        bumped: dict = {}
+        step_all([self])
+        return loss
+
+    def _collect(self, buckets: dict, bumped: dict):
+        """adds this optimiser's live parameters to ``buckets`` (keyed by the scalar state a launch shares) and its
+        device step counters to ``bumped``"""
         for group in self.param_groups:
             live = [p for p in group["params"] if p.grad is not None]
             if not live:
@@ -58,8 +61,7 @@ class FusedAdam(torch.optim.Optimizer):
                     if group["_step_dev"] is None:
                         group["_step_dev"] = torch.full((1,), group["_host_step"] - 1, dtype=torch.int64, device=dev0)
                     step_dev = group["_step_dev"]
-                if id(step_dev) not in bumped:
-                    bumped[id(step_dev)] = step_dev
+                bumped.setdefault(id(step_dev), step_dev)
             for p in live:
                 st = self.state[p]
                 if not st:
@@ -67,27 +69,52 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32):
                     raise RuntimeError("FusedAdam needs contiguous float32 parameters on the GPU (no CPU fallback)")
-                key = (group["betas"], group["eps"], 0 if self.capturable else group["_host_step"], p.device)
+                key = (group["betas"], group["eps"], -1 if self.capturable else group["_host_step"], p.device)
                 buckets.setdefault(key, []).append((p, p.grad.contiguous(), st, float(group["lr"]), step_dev))
-        if bumped:                                     # all device step counters of this update in one tiny launch
-            ctrs = list(bumped.values())
-            for i in range(0, len(ctrs), _MAX_COUNTERS):
-                part = ctrs[i:i + _MAX_COUNTERS]
-                check(lib.gsx_counters_add(len(part), (C.c_void_p * len(part))(*[t.data_ptr() for t in part]), 1,
-                                           stream_ptr(part[0].device)), "gsx_counters_add")
-        for (betas, eps, step, dev), items in buckets.items():
-            for i in range(0, len(items), _MAX):
-                chunk = items[i:i + _MAX]
-                n = len(chunk)
-                arr = lambda xs: (C.c_void_p * n)(*xs)
-                common = (n, arr([c_[0].data_ptr() for c_ in chunk]), arr([c_[1].data_ptr() for c_ in chunk]),
-                          arr([c_[2]["exp_avg"].data_ptr() for c_ in chunk]),
-                          arr([c_[2]["exp_avg_sq"].data_ptr() for c_ in chunk]),
-                          (C.c_int64 * n)(*[c_[0].numel() for c_ in chunk]),
-                          (C.c_float * n)(*[c_[3] for c_ in chunk]), float(betas[0]), float(betas[1]), float(eps))
-                if self.capturable:
-                    check(lib.gsx_adam_multi_steps(*common, arr([c_[4].data_ptr() for c_ in chunk]), stream_ptr(dev)),
-                          "gsx_adam_multi_steps")
+
+
+@torch.no_grad()
+def step_all(optimizers, decay=None):
+    """One update of several FusedAdam instances with as few launches as their scalar state allows: every device step
+    counter of every optimiser is bumped by ONE gsx_counters_add, and parameters that share (betas, eps) go into the
+    same multi-tensor launch whichever optimiser owns them (the splat and pose Adams of gslam/backend.py:554-602 become
+    one launch).  decay = (param, mask_int32, min_count, factor): param *= factor where mask > min_count, applied by the
+    launch that updates ``param`` (capturable optimisers only) - the opacity decay of backend.py:356-359."""
+    buckets: dict = {}
+    bumped: dict = {}
+    for opt in optimizers:
+        opt._collect(buckets, bumped)
+    if bumped:                                         # all device step counters of this update in one tiny launch
+        ctrs = list(bumped.values())
+        for i in range(0, len(ctrs), _MAX_COUNTERS):
+            part = ctrs[i:i + _MAX_COUNTERS]
+            check(lib.gsx_counters_add(len(part), (C.c_void_p * len(part))(*[t.data_ptr() for t in part]), 1,
+                                       stream_ptr(part[0].device)), "gsx_counters_add")
+    decayed = False
+    for (betas, eps, step, dev), items in buckets.items():
+        for i in range(0, len(items), _MAX):
+            chunk = items[i:i + _MAX]
+            n = len(chunk)
+            arr = lambda xs: (C.c_void_p * n)(*xs)
+            common = (n, arr([c_[0].data_ptr() for c_ in chunk]), arr([c_[1].data_ptr() for c_ in chunk]),
+                      arr([c_[2]["exp_avg"].data_ptr() for c_ in chunk]),
+                      arr([c_[2]["exp_avg_sq"].data_ptr() for c_ in chunk]),
+                      (C.c_int64 * n)(*[c_[0].numel() for c_ in chunk]),
+                      (C.c_float * n)(*[c_[3] for c_ in chunk]), float(betas[0]), float(betas[1]), float(eps))
+            if step == -1:
+                k = -1
+                if decay is not None:
+                    k = next((j for j, c_ in enumerate(chunk) if c_[0] is decay[0]), -1)
+                steps = arr([c_[4].data_ptr() for c_ in chunk])
+                if k >= 0:
+                    mask = decay[1]
+                    if not (mask.dtype == torch.int32 and mask.is_contiguous() and mask.numel() == decay[0].numel()):
+                        raise RuntimeError("decay mask must be a contiguous int32 tensor with one entry per element")
+                    check(lib.gsx_adam_multi_steps_decay(*common, steps, k, mask.data_ptr(), int(decay[2]),
+                                                         float(decay[3]), stream_ptr(dev)), "gsx_adam_multi_steps_decay")
+                    decayed = True
                 else:
-                    check(lib.gsx_adam_multi(*common, int(step), None, stream_ptr(dev)), "gsx_adam_multi")
-        return loss
+                    check(lib.gsx_adam_multi_steps(*common, steps, stream_ptr(dev)), "gsx_adam_multi_steps")
+            else:
+                check(lib.gsx_adam_multi(*common, int(step), None, stream_ptr(dev)), "gsx_adam_multi")
+    return decayed

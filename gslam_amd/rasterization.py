@@ -273,10 +273,15 @@ def rasterization(
         betas_index = ch
         ch += 1
 
+    # the backward's gradient records: cleared by the projection kernel on its way (no zero-fill launch per backward)
+    needs_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (means, quats, log_scales, viewmats, logit_opacities, logit_colors,
+                                                    log_uncertainties))
+    v_rec_buf = torch.empty(C, N, 12, dtype=torch.float32, device=means.device) if needs_grad else None
     radii, means2d, depths, conics, _comps, rec, tiles_per_gauss, vis_count = ops._Projection.apply(
         means, quats, log_scales, viewmats, Ks, logit_opacities, logit_colors, log_uncertainties, int(width),
         int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), False, flags, True, True,
-        True)
+        True, v_rec_buf)
 
     # backgrounds: [C,3] + 0 for depth + e^1 for beta (rasterization.py:236-239,251-255)
     bg = _packed_backgrounds(backgrounds, C, depth_index is not None, betas_index is not None)
@@ -321,7 +326,7 @@ def rasterization(
 
     render, alphas, n_touched, _last = ops._RasterizeRecords.apply(
         rec, means2d, conics, bg, raster_offsets, flatten_ids, ch, int(width), int(height), float(visibility_min_T),
-        bool(absgrad), has_end, bool(need_n_touched))
+        bool(absgrad), has_end, bool(need_n_touched), v_rec_buf)
 
     out = RasterizationOutput(
         rgbs=render[..., :3],

@@ -67,6 +67,8 @@ int gsx_project_fwd(const float *means, const float *quats, const float *scales,
                     float *conics, float *comps, int32_t *tiles_per_gauss, int tile_w, int tile_h,
                     const float *logit_opacities, const float *logit_colors, const float *log_uncertainties,
                     float *rec, int32_t *vis_count /*[N] nullable: number of cameras with radii>0 (backend.py:287,357)*/,
+                    float *v_rec_clear /*[C,N,12] nullable (needs rec): zero-filled on the way, for gsx_raster_bwd's
+                                         accumulation - saves the separate clear in front of every backward */,
                     void *stream);
 
 /* ---- K2: projection bwd (autograd of K1; pose gradient used at gslam/frontend.py:627-646, backend.py:665-670) --
@@ -155,6 +157,8 @@ int gsx_sh_bwd(int degree, const float *dirs, const float *coeffs, const int32_t
  * fwd: out_sum[0] = sum of the SSIM map over the crop (crop = 5 for 'valid', 0 for 'same'); the mean is
  * out_sum/(B*CH*(H-2crop)*(W-2crop)).  dm_* (nullable when train=0): three [B,CH,H,W] planar maps for the bwd.    */
 int64_t gsx_ssim_workspace_bytes(int64_t B, int CH, int H, int W);
+/* number of per-workgroup partial sums gsx_ssim_fwd leaves at the start of its workspace when out_sum == NULL */
+int64_t gsx_ssim_partials(int64_t B, int CH, int H, int W);
 int gsx_ssim_fwd(const float *img1, const float *img2, int64_t B, int CH, int H, int W, const int64_t *strides1,
                  const int64_t *strides2, int crop, float *out_sum, float *dm_dmu1, float *dm_dsigma1_sq,
                  float *dm_dsigma12, void *workspace, int64_t workspace_bytes, void *stream);
@@ -183,6 +187,17 @@ int gsx_map_loss(const float *render, const float *alphas, const float *gt, cons
 int64_t gsx_isotropic_workspace_bytes(int64_t N);
 int gsx_isotropic_loss(const float *log_scales, const int32_t *vis_count, int64_t N, float weight, float *sum_out,
                        float *v_log_scales, void *workspace, int64_t workspace_bytes, void *stream);
+/* same, but v_log_scales += (the regulariser lands directly in the parameter's gradient; untouched rows are skipped) */
+int gsx_isotropic_loss_acc(const float *log_scales, const int32_t *vis_count, int64_t N, float weight, float *sum_out,
+                           float *v_log_scales, void *workspace, int64_t workspace_bytes, void *stream);
+/* One finishing launch for a whole loss block.  gsx_map_loss(sums = NULL), gsx_ssim_fwd(out_sum = NULL) and
+ * gsx_isotropic_loss[_acc](sum_out = NULL) skip their own one-workgroup reductions and leave their per-workgroup partial
+ * rows in their workspaces; this call sums them: sums5 (nullable) = raw (photometric, 0.5 log^2 beta, tv, ssim,
+ * isotropic) sums, v_exposure [C,2] (nullable), out2[i] = bias_i + sum_k coef_i[k] * sums5[k] (coef: HOST float[5]).
+ * ssim_ws / iso_ws may be NULL (ssim_partials = 0 / term absent); C, H, W, N as given to the producers. */
+int gsx_loss_finish(const void *map_loss_ws, int64_t C, int H, int W, const void *ssim_ws, int64_t ssim_partials,
+                    const void *iso_ws, int64_t N, const float *coef0, const float *coef1, float bias0, float bias1,
+                    float *sums5, float *v_exposure, float *out2, void *stream);
 /* out2[i] = bias_i + sum_k coef_i[k] * terms[k][0]  (device scalars in, device scalars out; host arrays of pointers) */
 int gsx_combine_terms(int n, const float *const *terms, const float *coef0, const float *coef1, float bias0,
                       float bias1, float *out2, void *stream);
@@ -216,6 +231,13 @@ int gsx_adam_multi(int n_tensors, float *const *params, const float *const *grad
                    float eps, int64_t step_host, const int64_t *step_dev /*nullable device int64: overrides step_host*/,
                    void *stream);
 
+/* gsx_adam_multi_steps + a masked post-update decay of ONE of the tensors: params[decay_tensor][j] *= decay where
+ * decay_mask[j] > decay_min_count (the opacity decay of gslam/backend.py:356-359 riding in the update before it;
+ * decay_tensor = -1: none).  decay_mask has one int32 per element of that tensor. */
+int gsx_adam_multi_steps_decay(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                               float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1,
+                               float beta2, float eps, const int64_t *const *steps, int decay_tensor,
+                               const int32_t *decay_mask, int decay_min_count, float decay, void *stream);
 /* Same update with one device step counter PER TENSOR (steps: HOST array of n_tensors DEVICE int64 pointers; the
  * counters hold the 1-based step of this update), so tensors that joined the optimiser at different times (poses of
  * new keyframes, backend.py:665-670) update in the same launch.  gsx_counters_add bumps up to 16 such counters in one
