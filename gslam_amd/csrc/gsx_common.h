@@ -66,6 +66,13 @@ __device__ __forceinline__ float gsx_wave_sum_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Inline-asm DPP sequences get no automatic hazard padding (a VALU write needs 2 wait states before a DPP read of the
+// same register), and `asm volatile` does not stop the scheduler from sinking the ordinary VALU instruction that
+// produces an operand right in front of the statement that reads it (seen in the disassembly: wrong sums).  A
+// scheduling barrier that lets everything but VALU / transcendental instructions through pins the producers in front of
+// the leading s_nop and keeps the DPP chain as written.
+#define GSX_DPP_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 // Interleaved partial reduction of N independent values: after the call, lanes 15/31/47/63 hold the sums of their
 // 16-lane DPP rows.  The N chains are advanced step by step so that consecutive DPP instructions are independent
 // (no s_nop wait states between a VALU write and the DPP read of the same register).
@@ -76,10 +83,14 @@ template <int N>
 __device__ __forceinline__ void gsx_row16_sum(float (&v)[N]) {
 #define GSX_ROW_STEP(SHR)                                                                                      \
     if (N < 3) asm volatile("s_nop 1");                                                                        \
-    _Pragma("unroll") for (int k = 0; k < N; ++k)                                                              \
+    _Pragma("unroll") for (int k = 0; k < N; ++k) {                                                            \
         asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1"       \
-                     : "+v"(v[k]));
+                     : "+v"(v[k]));                                                                            \
+        GSX_DPP_FENCE();                                                                                       \
+    }
+    GSX_DPP_FENCE();
     asm volatile("s_nop 1");  // the values were just produced by ordinary VALU instructions
+    GSX_DPP_FENCE();
     GSX_ROW_STEP(1)
     GSX_ROW_STEP(2)
     GSX_ROW_STEP(4)
@@ -95,50 +106,71 @@ __device__ __forceinline__ void gsx_wave63_sum(float (&v)[N]) {
     gsx_row16_sum<N>(v);
     if (N < 3) asm volatile("s_nop 1");
 #pragma unroll
-    for (int k = 0; k < N; ++k)
+    for (int k = 0; k < N; ++k) {
         asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v[k]));
+        GSX_DPP_FENCE();
+    }
     if (N < 3) asm volatile("s_nop 1");
 #pragma unroll
-    for (int k = 0; k < N; ++k)
+    for (int k = 0; k < N; ++k) {
         asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v[k]));
+        GSX_DPP_FENCE();
+    }
 }
 
 // Reduce-scatter of N <= 12 per-lane values over the wavefront's four 16-lane rows (measured on MI355X: every DPP
 // instruction costs 4.2 SIMD cycles against 2.4 for a plain v_fma, tools/ubench/valu_rates.hip, so the 6 N DPP adds of a
 // full reduction of each value dominate the rasteriser backward).  Steps:
-//   1. quad butterflies (quad_perm xor 1, xor 2): every lane holds its quad's sum of every value        2 N ops
-//   2. scatter over the banks (4-lane groups) with row_shl / row_shr 4 and bank_mask, which selects the
-//      writing lanes for free: register j = values (2j | 2j+1) in (even | odd) banks                     ~N ops
-//   3. the same over bank pairs with row_shl / row_shr 8: register m = values 4m + bank                 ~N/2 ops
+//   1. scatter over the banks (4-lane groups) with row_shl / row_shr 4 and bank_mask, which selects the
+//      writing lanes for free: register 2j = values (2j | 2j+1) in (even | odd) banks, summed over the bank pair  N ops
+//   2. the same over bank pairs with row_shl / row_shr 8: register 4m = value 4m + bank, summed over the
+//      four lanes of the row that sit at the same position of their quads                                      N/2 ops
+//   3. quad butterflies (quad_perm xor 1, xor 2) on the (N+3)/4 registers that are left                          N/2 ops
 // Afterwards, in every row, a lane of bank b holds in v[m] (m < (N+3)/4) that ROW's sum of value 4m + b; the caller
-// adds the four rows up in memory (one ds_add_f32 per m with the 16 lanes `lane % 4 == 0`).  3.5 N DPP ops instead
-// of 6 N and (N+3)/4 LDS instructions instead of N.  Slots 4m + b >= N hold garbage.
+// adds the four rows up in memory (one ds_add_f32 per m with the 16 lanes `lane % 4 == 0`).  2 N DPP ops instead of
+// 6 N and (N+3)/4 LDS instructions instead of N.  Slots 4m + b >= N hold garbage.  (The first version ran the quad
+// butterflies first, on all N registers: 3.5 N ops.)
 template <int N>
 __device__ __forceinline__ void gsx_reduce_scatter(float (&v)[N]) {
     static_assert(N >= 1 && N <= 12, "gsx_reduce_scatter: N <= 12");
+    GSX_DPP_FENCE();
     asm volatile("s_nop 1");
-#pragma unroll
-    for (int k = 0; k < N; ++k)
-        asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[k]));
-    if (N < 3) asm volatile("s_nop 1");
-#pragma unroll
-    for (int k = 0; k < N; ++k)
-        asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v[k]));
-    asm volatile("s_nop 1");
+    GSX_DPP_FENCE();
     constexpr int N1 = (N + 1) / 2;
 #pragma unroll
     for (int j = 0; j < N1; ++j) {          // banks 0,2 <- value 2j summed over the bank pair; banks 1,3 <- value 2j+1
         asm volatile("v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(v[2 * j]));
-        if (2 * j + 1 < N)
+        GSX_DPP_FENCE();
+        if (2 * j + 1 < N) {
             asm volatile("v_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(v[2 * j]) : "v"(v[2 * j + 1]));
+            GSX_DPP_FENCE();
+        }
     }
     asm volatile("s_nop 1");
+    GSX_DPP_FENCE();
     constexpr int N2 = (N1 + 1) / 2;
 #pragma unroll
     for (int m = 0; m < N2; ++m) {          // banks 0,1 <- register 2m summed over the row; banks 2,3 <- register 2m+1
         asm volatile("v_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0x3" : "+v"(v[4 * m]));
-        if (2 * m + 1 < N1)
+        GSX_DPP_FENCE();
+        if (2 * m + 1 < N1) {
             asm volatile("v_add_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc" : "+v"(v[4 * m]) : "v"(v[4 * m + 2]));
+            GSX_DPP_FENCE();
+        }
+    }
+    asm volatile("s_nop 1");
+    GSX_DPP_FENCE();
+#pragma unroll
+    for (int m = 0; m < N2; ++m) {
+        asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[4 * m]));
+        GSX_DPP_FENCE();
+    }
+    asm volatile("s_nop 1");
+    GSX_DPP_FENCE();
+#pragma unroll
+    for (int m = 0; m < N2; ++m) {
+        asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v[4 * m]));
+        GSX_DPP_FENCE();
     }
     // compact: result register m lives in v[4m]
 #pragma unroll
