@@ -177,6 +177,17 @@ __device__ __forceinline__ void gsx_reduce_scatter(float (&v)[N]) {
     for (int m = 1; m < N2; ++m) v[m] = v[4 * m];
 }
 
+// lane i + lane i^16 + lane i^32 + lane i^48 in every lane (gfx950 v_permlane32_swap / v_permlane16_swap: no LDS, no DPP
+// row limit): the cross-row step that the DPP network lacks for lane-wise data.
+__device__ __forceinline__ float gsx_xrow_sum(float v) {
+    unsigned a = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    a = __float_as_uint(v);
+    const auto s = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+
 // 48-byte splat record fetched through the scalar data cache into SGPRs (uniform address): the broadcast of a
 // Gaussian to all 64 pixel lanes costs no VALU instruction and no LDS traffic.
 typedef float gsx_f4 __attribute__((ext_vector_type(4)));

@@ -682,9 +682,10 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     const int variant = raster_variant(true, T);
     const bool v1 = (use_v1() || variant == 1) && !offsets_has_end;
     const char *bb = getenv("GSX_BWD_MODE");
-    // reduce-scatter (mode 2) wins while the chip is not full (-8..10 % at one camera); its four rows adding to one LDS
-    // address lose to the single-lane add (mode 1) once it is (+7 % at eight cameras): tools/ab_raster.py
-    const int bwd_mode = (bb && bb[0] >= '0' && bb[0] <= '2') ? bb[0] - '0' : (T < 4096 ? 2 : 1);
+    // mode 4 (reduce-scatter + cross-row sums in registers, plain stores into per-wavefront accumulator copies, batches
+    // of 128) is the default: -4 % at one camera, -16..18 % at eight against the LDS-atomic modes (tools/ab_raster.py);
+    // GSX_BWD_MODE=0..3 select the earlier accumulation schemes for A/B runs
+    const int bwd_mode = (bb && bb[0] >= '0' && bb[0] <= '4') ? bb[0] - '0' : 4;
     const char *sb = getenv("GSX_BWD_SCALAR");
     const bool scalar_bwd = sb && sb[0] == '1';
 #define ARGS1 rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
@@ -692,7 +693,15 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
         if (variant >= 4 && !v1 && !v_abs) {                                                                        \
-            if (bwd_mode == 2)                                                                                      \
+            if (bwd_mode == 3)                                                                                      \
+                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 3>), dim3((unsigned)T), dim3(128), 0, st, rec, \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
+            else if (bwd_mode == 4)                                                                                 \
+                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 128, 3>), dim3((unsigned)T), dim3(128), 0, st, rec, \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
+            else if (bwd_mode == 2)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 2>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
                                    alphas, last_ids, v_render, v_alphas, v_rec);                                    \
