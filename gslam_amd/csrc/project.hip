@@ -259,6 +259,9 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
 #define PBWD_THREADS 256
 #define PBWD_MAX_C 16
 
+// POSE_ONLY: only the pose-gradient partials are wanted (tracking: the map is frozen, gslam/frontend.py:613-658), so the
+// world-covariance accumulation, the quaternion / scale chain and 60 B of gradient stores per Gaussian are skipped.
+template <bool POSE_ONLY>
 __global__ __launch_bounds__(PBWD_THREADS) void project_bwd_kernel(
     const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ viewmats, const float *__restrict__ Ks, int64_t N, int C, int W, int H, float eps2d,
@@ -303,11 +306,13 @@ __global__ __launch_bounds__(PBWD_THREADS) void project_bwd_kernel(
             float vdepth = v_depths ? v_depths[idx] : 0.f;
             if (v_rec) {
                 const float *vr = v_rec + idx * RS;
-                v_opac_sum += vr[5];
-                v_col_sum[0] += vr[6]; v_col_sum[1] += vr[7]; v_col_sum[2] += vr[8];
+                if (!POSE_ONLY) {
+                    v_opac_sum += vr[5];
+                    v_col_sum[0] += vr[6]; v_col_sum[1] += vr[7]; v_col_sum[2] += vr[8];
+                }
                 int n = 9;
                 if (flags & GSX_PROJ_RENDER_DEPTH) vdepth += vr[n++];
-                if (flags & GSX_PROJ_BETAS) v_beta_sum += vr[n++];
+                if (!POSE_ONLY && (flags & GSX_PROJ_BETAS)) v_beta_sum += vr[n++];
             }
             // 1. conic = inverse(blurred cov2d): GX = -Y G Y
             const float a = p.conic[0], b = p.conic[1], cc = p.conic[2];
@@ -369,13 +374,15 @@ __global__ __launch_bounds__(PBWD_THREADS) void project_bwd_kernel(
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    vS[i * 3 + j] += R[i] * A[j] + R[3 + i] * A[3 + j] + R[6 + i] * A[6 + j];
+                    if (!POSE_ONLY) vS[i * 3 + j] += R[i] * A[j] + R[3 + i] * A[3 + j] + R[6 + i] * A[6 + j];
                     vR[i * 3 + j] = 2.0f * (A[i * 3 + 0] * symget(S, 0, j) + A[i * 3 + 1] * symget(S, 1, j) +
                                             A[i * 3 + 2] * symget(S, 2, j)) +
                                     vpc[i] * mean[j];
                 }
+            if (!POSE_ONLY) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) vmean[j] += R[j] * vpc[0] + R[3 + j] * vpc[1] + R[6 + j] * vpc[2];
+                for (int j = 0; j < 3; ++j) vmean[j] += R[j] * vpc[0] + R[3 + j] * vpc[1] + R[6 + j] * vpc[2];
+            }
         }
         if (view_partials) {
             // block reduction of the 12 pose-gradient entries of camera c
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(PBWD_THREADS) void project_bwd_kernel(
             __syncthreads();
         }
     }
-    if (!active) return;
+    if (!active || POSE_ONLY) return;
     // 6. S = M M^T : vM = 2 vS M ; M = Rq diag(s)
     float vM[9], vRq[9];
 #pragma unroll
@@ -567,10 +574,11 @@ extern "C" int gsx_project_bwd(const float *means, const float *quats, const flo
                                int64_t workspace_bytes, void *stream) {
     GSX_CHECK_ARG(N >= 0 && C >= 1 && W > 0 && H > 0);
     GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && radii && v_means2d && v_conics);
-    GSX_CHECK_ARG(v_means && v_quats && v_scales);
+    const bool pose_only = !v_means && !v_quats && !v_scales;     // Gaussian gradients not wanted (tracking)
+    GSX_CHECK_ARG(pose_only ? (v_viewmats != nullptr) : (v_means && v_quats && v_scales));
     GSX_CHECK_ARG(v_means2d_stride >= 2 && v_conics_stride >= 3);
-    if (v_rec) GSX_CHECK_ARG(logit_opacities && logit_colors && v_logit_opacities && v_logit_colors);
-    if (v_rec && (flags & GSX_PROJ_BETAS)) GSX_CHECK_ARG(log_uncertainties && v_log_unc);
+    if (v_rec && !pose_only) GSX_CHECK_ARG(logit_opacities && logit_colors && v_logit_opacities && v_logit_colors);
+    if (v_rec && !pose_only && (flags & GSX_PROJ_BETAS)) GSX_CHECK_ARG(log_uncertainties && v_log_unc);
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) {
         if (v_viewmats && !gsx_zero_async(v_viewmats, 16 * C, st)) return GSX_E_LAUNCH;
@@ -585,11 +593,15 @@ extern "C" int gsx_project_bwd(const float *means, const float *quats, const flo
         }
         partials = (float *)workspace;
     }
-    hipLaunchKernelGGL(project_bwd_kernel, dim3(blocks), dim3(PBWD_THREADS), 0, st, means, quats, scales, viewmats,
-                       Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, flags, radii, v_means2d, v_means2d_stride,
-                       v_depths, v_conics, v_conics_stride, v_comps, logit_opacities, logit_colors,
-                       log_uncertainties, v_rec, 12, v_means, v_quats, v_scales, partials, v_logit_opacities,
-                       v_logit_colors, v_log_unc);
+#define GSX_PBWD_ARGS                                                                                                  \
+    means, quats, scales, viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, flags, radii, v_means2d,        \
+        v_means2d_stride, v_depths, v_conics, v_conics_stride, v_comps, logit_opacities, logit_colors,                 \
+        log_uncertainties, v_rec, 12, v_means, v_quats, v_scales, partials, v_logit_opacities, v_logit_colors, v_log_unc
+    if (pose_only)
+        hipLaunchKernelGGL(project_bwd_kernel<true>, dim3(blocks), dim3(PBWD_THREADS), 0, st, GSX_PBWD_ARGS);
+    else
+        hipLaunchKernelGGL(project_bwd_kernel<false>, dim3(blocks), dim3(PBWD_THREADS), 0, st, GSX_PBWD_ARGS);
+#undef GSX_PBWD_ARGS
     GSX_CHECK_LAUNCH();
     if (v_viewmats) {
         hipLaunchKernelGGL(project_bwd_finish_kernel, dim3((unsigned)C), dim3(256), 0, st, partials, (int)blocks,

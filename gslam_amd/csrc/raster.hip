@@ -682,10 +682,14 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     const int variant = raster_variant(true, T);
     const bool v1 = (use_v1() || variant == 1) && !offsets_has_end;
     const char *bb = getenv("GSX_BWD_MODE");
-    // mode 4 (reduce-scatter + cross-row sums in registers, plain stores into per-wavefront accumulator copies, batches
-    // of 128) is the default: -4 % at one camera, -16..18 % at eight against the LDS-atomic modes (tools/ab_raster.py);
-    // GSX_BWD_MODE=0..3 select the earlier accumulation schemes for A/B runs
-    const int bwd_mode = (bb && bb[0] >= '0' && bb[0] <= '4') ? bb[0] - '0' : 4;
+    // Gradient accumulation without LDS atomics (reduce-scatter + cross-row sums in registers, plain stores into
+    // per-wavefront accumulator copies).  Full chip (>= 4096 tiles): two pixels per lane, two wavefronts per tile, batches
+    // of 128 (mode 4: -16..18 % at eight cameras against the LDS-atomic modes).  One camera: the time is that of the
+    // most loaded SIMD (1200 tiles, everything resident at once), so four quadrant wavefronts per tile with one pixel
+    // per lane balance better although they execute more instructions in total (modes 5 / 6 = batches of 64 / 128:
+    // another -4..5 %; batches of 128 pay off with deep tile lists).  GSX_BWD_MODE=0..6 for A/B runs (tools/ab_raster.py).
+    const int bwd_auto = T >= 4096 ? 4 : (M / (T > 0 ? T : 1) > 1000 ? 6 : 5);
+    const int bwd_mode = (bb && bb[0] >= '0' && bb[0] <= '6') ? bb[0] - '0' : bwd_auto;
     const char *sb = getenv("GSX_BWD_SCALAR");
     const bool scalar_bwd = sb && sb[0] == '1';
 #define ARGS1 rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
@@ -693,7 +697,15 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
         if (variant >= 4 && !v1 && !v_abs) {                                                                        \
-            if (bwd_mode == 3)                                                                                      \
+            if (bwd_mode == 5)                                                                                      \
+                hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64>), dim3((unsigned)T), dim3(256), 0, st, rec,     \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
+            else if (bwd_mode == 6)                                                                                 \
+                hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128>), dim3((unsigned)T), dim3(256), 0, st, rec,    \
+                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
+                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
+            else if (bwd_mode == 3)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 3>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
                                    alphas, last_ids, v_render, v_alphas, v_rec);                                    \

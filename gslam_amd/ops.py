@@ -129,13 +129,15 @@ class _Projection(torch.autograd.Function):
             v_rec = torch.zeros(Cn, N, 12, dtype=torch.float32, device=dev)
         if v_rec is not None:
             v_rec = v_rec.contiguous()
-        v_means = torch.empty_like(means)
-        v_quats = torch.empty_like(quats)
-        v_scales = torch.empty_like(scales)
         need_view = ctx.needs_input_grad[3]
+        # tracking (frozen map): only the pose gradient is wanted; the kernel then skips the per-Gaussian chain and stores
+        need_gauss = any(ctx.needs_input_grad[i] for i in (0, 1, 2, 5, 6, 7)) or not need_view
+        v_means = torch.empty_like(means) if need_gauss else None
+        v_quats = torch.empty_like(quats) if need_gauss else None
+        v_scales = torch.empty_like(scales) if need_gauss else None
         v_view = torch.empty(Cn, 4, 4, dtype=torch.float32, device=dev) if need_view else None
         v_lo = v_lc = v_lu = None
-        if want_rec:
+        if want_rec and need_gauss:
             v_lo = torch.empty_like(logit_opac)
             v_lc = torch.empty_like(logit_colors)
             v_lu = torch.empty_like(log_unc) if log_unc is not None else None

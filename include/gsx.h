@@ -76,6 +76,8 @@ int gsx_project_fwd(const float *means, const float *quats, const float *scales,
  * a v_rec buffer).  v_depths, v_comps, v_rec nullable.  Outputs are OVERWRITTEN (sum over cameras done inside):
  * v_means [N,3], v_quats [N,4], v_scales [N,3] (w.r.t. log-scales when GSX_PROJ_LOG_SCALES), v_viewmats [C,4,4]
  * (nullable).  With v_rec: also v_logit_opacities [N], v_logit_colors [N,3], v_log_unc [N] (gslam front-end bwd).
+ * Pose-only call (tracking against a frozen map): v_means = v_quats = v_scales = NULL (and the v_logit_* / v_log_unc
+ * outputs ignored) with v_viewmats != NULL skips the per-Gaussian chain and its stores.
  * workspace: gsx_project_bwd_workspace_bytes(N, C).
  */
 int64_t gsx_project_bwd_workspace_bytes(int64_t N, int64_t C);

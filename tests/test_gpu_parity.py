@@ -172,7 +172,7 @@ def _oracle_pipeline(o, sc, viewmats, Ks, W, H, ch, seed=3):
     return m2d, con, colors, opac, bg, off, flat
 
 
-@pytest.mark.parametrize("variant", [None, "2", "3", "4", "4/1", "4/2", "4/3"])
+@pytest.mark.parametrize("variant", [None, "2", "3", "4", "4/1", "4/2", "4/3", "4/4", "4/5", "4/6"])
 @pytest.mark.parametrize("n,c,W,H,ch", [(3000, 1, 640, 480, 5), (3000, 2, 320, 240, 3), (2000, 1, 200, 120, 1),
                                          (2000, 1, 330, 250, 4), (2000, 1, 330, 250, 2)])
 def test_raster_forward_backward_vs_oracle(dev, oracle32, monkeypatch, n, c, W, H, ch, variant):

@@ -88,16 +88,16 @@ def run(N, C, W=640, H=480):
             res.setdefault(("fwd", ver), []).append(timed(fwd))
             res.setdefault(("bwd", ver), []).append(timed(bwd))
     os.environ["GSX_RASTER"] = "4"
-    for mode in ("1", "2", "3", "4"):
+    for mode in ("1", "2", "4", "5", "6"):
         os.environ["GSX_BWD_MODE"] = mode
         res[("bwd", "4/mode" + mode)] = [timed(bwd), timed(bwd)]
     outs = {}
-    for mode in ("1", "2", "3", "4"):                       # same numbers from every accumulation mode
+    for mode in ("1", "2", "3", "4", "5", "6"):             # same numbers from every accumulation mode
         os.environ["GSX_BWD_MODE"] = mode
         v_rec.zero_()
         bwd()
         outs[mode] = v_rec.clone()
-    for mode in ("2", "3", "4"):
+    for mode in ("2", "3", "4", "5", "6"):
         err = (outs[mode] - outs["1"]).abs().max().item() / (outs["1"].abs().max().item() + 1e-20)
         print(f"  bwd mode {mode} vs mode 1: max rel err {err:.2e}")
     os.environ.pop("GSX_BWD_MODE", None)
