@@ -44,6 +44,7 @@ struct Rect {
     int x0, y0, x1, y1;
 };
 
+
 __device__ __forceinline__ Rect tile_rect(float mx, float my, int32_t radius, int tile_w, int tile_h) {
     const float ts = (float)GSX_TILE;
     const float tr = (float)radius / ts, tx = mx / ts, ty = my / ts;
@@ -159,13 +160,14 @@ __global__ __launch_bounds__(1024) void tile_offsets_kernel(const int *__restric
 // owning lane's 64-bit payload; small rectangles are walked by their own lane, large ones by all 64 lanes together
 // (payload broadcast once per large rectangle).  Must be called by all lanes of the wavefront.
 template <typename Op>
-__device__ __forceinline__ void walk_rects(const Rect &r, int tile_w, unsigned int lo, unsigned int hi, Op op) {
+__device__ __forceinline__ void walk_rects(const Rect &r, int tile_w, unsigned int lo, unsigned int hi, Op op,
+                                           int base = 0 /* added to every tile index (camera offset) */) {
     const int w = r.x1 - r.x0, h = r.y1 - r.y0;
     const int area = (w > 0 && h > 0) ? w * h : 0;
     const int lane = threadIdx.x & 63;
     if (area > 0 && area <= COOP_AREA) {
         for (int y = r.y0; y < r.y1; ++y)
-            for (int x = r.x0; x < r.x1; ++x) op(y * tile_w + x, lo, hi);
+            for (int x = r.x0; x < r.x1; ++x) op(base + y * tile_w + x, lo, hi);
     }
     unsigned long long big = __ballot(area > COOP_AREA);
     while (big != 0ull) {
@@ -173,11 +175,12 @@ __device__ __forceinline__ void walk_rects(const Rect &r, int tile_w, unsigned i
         big &= big - 1ull;
         const int bx0 = __builtin_amdgcn_readlane(r.x0, l), by0 = __builtin_amdgcn_readlane(r.y0, l);
         const int bw = __builtin_amdgcn_readlane(w, l), ba = __builtin_amdgcn_readlane(area, l);
+        const int bbase = __builtin_amdgcn_readlane(base, l);
         const unsigned int blo = (unsigned int)__builtin_amdgcn_readlane((int)lo, l);
         const unsigned int bhi = (unsigned int)__builtin_amdgcn_readlane((int)hi, l);
         for (int k = lane; k < ba; k += 64) {
             const int yy = k / bw, xx = k - yy * bw;
-            op((by0 + yy) * tile_w + bx0 + xx, blo, bhi);
+            op(bbase + (by0 + yy) * tile_w + bx0 + xx, blo, bhi);
         }
     }
 }
@@ -306,6 +309,132 @@ __global__ __launch_bounds__(BIN_THREADS) void place_kernel(const float *__restr
             const int pos = atomicAdd(&s_cur[tile], 1);
             if ((uint64_t)(uint32_t)pos < (uint64_t)M_cap) entries[pos] = ((unsigned long long)hi << 32) | lo;
         });
+    }
+}
+
+// ---- 3c. binning for large maps: spatial pre-sort of the Gaussians --------------------------------------------------
+// place_kernel's workgroups hold arbitrary Gaussians, so each of them appends to every tile a few entries at a time: with
+// hundreds of resident workgroups the partially written 128-byte lines of the output are (workgroups x tiles) many -
+// far beyond the L2 - and go out to HBM half empty (5M Gaussians at 1080p: 1.48 ms for 606 MB, the largest kernel of
+// the render; 2M x 8 cameras: 0.95 ms).  Here the visible (camera, Gaussian) instances are first binned by the 4x4-tile
+// block that holds the top-left tile of their rectangle (16-byte records: packed rectangle, depth bits, flatten id;
+// same count matrix / column scan / placement scheme, one level up).  The tile-level count and placement passes then
+// read those records in order: a workgroup's instances share a neighbourhood, touch ~100 tiles instead of all of
+// them, and fill each line of the output within one trip of its loop, so the L2 merges the 8-byte stores into full lines.
+// The records take 16 B x C x N of extra workspace (gsx_isect_bin_workspace_bytes_n); a caller that sized its
+// workspace without them (gsx_isect_bin_workspace_bytes) gets the direct placement.
+constexpr int SUPER = 4;              // tiles per side of a pre-sort block
+
+struct PreRec {
+    uint32_t xs, ys_c, depth, id;     // x0 | x1 << 16 ; y0 | y1 << 12 | camera << 24 ; depth bits ; flatten id
+};
+
+__global__ __launch_bounds__(BIN_THREADS) void coarse_count_kernel(const float *__restrict__ means2d,
+                                                                   const int32_t *__restrict__ radii, int64_t N,
+                                                                   int tile_w, int tile_h, int items, int sw, int S,
+                                                                   int32_t *__restrict__ cnt /*[C][gblocks][S]*/) {
+    extern __shared__ int s_cnt[];  // [S]
+    const int c = blockIdx.y;
+    for (int i = threadIdx.x; i < S; i += BIN_THREADS) s_cnt[i] = 0;
+    __syncthreads();
+    for (int it = 0; it < items; ++it) {
+        const int64_t g = ((int64_t)blockIdx.x * items + it) * BIN_THREADS + threadIdx.x;
+        const Rect r = load_rect(means2d, radii, (int64_t)c * N + g, tile_w, tile_h, g < N);
+        if (r.x1 > r.x0 && r.y1 > r.y0) atomicAdd(&s_cnt[(r.y0 / SUPER) * sw + r.x0 / SUPER], 1);
+    }
+    __syncthreads();
+    int32_t *row = cnt + ((int64_t)c * gridDim.x + blockIdx.x) * S;
+    for (int i = threadIdx.x; i < S; i += BIN_THREADS) row[i] = s_cnt[i];
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void coarse_place_kernel(const float *__restrict__ means2d,
+                                                                   const int32_t *__restrict__ radii,
+                                                                   const float *__restrict__ depths, int64_t N,
+                                                                   int tile_w, int tile_h, int items, int sw, int S,
+                                                                   int64_t rec_cap, const int32_t *__restrict__ coff,
+                                                                   const int32_t *__restrict__ cnt,
+                                                                   PreRec *__restrict__ recs) {
+    extern __shared__ int s_cur[];  // [S]
+    const int c = blockIdx.y;
+    const int32_t *row = cnt + ((int64_t)c * gridDim.x + blockIdx.x) * S;
+    for (int i = threadIdx.x; i < S; i += BIN_THREADS) s_cur[i] = coff[(int64_t)c * S + i] + row[i];
+    __syncthreads();
+    for (int it = 0; it < items; ++it) {
+        const int64_t g = ((int64_t)blockIdx.x * items + it) * BIN_THREADS + threadIdx.x;
+        const int64_t idx = (int64_t)c * N + g;
+        const Rect r = load_rect(means2d, radii, idx, tile_w, tile_h, g < N);
+        if (r.x1 > r.x0 && r.y1 > r.y0) {
+            const int pos = atomicAdd(&s_cur[(r.y0 / SUPER) * sw + r.x0 / SUPER], 1);
+            if ((uint64_t)(uint32_t)pos < (uint64_t)rec_cap) {
+                PreRec o;
+                o.xs = (uint32_t)r.x0 | ((uint32_t)r.x1 << 16);
+                o.ys_c = (uint32_t)r.y0 | ((uint32_t)r.y1 << 12) | ((uint32_t)c << 24);
+                o.depth = __float_as_uint(depths[idx]);
+                o.id = (uint32_t)idx;
+                reinterpret_cast<uint4 *>(recs)[pos] = make_uint4(o.xs, o.ys_c, o.depth, o.id);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ Rect unpack_rec(const uint4 &v, int n_tiles, int &base) {
+    Rect r;
+    r.x0 = (int)(v.x & 0xffffu); r.x1 = (int)(v.x >> 16);
+    r.y0 = (int)(v.y & 0xfffu);  r.y1 = (int)((v.y >> 12) & 0xfffu);
+    base = (int)(v.y >> 24) * n_tiles;
+    return r;
+}
+
+// (Tried and dropped: a tile-major walk - the wavefront loops over the tiles of its 64 records' common window, a ballot
+// gives each tile's count and ranks, one LDS add per tile - to get rid of the same-address LDS atomics that neighbouring
+// records cause; the serial ballot -> scalar -> writelane chain per tile made both passes 2-2.4x slower.)
+__global__ __launch_bounds__(BIN_THREADS) void fine_count_kernel(const PreRec *__restrict__ recs,
+                                                                 const int64_t *__restrict__ n_inst, int chunk,
+                                                                 int tile_w, int n_tiles, int T,
+                                                                 int32_t *__restrict__ cnt /*[gblocks][T]*/) {
+    extern __shared__ int s_cnt[];  // [T]
+    for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cnt[i] = 0;
+    __syncthreads();
+    const int64_t n = n_inst[0];
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (int64_t i0 = lo; i0 < hi; i0 += BIN_THREADS) {    // uniform trip count: the walks need the whole wavefront
+        const int64_t i = i0 + threadIdx.x;
+        Rect r = {0, 0, 0, 0};
+        int base = 0;
+        if (i < hi) r = unpack_rec(reinterpret_cast<const uint4 *>(recs)[i], n_tiles, base);
+        walk_rects(r, tile_w, 0u, 0u, [&](int tile, unsigned int, unsigned int) { atomicAdd(&s_cnt[tile], 1); }, base);
+    }
+    __syncthreads();
+    int32_t *row = cnt + (int64_t)blockIdx.x * T;
+    for (int i = threadIdx.x; i < T; i += BIN_THREADS) row[i] = s_cnt[i];
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void fine_place_kernel(const PreRec *__restrict__ recs,
+                                                                 const int64_t *__restrict__ n_inst, int chunk,
+                                                                 int tile_w, int n_tiles, int T, int64_t M_cap,
+                                                                 const int32_t *__restrict__ offsets,
+                                                                 const int32_t *__restrict__ cnt,
+                                                                 unsigned long long *__restrict__ entries) {
+    extern __shared__ int s_cur[];  // [T]
+    const int32_t *row = cnt + (int64_t)blockIdx.x * T;
+    for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cur[i] = offsets[i] + row[i];
+    __syncthreads();
+    const int64_t n = n_inst[0];
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (int64_t i0 = lo; i0 < hi; i0 += BIN_THREADS) {
+        const int64_t i = i0 + threadIdx.x;
+        Rect r = {0, 0, 0, 0};
+        int base = 0;
+        unsigned int klo = 0u, khi = 0u;
+        if (i < hi) {
+            const uint4 v = reinterpret_cast<const uint4 *>(recs)[i];
+            r = unpack_rec(v, n_tiles, base);
+            klo = v.w; khi = v.z;
+        }
+        walk_rects(r, tile_w, klo, khi, [&](int tile, unsigned int l, unsigned int h) {
+            const int pos = atomicAdd(&s_cur[tile], 1);
+            if ((uint64_t)(uint32_t)pos < (uint64_t)M_cap) entries[pos] = ((unsigned long long)h << 32) | l;
+        }, base);
     }
 }
 
@@ -655,10 +784,11 @@ BinLayout bin_layout(int64_t C, int tile_w, int tile_h, int64_t M_cap) {
     const int64_t T = C * tile_w * tile_h;
     L.diff_off = 0;
     L.cursor_off = gsx_align256(C * G * 4);
-    L.entries_off = L.cursor_off + gsx_align256(T * 4);
+    L.entries_off = L.cursor_off + gsx_align256((T + 1) * 4);
     L.scratch_off = L.entries_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);
     L.matrix_off = L.scratch_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);
     L.total = L.matrix_off + gsx_align256(T * (int64_t)GB_MAX * 4) + 256;     // [C][<= GB_MAX workgroups][tiles] counts
+    L.total = gsx_align256(L.total);
     return L;
 }
 
@@ -666,6 +796,10 @@ BinLayout bin_layout(int64_t C, int tile_w, int tile_h, int64_t M_cap) {
 
 extern "C" int64_t gsx_isect_bin_workspace_bytes(int64_t C, int tile_w, int tile_h, int64_t M_cap) {
     return bin_layout(C, tile_w, tile_h, M_cap).total;
+}
+
+extern "C" int64_t gsx_isect_bin_workspace_bytes_n(int64_t C, int64_t N, int tile_w, int tile_h, int64_t M_cap) {
+    return bin_layout(C, tile_w, tile_h, M_cap).total + (C > 0 && N > 0 ? C * N * 16 : 0) + 256;
 }
 
 extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, const float *depths, int64_t N, int64_t C,
@@ -715,6 +849,51 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
         int32_t *cnt = (int32_t *)(ws + L.matrix_off);
         int64_t items = BIN_ITEMS;
         while ((N + BIN_THREADS * items - 1) / (BIN_THREADS * items) > GB_MAX) items *= 2;
+        // large maps: spatial pre-sort of the visible instances first (see 3c); GSX_BIN_PRESORT=0/1 forces the choice
+        const char *ps = getenv("GSX_BIN_PRESORT");
+        const int sw = (tile_w + SUPER - 1) / SUPER, S = sw * ((tile_h + SUPER - 1) / SUPER);
+        const int64_t rec_cap = C * N;
+        const bool presort_ok = N > 0 && M_cap > 0 && workspace_bytes >= L.total + rec_cap * 16 && T <= 16000 && C <= 255 && tile_w < 4096 && tile_h < 4096 &&
+                                S * (int64_t)sizeof(int) <= 65536;
+        // measured (MI355X): 5M Gaussians at 1920x1080 (8160 tiles per camera): count + placement 1.70 -> 1.14 ms;
+        // 2M x 8 cameras at 640x480 (1200 tiles per camera): 1.08 -> 1.23 ms - with few tiles per camera the direct
+        // placement already writes long enough runs, so the pre-sort is for high-resolution renders of large maps only
+        const bool presort = presort_ok && (ps ? ps[0] == '1' : (C * N >= ((int64_t)1 << 21) && n_tiles >= 4096));
+        if (presort) {
+            const unsigned gblocks = (unsigned)((N + BIN_THREADS * items - 1) / (BIN_THREADS * items));
+            int32_t *coff = cursor;                          // [C * S + 1] (S <= tiles per camera)
+            int64_t *n_inst = (int64_t *)diff;
+            PreRec *recs = (PreRec *)(ws + L.total);         // the tail behind the base layout (256-byte aligned)
+            hipLaunchKernelGGL(coarse_count_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(S * 4), st,
+                               means2d, radii, N, tile_w, tile_h, (int)items, sw, S, cnt);
+            GSX_CHECK_LAUNCH();
+            hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(64 * CS_GROUPS), 0,
+                               st, cnt, (int)gblocks, S, coff);
+            GSX_CHECK_LAUNCH();
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, (int)(C * S), C * N, coff, n_inst, status);
+            GSX_CHECK_LAUNCH();
+            hipLaunchKernelGGL(coarse_place_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(S * 4), st,
+                               means2d, radii, depths, N, tile_w, tile_h, (int)items, sw, S, rec_cap, coff, cnt, recs);
+            GSX_CHECK_LAUNCH();
+            // tile level: chunks of instances, at most GB_MAX of them over the record capacity
+            int64_t chunk = BIN_THREADS * 4;
+            const int64_t inst_cap = rec_cap;
+            while ((inst_cap + chunk - 1) / chunk > GB_MAX) chunk *= 2;
+            const unsigned gb2 = (unsigned)((inst_cap + chunk - 1) / chunk);
+            hipLaunchKernelGGL(fine_count_kernel, dim3(gb2), dim3(BIN_THREADS), (size_t)(T * 4), st, recs, n_inst,
+                               (int)chunk, tile_w, (int)n_tiles, (int)T, cnt);
+            GSX_CHECK_LAUNCH();
+            hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((T + 63) / 64), 1u), dim3(64 * CS_GROUPS), 0, st, cnt,
+                               (int)gb2, (int)T, offsets);
+            GSX_CHECK_LAUNCH();
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, (int)T, M_cap, offsets, M_dev, status);
+            GSX_CHECK_LAUNCH();
+            if (M_cap > 0) {
+                hipLaunchKernelGGL(fine_place_kernel, dim3(gb2), dim3(BIN_THREADS), (size_t)(T * 4), st, recs, n_inst,
+                                   (int)chunk, tile_w, (int)n_tiles, (int)T, M_cap, offsets, cnt, entries);
+                GSX_CHECK_LAUNCH();
+            }
+        } else {
         // fatter workgroups while the grid still covers the chip twice: the 8-byte entries of a workgroup land in
         // longer runs per tile, which the L2 merges into fuller lines before they go out to HBM
         const char *bi = getenv("GSX_BIN_ITEMS");
@@ -737,6 +916,7 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
             hipLaunchKernelGGL(place_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4), st,
                                means2d, radii, depths, N, tile_w, tile_h, (int)items, M_cap, offsets, cnt, entries);
             GSX_CHECK_LAUNCH();
+        }
         }
     }
     if (N > 0 && M_cap > 0) {

@@ -256,7 +256,7 @@ def isect_bin_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_width: i
     offsets = torch.empty(T + 1, dtype=torch.int32, device=dev) if offsets is None else offsets
     M_dev = torch.empty(1, dtype=torch.int64, device=dev) if M_dev is None else M_dev
     status = torch.zeros(1, dtype=torch.int32, device=dev) if status is None else status
-    ws = workspace(lib.gsx_isect_bin_workspace_bytes(Cn, tile_width, tile_height, capacity), dev, "isect_bin")
+    ws = workspace(lib.gsx_isect_bin_workspace_bytes_n(Cn, N, tile_width, tile_height, capacity), dev, "isect_bin")
     check(lib.gsx_isect_bin_sort(ptr(means2d), ptr(radii), ptr(depths), N, Cn, tile_width, tile_height, capacity,
                                  ptr(offsets), ptr(M_dev), ptr(status), ptr(isect_ids), ptr(flatten_ids), ptr(ws),
                                  ws.numel(), stream_ptr(dev)), "gsx_isect_bin_sort")

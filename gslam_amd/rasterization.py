@@ -117,7 +117,9 @@ class _IsectPool:
             if st & 1:
                 ok = False
                 self.overflowed = True
-                self.capacity = int(M * self.GROW) + 4096
+                # M can be an under-estimate when the overflow was in the pre-sort's instance records (csrc/isect_bin.hip
+                # 3c): grow geometrically from the current capacity as well
+                self.capacity = int(max(M, self.capacity) * self.GROW) + 4096
                 self.status.zero_()
             else:
                 self.ensure(M)
@@ -195,7 +197,7 @@ def validate(device=None, signature=None) -> bool:
             p.last_M = int(p._graph_M.item())
             if st & 1:
                 p.overflowed = True
-                p.capacity = int(p.last_M * p.GROW) + 4096
+                p.capacity = int(max(p.last_M, p.capacity) * p.GROW) + 4096
                 p.status.zero_()
                 p._graph_M = None                   # the captured graph is stale (capacity baked in): re-capture
         bad = bad or p.overflowed

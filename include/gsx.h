@@ -122,6 +122,9 @@ int gsx_isect_offset_encode(const int64_t *isect_ids, int64_t M, int64_t C, int 
  * beyond M_cap are dropped - the caller must re-run with a larger capacity); flatten_ids [M_cap]; isect_ids
  * [M_cap] nullable. */
 int64_t gsx_isect_bin_workspace_bytes(int64_t C, int tile_w, int tile_h, int64_t M_cap);
+/* the same plus 16 B x C x N for the spatial pre-sort of large maps (C * N >= 2^21): with the smaller workspace the call
+ * still works and places the intersections directly (slower beyond ~2M instances) */
+int64_t gsx_isect_bin_workspace_bytes_n(int64_t C, int64_t N, int tile_w, int tile_h, int64_t M_cap);
 int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, const float *depths, int64_t N, int64_t C,
                        int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev, int32_t *status,
                        int64_t *isect_ids, int32_t *flatten_ids, void *workspace, int64_t workspace_bytes,
