@@ -206,7 +206,8 @@ struct AdamArgs {
     const float *g[ADAM_MAX];
     float *m[ADAM_MAX];
     float *v[ADAM_MAX];
-    int64_t start[ADAM_MAX + 1];  // exclusive prefix of numels
+    int64_t start[ADAM_MAX + 1];  // exclusive prefix of the tensors' sizes in 4-float units (each rounded up)
+    int64_t numel[ADAM_MAX];
     float step_size[ADAM_MAX];    // lr / bias_correction1 (host-step mode)
     float lr[ADAM_MAX];
     const int64_t *step_dev;      // non-null: the step lives on the device (graph-capturable)
@@ -223,41 +224,73 @@ struct AdamArgs {
     const int32_t *decay_mask;
 };
 
+// One element of the update (torch.optim.Adam, lerp form of the first moment)
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float beta1, float beta2, float eps,
+                                         float step_size, float bc2_sqrt) {
+    m = m + (g - m) * (1.0f - beta1);
+    v = beta2 * v + (1.0f - beta2) * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - (step_size * m) / denom;
+}
+
+// A workgroup owns ADAM_UNITS consecutive 4-float units of the concatenated tensors (every tensor padded to whole
+// units) and walks the tensors that overlap its range: the tensor lookup, its pointers, learning rate and bias
+// corrections are workgroup-uniform (scalar registers), and a lane moves 16 bytes per access.  (The first version
+// looked every element's tensor up with a per-lane binary search over the argument block and moved 4 bytes per lane:
+// 21 us for the 1.5 M parameters of a 100 k map, 2 TB/s.)
+constexpr int ADAM_UNITS = 512;
+
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
-    const int64_t total = a.start[a.count];
-    float bc1 = 1.0f, bc2_sqrt = a.bc2_sqrt;
-    if (a.step_dev && !a.per_tensor) {
-        const float t = (float)a.step_dev[0];
-        bc1 = 1.0f - powf(a.beta1, t);
-        bc2_sqrt = sqrtf(1.0f - powf(a.beta2, t));
-    }
-    int k_cached = -1;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int lo = 0, hi = a.count - 1;                   // last tensor whose start is <= i
-#pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (a.start[mid] <= i) lo = mid; else hi = mid - 1;
-        }
-        const int k = lo;
-        if (a.per_tensor && k != k_cached) {
-            const float t = (float)a.step_of[k][0];
+    int64_t u0 = (int64_t)blockIdx.x * ADAM_UNITS;
+    const int64_t u_end = min(a.start[a.count], u0 + ADAM_UNITS);       // start[] is in units here
+    if (u0 >= u_end) return;
+    int k = 0;
+    while (k + 1 < a.count && a.start[k + 1] <= u0) ++k;                   // uniform: first tensor of the range
+    for (; u0 < u_end; ++k) {
+        const int64_t seg_end = min(u_end, a.start[k + 1]);
+        float bc1 = 1.0f, bc2_sqrt = a.bc2_sqrt;
+        if (a.step_dev) {
+            const float t = (float)(a.per_tensor ? a.step_of[k][0] : a.step_dev[0]);
             bc1 = 1.0f - powf(a.beta1, t);
             bc2_sqrt = sqrtf(1.0f - powf(a.beta2, t));
-            k_cached = k;
         }
-        const int64_t j = i - a.start[k];
-        const float grad = a.g[k][j];
-        float m = a.m[k][j], v = a.v[k][j];
-        m = m + (grad - m) * (1.0f - a.beta1);          // torch lerp form
-        v = a.beta2 * v + (1.0f - a.beta2) * grad * grad;
-        const float denom = sqrtf(v) / bc2_sqrt + a.eps;
         const float step_size = a.step_dev ? a.lr[k] / bc1 : a.step_size[k];
-        float p = a.p[k][j] - (step_size * m) / denom;
-        if (k == a.decay_k && a.decay_mask[j] > a.decay_min) p *= a.decay;
-        a.p[k][j] = p;
-        a.m[k][j] = m;
-        a.v[k][j] = v;
+        float *p = a.p[k], *m = a.m[k], *v = a.v[k];
+        const float *g = a.g[k];
+        const int64_t numel = a.numel[k];
+        const bool decays = (k == a.decay_k);
+        const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) &&
+                         (!decays || (((uintptr_t)a.decay_mask & 15) == 0));
+        for (int64_t u = u0 + threadIdx.x; u < seg_end; u += 256) {
+            const int64_t j = (u - a.start[k]) * 4;
+            if (vec && j + 4 <= numel) {
+                float4 pp = *reinterpret_cast<float4 *>(p + j), mm = *reinterpret_cast<float4 *>(m + j),
+                       vv = *reinterpret_cast<float4 *>(v + j);
+                const float4 gg = *reinterpret_cast<const float4 *>(g + j);
+                adam_one(pp.x, gg.x, mm.x, vv.x, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
+                adam_one(pp.y, gg.y, mm.y, vv.y, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
+                adam_one(pp.z, gg.z, mm.z, vv.z, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
+                adam_one(pp.w, gg.w, mm.w, vv.w, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
+                if (decays) {
+                    const int4 mk = *reinterpret_cast<const int4 *>(a.decay_mask + j);
+                    if (mk.x > a.decay_min) pp.x *= a.decay;
+                    if (mk.y > a.decay_min) pp.y *= a.decay;
+                    if (mk.z > a.decay_min) pp.z *= a.decay;
+                    if (mk.w > a.decay_min) pp.w *= a.decay;
+                }
+                *reinterpret_cast<float4 *>(p + j) = pp;
+                *reinterpret_cast<float4 *>(m + j) = mm;
+                *reinterpret_cast<float4 *>(v + j) = vv;
+            } else {
+                for (int64_t e = j; e < min(numel, j + 4); ++e) {
+                    float pe = p[e], me = m[e], ve = v[e];
+                    adam_one(pe, g[e], me, ve, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
+                    if (decays && a.decay_mask[e] > a.decay_min) pe *= a.decay;
+                    p[e] = pe; m[e] = me; v[e] = ve;
+                }
+            }
+        }
+        u0 = seg_end;
     }
 }
 
@@ -343,7 +376,8 @@ static int adam_launch(int n_tensors, float *const *params, const float *const *
         if (steps && in) GSX_CHECK_ARG(steps[k]);
         a.p[k] = in ? params[k] : nullptr; a.g[k] = in ? grads[k] : nullptr;
         a.m[k] = in ? exp_avg[k] : nullptr; a.v[k] = in ? exp_avg_sq[k] : nullptr;
-        a.start[k + 1] = a.start[k] + (in ? numels[k] : 0);
+        a.start[k + 1] = a.start[k] + (in ? (numels[k] + 3) / 4 : 0);
+        a.numel[k] = in ? numels[k] : 0;
         a.step_size[k] = in ? (float)((double)lrs[k] / bc1) : 0.f;
         a.lr[k] = in ? lrs[k] : 0.f;
         if (in) GSX_CHECK_ARG(numels[k] >= 1 && params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k]);
@@ -351,8 +385,8 @@ static int adam_launch(int n_tensors, float *const *params, const float *const *
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.bc2_sqrt = (float)sqrt(bc2);
     a.decay_k = decay_tensor < 0 ? -1 : decay_tensor; a.decay_mask = decay_mask; a.decay_min = decay_min; a.decay = decay;
     const int64_t total = a.start[n_tensors];
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 2048 * 4) blocks = 2048 * 4;
+    const int64_t blocks = (total + ADAM_UNITS - 1) / ADAM_UNITS;
+    GSX_CHECK_ARG(blocks < ((int64_t)1 << 31));
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     GSX_CHECK_LAUNCH();
     return GSX_OK;
