@@ -894,11 +894,16 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
                 GSX_CHECK_LAUNCH();
             }
         } else {
-        // fatter workgroups while the grid still covers the chip twice: the 8-byte entries of a workgroup land in
-        // longer runs per tile, which the L2 merges into fuller lines before they go out to HBM
+        // Gaussians per thread (tools/dbg/ab_items.sh, MI355X): the grid has to cover the chip (>= 512 workgroups over all
+        // cameras: 100 k Gaussians at one camera want ONE Gaussian per thread, 36 vs 50 us for the whole tile-list
+        // build), beyond that fatter workgroups write longer runs per tile, up to 8 per thread; the count matrix caps the
+        // workgroups per camera at GB_MAX
         const char *bi = getenv("GSX_BIN_ITEMS");
-        if (bi) items = atoi(bi) > 0 ? atoi(bi) : items;
-        else while (items < 32 && C * ((N + BIN_THREADS * items * 2 - 1) / (BIN_THREADS * items * 2)) >= 512) items *= 2;
+        auto blocks_of = [&](int64_t it) { return (N + BIN_THREADS * it - 1) / (BIN_THREADS * it); };
+        items = 1;
+        while (items < 8 && C * blocks_of(items * 2) >= 512) items *= 2;
+        if (bi && atoi(bi) > 0) items = atoi(bi);
+        while (blocks_of(items) > GB_MAX) items *= 2;
         const unsigned gblocks = (unsigned)((N + BIN_THREADS * items - 1) / (BIN_THREADS * items));
         if (N > 0) {
             hipLaunchKernelGGL(count_matrix_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4),

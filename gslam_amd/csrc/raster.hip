@@ -120,10 +120,10 @@ struct Quad {
     float fx, fy, x0, y0, x1, y1;
 };
 
-__device__ __forceinline__ Quad make_quad(int tile_w, int tile_h, int W, int H) {
+__device__ __forceinline__ Quad make_quad(int tile_w, int tile_h, int W, int H, int tile = -1) {
     Quad q;
     const int tiles_per_cam = tile_w * tile_h;
-    q.tile = blockIdx.x;
+    q.tile = tile >= 0 ? tile : (int)blockIdx.x;
     q.c = q.tile / tiles_per_cam;
     const int tl = q.tile - q.c * tiles_per_cam;
     const int ty = tl / tile_w, tx = tl - ty * tile_w;
@@ -358,10 +358,10 @@ struct Half {
     float fx, fy0, x0, y0, x1, y1;
 };
 
-__device__ __forceinline__ Half make_half(int tile_w, int tile_h, int W, int H) {
+__device__ __forceinline__ Half make_half(int tile_w, int tile_h, int W, int H, int tile = -1) {
     Half q;
     const int tiles_per_cam = tile_w * tile_h;
-    q.tile = blockIdx.x;
+    q.tile = tile >= 0 ? tile : (int)blockIdx.x;
     q.c = q.tile / tiles_per_cam;
     const int tl = q.tile - q.c * tiles_per_cam;
     const int ty = tl / tile_w, tx = tl - ty * tile_w;
@@ -609,6 +609,10 @@ bool use_v1() {
 
 }  // namespace
 
+// Launch order of the tiles (nullable): entry i = the tile the i-th workgroup takes.  See gsx_raster_set_tile_order.
+static const int32_t *g_tile_order = nullptr;
+extern "C" void gsx_raster_set_tile_order(const int32_t *order) { g_tile_order = order; }
+
 extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
                               const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
                               int tile_w, int tile_h, float visibility_min_T, float *render, float *alphas,
@@ -628,11 +632,11 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
             if (n_touched)                                                                                          \
                 hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, rec,   \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   visibility_min_T, render, alphas, last_ids, n_touched);                          \
+                                   visibility_min_T, render, alphas, last_ids, n_touched, g_tile_order);                          \
             else                                                                                                    \
                 hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, rec,  \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   visibility_min_T, render, alphas, last_ids, n_touched);                          \
+                                   visibility_min_T, render, alphas, last_ids, n_touched, g_tile_order);                          \
         } else if (variant == 4 && !v1) {                                                                           \
             if (n_touched)                                                                                          \
                 hipLaunchKernelGGL((raster_fwd_kernel4<ch, rs, true>), dim3((unsigned)T), dim3(128), 0, st, rec,    \
@@ -700,11 +704,11 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
             if (bwd_mode == 5)                                                                                      \
                 hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64>), dim3((unsigned)T), dim3(256), 0, st, rec,     \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
+                                   alphas, last_ids, v_render, v_alphas, v_rec, g_tile_order);                                    \
             else if (bwd_mode == 6)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128>), dim3((unsigned)T), dim3(256), 0, st, rec,    \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
+                                   alphas, last_ids, v_render, v_alphas, v_rec, g_tile_order);                                    \
             else if (bwd_mode == 3)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 3>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
@@ -712,7 +716,7 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
             else if (bwd_mode == 4)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 128, 3>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
+                                   alphas, last_ids, v_render, v_alphas, v_rec, g_tile_order);                                    \
             else if (bwd_mode == 2)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 2>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \

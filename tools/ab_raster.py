@@ -102,6 +102,16 @@ def run(N, C, W=640, H=480):
         print(f"  bwd mode {mode} vs mode 1: max rel err {err:.2e}")
     os.environ.pop("GSX_BWD_MODE", None)
     os.environ.pop("GSX_RASTER", None)
+    # heaviest tiles first: launch order = tiles sorted by descending list length
+    flat_off = torch.cat([off.reshape(-1).long(), torch.tensor([M], device=dev)])
+    counts = flat_off[1:] - flat_off[:-1]
+    order = torch.argsort(counts, descending=True).to(torch.int32).contiguous()
+    for name, o in (("spatial", None), ("heavy-first", order), ("spatial", None), ("heavy-first", order)):
+        lib.gsx_raster_set_tile_order(ptr(o) if o is not None else None)
+        fwd()
+        a, b = timed(fwd), timed(bwd)
+        print(f"  tile order {name}: fwd {a[0]:.1f} us, bwd {b[0]:.1f} us")
+    lib.gsx_raster_set_tile_order(None)
     fwd()
     res[("fwd", "auto")] = [timed(fwd)]
     res[("bwd", "auto")] = [timed(bwd)]

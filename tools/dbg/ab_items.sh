@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for it in 4 8 16 32; do echo "== items $it"; GSX_BIN_ITEMS=$it timeout -k 10 200 python tools/ab_raster.py 500000 C=1 C=8 2>&1 | grep "N=\|isect_bin"; done
-echo "== auto"; timeout -k 10 200 python tools/ab_raster.py 100000 500000 C=1 C=8 2>&1 | grep "N=\|isect_bin"
+for it in 1 2 4 8 16 32; do
+  GSX_BIN_ITEMS=$it timeout -k 10 300 python tools/ab_raster.py 100000 500000 2000000 C=1 C=8 2>&1 | grep -E "^N=|isect_bin_sort" | sed -e 's/ 640x480.*//' -e 's/.*sync-free): //' | paste -sd' ' | sed "s/^/items=$it: /"
+done
