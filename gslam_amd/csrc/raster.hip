@@ -609,14 +609,10 @@ bool use_v1() {
 
 }  // namespace
 
-// Launch order of the tiles (nullable): entry i = the tile the i-th workgroup takes.  See gsx_raster_set_tile_order.
-static const int32_t *g_tile_order = nullptr;
-extern "C" void gsx_raster_set_tile_order(const int32_t *order) { g_tile_order = order; }
-
 extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
                               const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
                               int tile_w, int tile_h, float visibility_min_T, float *render, float *alphas,
-                              int32_t *last_ids, int32_t *n_touched, void *stream) {
+                              int32_t *last_ids, int32_t *n_touched, const int32_t *tile_order, void *stream) {
     GSX_CHECK_ARG(offsets && render && alphas && last_ids && C >= 1 && W > 0 && H > 0);   // n_touched: NULL = not wanted
     GSX_CHECK_ARG(tile_w == (W + GSX_TILE - 1) / GSX_TILE && tile_h == (H + GSX_TILE - 1) / GSX_TILE);
     GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31));
@@ -632,11 +628,11 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
             if (n_touched)                                                                                          \
                 hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, rec,   \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   visibility_min_T, render, alphas, last_ids, n_touched, g_tile_order);                          \
+                                   visibility_min_T, render, alphas, last_ids, n_touched, tile_order);                          \
             else                                                                                                    \
                 hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, rec,  \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   visibility_min_T, render, alphas, last_ids, n_touched, g_tile_order);                          \
+                                   visibility_min_T, render, alphas, last_ids, n_touched, tile_order);                          \
         } else if (variant == 4 && !v1) {                                                                           \
             if (n_touched)                                                                                          \
                 hipLaunchKernelGGL((raster_fwd_kernel4<ch, rs, true>), dim3((unsigned)T), dim3(128), 0, st, rec,    \
@@ -675,7 +671,8 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
 extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
                               const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
                               int tile_w, int tile_h, const float *alphas, const int32_t *last_ids,
-                              const float *v_render, const float *v_alphas, float *v_rec, float *v_abs, void *stream) {
+                              const float *v_render, const float *v_alphas, float *v_rec, float *v_abs,
+                              const int32_t *tile_order, void *stream) {
     GSX_CHECK_ARG(offsets && alphas && last_ids && v_render && C >= 1 && W > 0 && H > 0);  // v_alphas: NULL = 0
     GSX_CHECK_ARG(tile_w == (W + GSX_TILE - 1) / GSX_TILE && tile_h == (H + GSX_TILE - 1) / GSX_TILE);
     GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31));
@@ -704,11 +701,11 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
             if (bwd_mode == 5)                                                                                      \
                 hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64>), dim3((unsigned)T), dim3(256), 0, st, rec,     \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec, g_tile_order);                                    \
+                                   alphas, last_ids, v_render, v_alphas, v_rec, tile_order);                                    \
             else if (bwd_mode == 6)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128>), dim3((unsigned)T), dim3(256), 0, st, rec,    \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec, g_tile_order);                                    \
+                                   alphas, last_ids, v_render, v_alphas, v_rec, tile_order);                                    \
             else if (bwd_mode == 3)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 3>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
@@ -716,7 +713,7 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
             else if (bwd_mode == 4)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 128, 3>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec, g_tile_order);                                    \
+                                   alphas, last_ids, v_render, v_alphas, v_rec, tile_order);                                    \
             else if (bwd_mode == 2)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 2>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \

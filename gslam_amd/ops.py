@@ -247,9 +247,11 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
 @torch.no_grad()
 def isect_bin_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_width: int, tile_height: int, capacity: int,
                    isect_ids: Optional[Tensor], flatten_ids: Tensor, offsets: Optional[Tensor] = None,
-                   M_dev: Optional[Tensor] = None, status: Optional[Tensor] = None):
+                   M_dev: Optional[Tensor] = None, status: Optional[Tensor] = None,
+                   tile_order: Optional[Tensor] = None):
     """Sync-free K3..K7: fills ``flatten_ids`` (and ``isect_ids``) up to ``capacity`` and returns
-    (offsets int32 [T+1], M_dev int64 [1], status int32 [1]); status bit 0 = capacity overflow."""
+    (offsets int32 [T+1], M_dev int64 [1], status int32 [1]); status bit 0 = capacity overflow.  ``tile_order``
+    (int32 [T], optional) receives the heaviest-first launch order for the rasteriser."""
     Cn, N = radii.shape
     dev = means2d.device
     T = Cn * tile_width * tile_height
@@ -258,8 +260,8 @@ def isect_bin_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_width: i
     status = torch.zeros(1, dtype=torch.int32, device=dev) if status is None else status
     ws = workspace(lib.gsx_isect_bin_workspace_bytes_n(Cn, N, tile_width, tile_height, capacity), dev, "isect_bin")
     check(lib.gsx_isect_bin_sort(ptr(means2d), ptr(radii), ptr(depths), N, Cn, tile_width, tile_height, capacity,
-                                 ptr(offsets), ptr(M_dev), ptr(status), ptr(isect_ids), ptr(flatten_ids), ptr(ws),
-                                 ws.numel(), stream_ptr(dev)), "gsx_isect_bin_sort")
+                                 ptr(offsets), ptr(M_dev), ptr(status), ptr(isect_ids), ptr(flatten_ids),
+                                 ptr(tile_order), ptr(ws), ws.numel(), stream_ptr(dev)), "gsx_isect_bin_sort")
     return offsets, M_dev, status
 
 
@@ -285,8 +287,9 @@ class _RasterizeRecords(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rec, means2d, conics, backgrounds, offsets, flatten_ids, ch, width, height, vis_min_T, absgrad,
-                has_end=False, want_touched=True, v_rec_buf=None):
-        """v_rec_buf: a [C,N,RS] buffer already cleared by the projection forward (see _Projection) for the backward's
+                has_end=False, want_touched=True, v_rec_buf=None, tile_order=None):
+        """tile_order: int32 [T] launch order of the tiles (isect_bin_sort), a scheduling hint.
+        v_rec_buf: a [C,N,RS] buffer already cleared by the projection forward (see _Projection) for the backward's
         gradient records; used once, a second backward through the same node allocates its own.
         has_end: ``offsets`` is the flat int32 [T+1] array of gsx_isect_bin_sort and ``flatten_ids`` a
         capacity-sized buffer (sync-free path); otherwise the gsplat layout ([C,tile_h,tile_w] offsets, exact M).
@@ -306,8 +309,9 @@ class _RasterizeRecords(torch.autograd.Function):
         M = flatten_ids.shape[0]
         check(lib.gsx_raster_fwd(ptr(rec), ch, ptr(bg), ptr(offsets), ptr(flatten_ids), M, 1 if has_end else 0, Cn,
                                  width, height, tile_w, tile_h, vis_min_T, ptr(render), ptr(alphas), ptr(last_ids),
-                                 ptr(n_touched), stream_ptr(dev)), "gsx_raster_fwd")
+                                 ptr(n_touched), ptr(tile_order), stream_ptr(dev)), "gsx_raster_fwd")
         ctx.save_for_backward(rec, bg, offsets, flatten_ids, alphas, last_ids)
+        ctx.tile_order = tile_order
         ctx.set_materialize_grads(False)
         ctx.cfg = (ch, width, height, absgrad, has_end)
         ctx.means2d_ref = means2d
@@ -326,7 +330,7 @@ class _RasterizeRecords(torch.autograd.Function):
         dev = rec.device
         tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
         if v_render is None and v_alphas is None:
-            return (None,) * 14
+            return (None,) * 15
         v_render = torch.zeros_like(alphas).expand(-1, -1, -1, ch).contiguous() if v_render is None \
             else v_render.contiguous()
         v_alphas = None if v_alphas is None else v_alphas.contiguous()      # NULL = zero gradient (kernel-side)
@@ -337,7 +341,8 @@ class _RasterizeRecords(torch.autograd.Function):
         check(lib.gsx_raster_bwd(ptr(rec), ch, ptr(bg), ptr(offsets), ptr(flatten_ids), flatten_ids.shape[0],
                                  1 if has_end else 0, Cn, width, height, tile_w, tile_h, ptr(alphas), ptr(last_ids),
                                  ptr(v_render),
-                                 ptr(v_alphas), ptr(v_rec), ptr(v_abs), stream_ptr(dev)), "gsx_raster_bwd")
+                                 ptr(v_alphas), ptr(v_rec), ptr(v_abs), ptr(ctx.tile_order), stream_ptr(dev)),
+              "gsx_raster_bwd")
         if absgrad and ctx.means2d_ref is not None:
             ctx.means2d_ref.absgrad = v_abs  # same side channel as gsplat (absgrad is off in gslam, rasterization.py:63)
         if getattr(ctx.means2d_ref, "_gsx_share_grad", False):
@@ -346,7 +351,7 @@ class _RasterizeRecords(torch.autograd.Function):
         v_bg = None
         if bg is not None and ctx.needs_input_grad[3]:
             v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
-        return (v_rec, v_rec[..., 0:2], v_rec[..., 2:5], v_bg) + (None,) * 10
+        return (v_rec, v_rec[..., 0:2], v_rec[..., 2:5], v_bg) + (None,) * 11
 
 
 class _PackRecords(torch.autograd.Function):

@@ -120,15 +120,16 @@ int gsx_isect_offset_encode(const int64_t *isect_ids, int64_t M, int64_t C, int 
  * sort=1, but sync-free: every size stays on the device.  offsets: int32 [T+1] (offsets[T] = min(M, INT_MAX));
  * M_dev: int64 [1] = true number of intersections; status: int32 [1], bit 0 is OR-ed in when M > M_cap (entries
  * beyond M_cap are dropped - the caller must re-run with a larger capacity); flatten_ids [M_cap]; isect_ids
- * [M_cap] nullable. */
+ * [M_cap] nullable; tile_order [T] nullable: the tiles grouped by descending list length, to be handed to
+ * gsx_raster_fwd / gsx_raster_bwd as their workgroup launch order (a scheduling hint: results do not depend on it). */
 int64_t gsx_isect_bin_workspace_bytes(int64_t C, int tile_w, int tile_h, int64_t M_cap);
 /* the same plus 16 B x C x N for the spatial pre-sort of large maps (C * N >= 2^21): with the smaller workspace the call
  * still works and places the intersections directly (slower beyond ~2M instances) */
 int64_t gsx_isect_bin_workspace_bytes_n(int64_t C, int64_t N, int tile_w, int tile_h, int64_t M_cap);
 int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, const float *depths, int64_t N, int64_t C,
                        int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev, int32_t *status,
-                       int64_t *isect_ids, int32_t *flatten_ids, void *workspace, int64_t workspace_bytes,
-                       void *stream);
+                       int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_order, void *workspace,
+                       int64_t workspace_bytes, void *stream);
 
 /* ---- K8: gsplat(fork) rasterize_to_pixels fwd (gslam/rasterization.py:325-339; fork: + n_touched) ----------------
  * rec: splat records [C*N, gsx_record_stride(CH)].  render [C,H,W,CH], alphas [C,H,W], last_ids [C,H,W] (global
@@ -141,6 +142,7 @@ int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds /*[C,CH] n
                    const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H, int tile_w,
                    int tile_h,
                    float visibility_min_T, float *render, float *alphas, int32_t *last_ids, int32_t *n_touched,
+                   const int32_t *tile_order /*[T] nullable: workgroup i renders tile tile_order[i] (gsx_isect_bin_sort)*/,
                    void *stream);
 /* ---- K9: rasterize_to_pixels bwd.  v_rec [C*N, stride] must be zeroed by the caller; gradients are accumulated
  * in record layout: v_xy(2) v_conic(3) v_opacity(1) v_colors(CH).  v_abs (nullable, [C*N,2], zeroed): absgrad.
@@ -149,7 +151,8 @@ int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int
                    const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H, int tile_w,
                    int tile_h,
                    const float *alphas, const int32_t *last_ids, const float *v_render, const float *v_alphas,
-                   float *v_rec, float *v_abs, void *stream);
+                   float *v_rec, float *v_abs, const int32_t *tile_order /*[T] nullable, as in gsx_raster_fwd*/,
+                   void *stream);
 
 /* ---- K13: spherical harmonics (gsplat.rendering.rasterization(sh_degree=)) -------------------------- */
 int gsx_sh_fwd(int degree, const float *dirs /*[C,N,3]*/, const float *coeffs /*[N,Kc,3]*/, const int32_t *radii,

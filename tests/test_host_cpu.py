@@ -44,7 +44,8 @@ def test_argument_validation_without_gpu():
     from gslam_amd._lib import lib
     rc = lib.gsx_isect_count(None, None, 10, 40, 30, None, None)
     assert rc == -1 and b"invalid argument" in lib.gsx_last_error()
-    rc = lib.gsx_raster_fwd(None, 9, None, None, None, 0, 0, 1, 640, 480, 40, 30, 0.5, None, None, None, None, None)
+    rc = lib.gsx_raster_fwd(None, 9, None, None, None, 0, 0, 1, 640, 480, 40, 30, 0.5, None, None, None, None, None,
+                            None)
     assert rc < 0
 
 

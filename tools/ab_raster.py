@@ -64,13 +64,15 @@ def run(N, C, W=640, H=480):
     v_rec = torch.zeros(C, N, 12, device=dev)
     st = stream_ptr(dev)
 
+    cur_order = [None]                                      # launch order of the tiles (None = spatial)
+
     def fwd():
         check(lib.gsx_raster_fwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, tw, th, 0.5, ptr(render_t),
-                                 ptr(alphas), ptr(last), ptr(nt), st), "fwd")
+                                 ptr(alphas), ptr(last), ptr(nt), ptr(cur_order[0]), st), "fwd")
 
     def bwd():
         check(lib.gsx_raster_bwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, tw, th, ptr(alphas),
-                                 ptr(last), ptr(v_render), ptr(v_alpha), ptr(v_rec), None, st), "bwd")
+                                 ptr(last), ptr(v_render), ptr(v_alpha), ptr(v_rec), None, ptr(cur_order[0]), st), "bwd")
 
     def sort1():
         ops.isect_tiles(m2d, radii, dep, 16, tw, th, tiles_per_gauss=tiles)
@@ -106,12 +108,17 @@ def run(N, C, W=640, H=480):
     flat_off = torch.cat([off.reshape(-1).long(), torch.tensor([M], device=dev)])
     counts = flat_off[1:] - flat_off[:-1]
     order = torch.argsort(counts, descending=True).to(torch.int32).contiguous()
-    for name, o in (("spatial", None), ("heavy-first", order), ("spatial", None), ("heavy-first", order)):
-        lib.gsx_raster_set_tile_order(ptr(o) if o is not None else None)
+    dev_order = torch.empty(C * tw * th, dtype=torch.int32, device=dev)       # what the library itself produces
+    ops.isect_bin_sort(m2d, radii, dep, tw, th, M, None, torch.empty(M, dtype=torch.int32, device=dev),
+                       tile_order=dev_order)
+    assert torch.equal(torch.sort(dev_order.long())[0], torch.arange(C * tw * th, device=dev)), "not a permutation"
+    for name, o in (("spatial", None), ("exact sort", order), ("library buckets", dev_order), ("spatial", None),
+                    ("exact sort", order), ("library buckets", dev_order)):
+        cur_order[0] = o
         fwd()
         a, b = timed(fwd), timed(bwd)
         print(f"  tile order {name}: fwd {a[0]:.1f} us, bwd {b[0]:.1f} us")
-    lib.gsx_raster_set_tile_order(None)
+    cur_order[0] = None
     fwd()
     res[("fwd", "auto")] = [timed(fwd)]
     res[("bwd", "auto")] = [timed(bwd)]
