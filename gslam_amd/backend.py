@@ -195,8 +195,17 @@ class Backend:
 
     # ---- messages out (backend.py:508-552) ---------------------------------------------------------------------------
     def sync(self):
+        """backend.py:508-519.  The map travels as a view of a double-buffered device slot filled by one launch
+        (gslam_amd.transport.MapMailbox) instead of seven clones; the tuple keeps the reference's shape."""
+        if self.splats.means.is_cuda:
+            if getattr(self, "_mailbox", None) is None:
+                from .transport import MapMailbox
+                self._mailbox = MapMailbox()
+            payload = self._mailbox.publish(self.splats)
+        else:
+            payload = self.splats.no_grad_clone()
         self.frontend_queue.put((BackendMessage.SYNC, deepcopy(self.keyframes), self.last_kf_depthmap.detach(),
-                                 self.last_kf_rgbs.detach(), self.splats.no_grad_clone(), deepcopy(self.pose_graph)))
+                                 self.last_kf_rgbs.detach(), payload, deepcopy(self.pose_graph)))
 
     def end_sync(self):
         self.frontend_queue.put((BackendMessage.END_SYNC, self.splats.clone(), deepcopy(self.keyframes)))

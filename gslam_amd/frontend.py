@@ -85,9 +85,15 @@ class Frontend:
         self.reference_depthmap = depthmap.clone()
         self.reference_frame = self.keyframes[sorted(self.keyframes.keys())[-1]]
         self.reference_rgbs = rgbs
-        self.splats = deepcopy(splats)
+        if splats.means.is_cuda:
+            # one-launch copy into the frontend's own map; same N -> same tensors, the captured tracking graph survives
+            from .transport import receive
+            self.splats, replaced = receive(getattr(self, "splats", None), splats)
+        else:
+            self.splats, replaced = deepcopy(splats), True
         self.pose_graph = pose_graph
-        self.tracker = None                                     # new map tensors: the captured closure is stale
+        if replaced:
+            self.tracker = None                                 # new map tensors: the captured closure is stale
 
     def sync_at_end(self, splats: GaussianSplattingData, keyframes):
         self.splats, self.keyframes = splats, deepcopy(keyframes)

@@ -241,10 +241,21 @@ class GraphedTracker:
                 self.graph.replay()
             check(lib.gsx_track_opt_report(self._state.data_ptr(), self._report.data_ptr(), stream_ptr(dev)),
                   "gsx_track_opt_report")
-            self._write_back(frame)
             if not sync:
+                self._write_back(frame)
                 return self._report
             rep = self._report.cpu()
+            # the map under the captured closure changes between frames (BA updates, in-place SYNC): if its tile lists
+            # outgrew the capacity baked into the graph, re-capture with the grown buffers and track this frame again
+            sig = (int(self.splats.means.shape[0]), 1, int(self.camera.width), int(self.camera.height))
+            if not self._validate(signature=sig) and not getattr(self, "_retrying", False):
+                self.graph = None
+                self._retrying = True
+                try:
+                    return self.track(frame, prev_exposure, max_eval, sync)
+                finally:
+                    self._retrying = False
+            self._write_back(frame)
             return float(rep[4]), int(rep[1])
         n_evals = 0
         last = None

@@ -94,3 +94,36 @@ def test_slam_loop_messages_and_tracking(dev):
     assert m[0] == BackendMessage.END_SYNC and len(m) == 3
     fe.handle_message_from_backend(m)
     assert fe.done and fe.splats.means.shape[0] == n
+
+
+def test_map_mailbox_double_buffer_and_in_place_receive(dev):
+    """the SYNC payload's map as a view of a double-buffered device slot (one launch per publish) and
+    an in-place, one-launch receive that keeps the consumer's tensor addresses while N is unchanged"""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.synthetic import make_scene
+    from gslam_amd.transport import MapMailbox, receive
+    src = GaussianSplattingData.from_dict(make_scene(5000, 0), dev)
+    box = MapMailbox()
+    a = box.publish(src)
+    for p in GaussianSplattingData._per_splat_params:
+        assert torch.equal(getattr(a, p), getattr(src, p)) and not getattr(a, p).requires_grad
+    assert a.ages.dtype == torch.int64
+    mine, replaced = receive(None, a)
+    assert replaced and torch.equal(mine.means, src.means) and mine.means.data_ptr() != a.means.data_ptr()
+    ptrs = [getattr(mine, p).data_ptr() for p in GaussianSplattingData._per_splat_params]
+    with torch.no_grad():
+        src.means.add_(1.0)
+        src.ages.add_(3)
+    b = box.publish(src)                                    # second slot: the first payload is still intact
+    assert b.means.data_ptr() != a.means.data_ptr()
+    assert torch.equal(a.means + 1.0, b.means) and torch.equal(a.ages + 3, b.ages)
+    mine2, replaced = receive(mine, b)
+    assert mine2 is mine and not replaced
+    assert [getattr(mine, p).data_ptr() for p in GaussianSplattingData._per_splat_params] == ptrs
+    assert torch.equal(mine.means, src.means) and torch.equal(mine.ages, src.ages)
+    c = box.publish(src)                                    # third publish reuses the first slot
+    assert c.means.data_ptr() == a.means.data_ptr()
+    bigger = GaussianSplattingData.from_dict(make_scene(7000, 1), dev)
+    d = box.publish(bigger)                                 # grown map: the slot is re-allocated, the receiver replaces
+    mine3, replaced = receive(mine, d)
+    assert replaced and mine3.means.shape[0] == 7000 and torch.equal(mine3.quats, bigger.quats)
