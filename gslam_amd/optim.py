@@ -84,6 +84,8 @@ def step_all(optimizers, decay=None):
     bumped: dict = {}
     for opt in optimizers:
         opt._collect(buckets, bumped)
+    # (Letting the Adam launch advance the counters itself - a ticket per workgroup, the last one bumps - was measured
+    # 8 % slower on the whole BA step: ~700 atomics on one address cost more than the 4.7 us launch they replace.)
     if bumped:                                         # all device step counters of this update in one tiny launch
         ctrs = list(bumped.values())
         for i in range(0, len(ctrs), _MAX_COUNTERS):
