@@ -65,9 +65,11 @@ def make_window(n_frames, W, H, dev, gt_scene, own):
 
 class StageTimer:
     """Times every C-ABI launch with HIP events on the stream the kernels are launched on (torch's current stream)."""
-    STAGES = ("gsx_project_fwd", "gsx_isect_bin_sort", "gsx_isect_scan", "gsx_isect_emit_sort",
-              "gsx_isect_offset_encode", "gsx_map_loss", "gsx_isotropic_loss", "gsx_raster_fwd",
-              "gsx_raster_bwd", "gsx_project_bwd", "gsx_ssim_fwd", "gsx_ssim_bwd", "gsx_adam_multi", "gsx_adam_multi_steps")
+    STAGES = ("gsx_pose_zhou_fwd", "gsx_project_fwd", "gsx_isect_bin_sort", "gsx_isect_scan", "gsx_isect_emit_sort",
+              "gsx_isect_offset_encode", "gsx_raster_fwd", "gsx_ssim_fwd", "gsx_ssim_bwd", "gsx_map_loss",
+              "gsx_raster_bwd", "gsx_project_bwd", "gsx_pose_zhou_bwd", "gsx_isotropic_loss", "gsx_isotropic_loss_acc",
+              "gsx_loss_finish", "gsx_counters_add", "gsx_adam_multi", "gsx_adam_multi_steps",
+              "gsx_adam_multi_steps_decay", "gsx_opacity_decay")
 
     def __init__(self):
         self.events = {s: [] for s in self.STAGES}
@@ -121,6 +123,7 @@ def algorithmic_bytes(N, C, M, P, CH):
         "gsx_ssim_bwd": 72 * P,
         "gsx_adam_multi": 420 * N,
         "gsx_adam_multi_steps": 420 * N,
+        "gsx_adam_multi_steps_decay": 420 * N + 4 * N,
     }
 
 
