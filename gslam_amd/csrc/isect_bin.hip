@@ -431,25 +431,49 @@ __device__ __forceinline__ Rect unpack_rec(const uint4 &v, int n_tiles, int &bas
 // (Tried and dropped: a tile-major walk - the wavefront loops over the tiles of its 64 records' common window, a ballot
 // gives each tile's count and ranks, one LDS add per tile - to get rid of the same-address LDS atomics that neighbouring
 // records cause; the serial ballot -> scalar -> writelane chain per tile made both passes 2-2.4x slower.)
+// Per-workgroup tile counts of a chunk of pre-sorted records.  Neighbouring records cover the same few tiles, so one LDS
+// atomic per (record, tile) piles up on a handful of addresses (384 us at 5M / 1080p).  Here every rectangle adds +-1 at
+// its four corners of a per-camera (tile_h + 1) x (tile_w + 1) difference grid in LDS - 4 atomics per record instead of
+// ~15 - and the grid is integrated once per workgroup (rows, then columns).
 __global__ __launch_bounds__(BIN_THREADS) void fine_count_kernel(const PreRec *__restrict__ recs,
                                                                  const int64_t *__restrict__ n_inst, int chunk,
-                                                                 int tile_w, int n_tiles, int T,
-                                                                 int32_t *__restrict__ cnt /*[gblocks][T]*/) {
-    extern __shared__ int s_cnt[];  // [T]
-    for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cnt[i] = 0;
+                                                                 int tile_w, int tile_h, int C,
+                                                                 int32_t *__restrict__ cnt /*[gblocks][C * tiles]*/) {
+    extern __shared__ int s_grid[];  // [C][tile_h + 1][tile_w + 1]
+    const int gw = tile_w + 1, gh = tile_h + 1, G = gw * gh;
+    const int n_tiles = tile_w * tile_h;
+    for (int i = threadIdx.x; i < C * G; i += BIN_THREADS) s_grid[i] = 0;
     __syncthreads();
     const int64_t n = n_inst[0];
     const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (int64_t i0 = lo; i0 < hi; i0 += BIN_THREADS) {    // uniform trip count: the walks need the whole wavefront
-        const int64_t i = i0 + threadIdx.x;
-        Rect r = {0, 0, 0, 0};
+    for (int64_t i = lo + threadIdx.x; i < hi; i += BIN_THREADS) {
         int base = 0;
-        if (i < hi) r = unpack_rec(reinterpret_cast<const uint4 *>(recs)[i], n_tiles, base);
-        walk_rects(r, tile_w, 0u, 0u, [&](int tile, unsigned int, unsigned int) { atomicAdd(&s_cnt[tile], 1); }, base);
+        const Rect r = unpack_rec(reinterpret_cast<const uint4 *>(recs)[i], n_tiles, base);
+        int *g = s_grid + (base / n_tiles) * G;
+        atomicAdd(&g[r.y0 * gw + r.x0], 1);
+        atomicAdd(&g[r.y0 * gw + r.x1], -1);
+        atomicAdd(&g[r.y1 * gw + r.x0], -1);
+        atomicAdd(&g[r.y1 * gw + r.x1], 1);
     }
     __syncthreads();
-    int32_t *row = cnt + (int64_t)blockIdx.x * T;
-    for (int i = threadIdx.x; i < T; i += BIN_THREADS) row[i] = s_cnt[i];
+    for (int row = threadIdx.x; row < C * gh; row += BIN_THREADS) {          // prefix along x
+        int *p = s_grid + (row / gh) * G + (row % gh) * gw;
+        int run = 0;
+        for (int x = 0; x < gw; ++x) { run += p[x]; p[x] = run; }
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < C * gw; col += BIN_THREADS) {          // prefix along y
+        int *p = s_grid + (col / gw) * G + (col % gw);
+        int run = 0;
+        for (int y = 0; y < gh; ++y) { run += p[y * gw]; p[y * gw] = run; }
+    }
+    __syncthreads();
+    int32_t *row_out = cnt + (int64_t)blockIdx.x * C * n_tiles;
+    for (int i = threadIdx.x; i < C * n_tiles; i += BIN_THREADS) {
+        const int c = i / n_tiles, tl = i - c * n_tiles;
+        const int y = tl / tile_w, x = tl - y * tile_w;
+        row_out[i] = s_grid[c * G + y * gw + x];
+    }
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void fine_place_kernel(const PreRec *__restrict__ recs,
@@ -724,12 +748,22 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
     static_assert(BIG_NB * 4 <= (CNT_MAXN + CNT_NB / 2) * 8, "streaming-regime cursors must fit behind the window");
     const int nb = small ? CNT_NB : BIG_NB;
     // 1. min / max of the depth bits (positive floats: same order as the values); the LDS regime stages the keys
+    // The streaming regime samples one 512-key block in four for the range (a quarter of this pass's traffic): keys
+    // outside the sampled range clamp to the first / last bucket, which keeps the map monotone (only the balance of the
+    // two end buckets can suffer, and the degenerate-bucket check covers that).
     unsigned int dmin = 0xffffffffu, dmax = 0u;
-    for (int i = t; i < n; i += SORT_THREADS) {
-        const unsigned long long k = seg[i];
-        if (small) s_a[i] = k;
-        const unsigned int d = (unsigned int)(k >> 32);
-        dmin = min(dmin, d); dmax = max(dmax, d);
+    if (small) {
+        for (int i = t; i < n; i += SORT_THREADS) {
+            const unsigned long long k = seg[i];
+            s_a[i] = k;
+            const unsigned int d = (unsigned int)(k >> 32);
+            dmin = min(dmin, d); dmax = max(dmax, d);
+        }
+    } else {
+        for (int i = t; i < n; i += 4 * SORT_THREADS) {
+            const unsigned int d = (unsigned int)(seg[i] >> 32);
+            dmin = min(dmin, d); dmax = max(dmax, d);
+        }
     }
     for (int i = t; i < nb; i += SORT_THREADS) s_cur[i] = 0;
 #pragma unroll
@@ -900,12 +934,15 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
         const char *ps = getenv("GSX_BIN_PRESORT");
         const int sw = (tile_w + SUPER - 1) / SUPER, S = sw * ((tile_h + SUPER - 1) / SUPER);
         const int64_t rec_cap = C * N;
-        const bool presort_ok = N > 0 && M_cap > 0 && workspace_bytes >= L.total + rec_cap * 16 && T <= 16000 && C <= 255 && tile_w < 4096 && tile_h < 4096 &&
+        const bool presort_ok = N > 0 && M_cap > 0 && workspace_bytes >= L.total + rec_cap * 16 && T <= 16000 &&
+                                C * G * 4 <= 65536 && C <= 255 && tile_w < 4096 && tile_h < 4096 &&
                                 S * (int64_t)sizeof(int) <= 65536;
         // measured (MI355X): 5M Gaussians at 1920x1080 (8160 tiles per camera): count + placement 1.70 -> 1.14 ms;
         // 2M x 8 cameras at 640x480 (1200 tiles per camera): 1.08 -> 1.23 ms - with few tiles per camera the direct
-        // placement already writes long enough runs, so the pre-sort is for high-resolution renders of large maps only
-        const bool presort = presort_ok && (ps ? ps[0] == '1' : (C * N >= ((int64_t)1 << 21) && n_tiles >= 4096));
+        // placement already writes long enough runs (after the counting pass moved to a difference grid the pre-sort
+        // wins from ~8M instances on: 2M x 8: tile lists 1.83 -> 1.71 ms; 500 k x 8 still loses, 318 -> 357 us)
+        const bool presort = presort_ok && (ps ? ps[0] == '1' : ((C * N >= ((int64_t)1 << 21) && n_tiles >= 4096) ||
+                                                                  C * N >= ((int64_t)1 << 23)));
         if (presort) {
             const unsigned gblocks = (unsigned)((N + BIN_THREADS * items - 1) / (BIN_THREADS * items));
             int32_t *coff = cursor;                          // [C * S + 1] (S <= tiles per camera)
@@ -928,8 +965,8 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
             const int64_t inst_cap = rec_cap;
             while ((inst_cap + chunk - 1) / chunk > GB_MAX) chunk *= 2;
             const unsigned gb2 = (unsigned)((inst_cap + chunk - 1) / chunk);
-            hipLaunchKernelGGL(fine_count_kernel, dim3(gb2), dim3(BIN_THREADS), (size_t)(T * 4), st, recs, n_inst,
-                               (int)chunk, tile_w, (int)n_tiles, (int)T, cnt);
+            hipLaunchKernelGGL(fine_count_kernel, dim3(gb2), dim3(BIN_THREADS), (size_t)(C * G * 4), st, recs, n_inst,
+                               (int)chunk, tile_w, tile_h, (int)C, cnt);
             GSX_CHECK_LAUNCH();
             hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((T + 63) / 64), 1u), dim3(64 * CS_GROUPS), 0, st, cnt,
                                (int)gb2, (int)T, offsets);

@@ -224,7 +224,10 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
         isect_ids = torch.empty(M, dtype=torch.int64, device=dev)
         flatten_ids = torch.empty(M, dtype=torch.int32, device=dev)
         if M > 0:
-            isect_bin_sort(means2d, radii, depths, tile_width, tile_height, M, isect_ids, flatten_ids)
+            off, _, _ = isect_bin_sort(means2d, radii, depths, tile_width, tile_height, M, isect_ids, flatten_ids)
+            # the binning already produced the per-tile offsets: isect_offset_encode(isect_ids, ...) hands them out
+            # instead of re-deriving them from the 64-bit keys (175 us for 76 M intersections)
+            isect_ids._gsx_offsets = (off[:-1].view(Cn, tile_height, tile_width), isect_ids._version)
         return tiles_per_gauss, isect_ids, flatten_ids
     cum = torch.empty(Cn * N, dtype=torch.int64, device=dev)
     M = 0
@@ -268,6 +271,10 @@ def isect_bin_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_width: i
 @torch.no_grad()
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
     """gsplat isect_offset_encode (gslam/rasterization.py:274) -> int32 [C, tile_h, tile_w]."""
+    cached = getattr(isect_ids, "_gsx_offsets", None)
+    if cached is not None and cached[1] == isect_ids._version and \
+            tuple(cached[0].shape) == (n_cameras, tile_height, tile_width):
+        return cached[0]
     isect_ids = isect_ids.contiguous()
     dev = isect_ids.device
     offsets = torch.empty(n_cameras, tile_height, tile_width, dtype=torch.int32, device=dev)

@@ -131,6 +131,8 @@ def test_isect_bit_exact(dev, oracle32, n, c, W, H):
     assert np.array_equal(_np(ids), oids)
     assert np.array_equal(_np(flat), oflat)
     assert np.array_equal(_np(off), ooff)
+    # `off` came from the binning (attached to ids by isect_tiles); the standalone K7 kernel on a bare copy of the keys
+    assert np.array_equal(_np(ops.isect_offset_encode(ids.clone(), c, tw, th)), ooff)
     assert len(oids) > 0
     # unsorted emission order is part of the contract too (sort=False)
     _, ids_u, flat_u = ops.isect_tiles(torch.from_numpy(m2d).to(dev), torch.from_numpy(radii).to(dev),

@@ -1,0 +1,4 @@
+set -e
+cd $GRAFT_REPO_ROOT
+timeout -k 10 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout -k 10 300 python tools/bench_configs.py 2>&1 | tail -2
