@@ -269,7 +269,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, int64_t M_cap, i
                                                          int32_t *__restrict__ order) {
     __shared__ long long s_scan[1024];
     __shared__ int s_bucket[257];
-    __shared__ int s_max;
+    __shared__ int s_wmax[16];
     const int t = threadIdx.x;
     const int per = (T + 1023) / 1024;
     const int lo = min(T, t * per), hi = min(T, lo + per);
@@ -279,11 +279,13 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, int64_t M_cap, i
     s_scan[t] = sum;
     if (order) {
         if (t < 257) s_bucket[t] = 0;
-        if (t == 0) s_max = 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off, 64));
+        if ((t & 63) == 0) s_wmax[t >> 6] = cmax;            // (1024 atomicMax on one LDS word took as long as the scan)
         __syncthreads();
-        atomicMax(&s_max, cmax);
-        __syncthreads();
-        const int mx = max(s_max, 1);
+        int mx = 1;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) mx = max(mx, s_wmax[w]);
         for (int i = lo; i < hi; ++i) {
             const int b = 255 - (int)(((long long)max(offsets[i], 0) * 255) / mx);     // bucket 0 = longest lists
             atomicAdd(&s_bucket[b + 1], 1);
