@@ -153,7 +153,9 @@ class GraphedTracker:
     def _closure_body(self, advance: bool = False):
         for p in self.params:
             p.grad = None               # AccumulateGrad then adopts the fresh gradient tensor (no accumulate kernel)
-        out = self.splats([self.camera], [self.pose], render_depth=True, need_n_touched=False)   # tracking never reads it
+        # the reference renders the depth channel in its tracking closure too (frontend.py:627-631) but only reads it
+        # under use_gt_depths (frontend.py:134-137), which this tracker does not implement: four channels instead of five
+        out = self.splats([self.camera], [self.pose], render_depth=False, need_n_touched=False)  # n_touched: never read
         # value and analytic gradient in one pass (csrc/loss.hip); the backward is seeded at the render tensor
         out2, v_render, v_exposure = self._loss_fn(out, self.img, self.exposure)
         torch.autograd.backward([out._render], [v_render])
