@@ -191,7 +191,19 @@ class Backend:
         self._render_last_keyframe()
 
     def optimize_poses_lbfgs(self):
-        return optimize_poses_lbfgs(self.splats, self.optimization_window(), self.conf)
+        """backend.py:447-506.  On the GPU the L-BFGS state machine runs on the device (mapping.GraphedPoseRefiner, one
+        captured closure per window composition); the host version remains for CPU tensors and oversized windows."""
+        window = self.optimization_window()
+        learn = [x for x in window if x.index != 0]
+        if not self.splats.means.is_cuda or not learn or 9 * len(learn) > 80:
+            return optimize_poses_lbfgs(self.splats, window, self.conf)
+        key = (tuple(id(x) for x in window), int(self.splats.means.shape[0]), self.splats.means.data_ptr())
+        cached = getattr(self, "_pose_refiner", None)
+        if cached is None or cached[0] != key:
+            from .mapping import GraphedPoseRefiner
+            cached = (key, GraphedPoseRefiner(self.splats, window, self.conf))
+            self._pose_refiner = cached
+        return cached[1].run()[0]
 
     # ---- messages out (backend.py:508-552) ---------------------------------------------------------------------------
     def sync(self):

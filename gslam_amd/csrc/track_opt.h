@@ -18,8 +18,14 @@
 #define TO_FN static inline
 #endif
 
+/* Capacity of one instantiation; a translation unit may set both before including this header (window_opt.hip:
+ * 8 poses x 9 parameters, history 10 for gslam/backend.py:447-506). */
+#ifndef TO_MAXN
 #define TO_MAXN 16   /* parameters: 3 (dt) + 6 (dR) + 2 (exposure) = 11 in the tracker */
-#define TO_MAXH 8    /* L-BFGS history (the reference uses 5) */
+#endif
+#ifndef TO_MAXH
+#define TO_MAXH 8    /* L-BFGS history (the tracker uses 5) */
+#endif
 
 enum { TO_PHASE_ADAM = 0, TO_PHASE_LBFGS_INIT = 1, TO_PHASE_LS_BRACKET = 2, TO_PHASE_LS_ZOOM = 3, TO_PHASE_DONE = 4 };
 

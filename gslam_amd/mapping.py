@@ -291,6 +291,122 @@ def optimize_poses_lbfgs(splats: GaussianSplattingData, window: List[Frame], con
     return last_loss
 
 
+class GraphedPoseRefiner:
+    """`Backend.optimize_poses_lbfgs` (gslam/backend.py:447-506) with the optimiser on the device:
+    torch.optim.LBFGS(history_size=10, strong_wolfe, tolerance_change=1e-7) over the poses of the window (the pose of
+    frame 0 stays fixed, :459-462) restated as the state machine of csrc/track_opt.h (sized for 80 parameters in
+    csrc/window_opt.hip) and advanced by one single-wave launch at the end of the captured closure.  One refinement is
+    ``max_eval + 1`` replays of one HIP graph and ONE read-back, instead of a `.item()` per closure (backend.py:501)
+    and ~40 eager launches each.  The closure is the host version's: C <= 8 cameras rendered against the frozen map,
+    photometric term only, pose-only backward.  Build one per window composition (the graph holds the addresses of the
+    window's pose parameters and images); ``run()`` may be called repeatedly while the same keyframes are in it."""
+
+    def __init__(self, splats: GaussianSplattingData, window: List[Frame], conf: Optional[MapConfig] = None,
+                 max_eval: int = 25):
+        from .rasterization import validate
+        self.splats, self.window, self.conf, self.max_eval = splats, list(window), conf or MapConfig(), int(max_eval)
+        self.params = [p for x in self.window if x.index != 0 for p in x.pose.parameters() if p.requires_grad]
+        self.n = sum(p.numel() for p in self.params)
+        if self.n == 0:
+            raise ValueError("no learnable pose in the window")
+        if self.n > 80 or len(self.params) > 16:
+            raise ValueError("window too large for the device optimiser (80 parameters in 16 tensors)")
+        dev = splats.means.device
+        self.cameras = [x.camera for x in self.window]
+        self.poses = [x.pose for x in self.window]
+        self.gt_imgs = create_batch(self.window, lambda x: x.img)
+        self.exposure = create_batch(self.window, lambda x: x.exposure_params).detach().clone()
+        self._state = torch.zeros(int(lib.gsx_window_opt_state_bytes()), dtype=torch.uint8, device=dev)
+        self._report = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._validate = validate
+        self._sig = (int(splats.means.shape[0]), len(self.window), int(self.cameras[0].width), int(self.cameras[0].height))
+        self.graph = None
+        self.loss = None
+
+    def _closure(self, advance: bool):
+        from .losses import loss_and_grads
+        for x in self.window:
+            for p in x.pose.parameters():
+                p.grad = None
+        out = self.splats(self.cameras, self.poses, render_depth=False, need_n_touched=False)
+        out2, v_render, _v_exp, _ = loss_and_grads(out._render, out.alphas, self.gt_imgs, self.exposure, None, None, -1,
+                                                   -1 if out._betas_index is None else out._betas_index, 1.0, 0.0, 0.0,
+                                                   0.0, 0 if self.conf.active_gs else 1)
+        torch.autograd.backward([out._render], [v_render])
+        loss = out2[0:1]
+        if advance:
+            import ctypes as C
+            n = len(self.params)
+            check(lib.gsx_window_opt_advance(
+                self._state.data_ptr(), n, (C.c_void_p * n)(*[p.data_ptr() for p in self.params]),
+                (C.c_void_p * n)(*[p.grad.data_ptr() for p in self.params]),
+                (C.c_int * n)(*[p.numel() for p in self.params]), loss.data_ptr(), stream_ptr(loss.device)),
+                "gsx_window_opt_advance")
+        return loss
+
+    def _frozen_map(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            flags = [p.requires_grad for p in self.splats.parameters()]
+            for p in self.splats.parameters():
+                p.requires_grad_(False)                       # only the poses move: pose-only projection backward
+            try:
+                yield
+            finally:
+                for p, r in zip(self.splats.parameters(), flags):
+                    p.requires_grad_(r)
+        return cm()
+
+    def capture(self):
+        from ._sync import capture_lock
+        with capture_lock, self._frozen_map():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _attempt in range(4):
+                    for _ in range(2):
+                        self._closure(False)
+                    if self._validate(signature=self._sig):
+                        break
+                else:
+                    raise RuntimeError("intersection capacity keeps changing during warm-up")
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+                self.loss = self._closure(True)
+
+    def run(self):
+        """-> (last closure loss, number of closure evaluations), poses updated in place"""
+        with torch.no_grad():
+            self.exposure.copy_(create_batch(self.window, lambda x: x.exposure_params).detach())
+        for attempt in range(2):
+            saved = [p.detach().clone() for p in self.params]
+            if self.graph is None:
+                self.capture()
+                with torch.no_grad():
+                    for p, s0 in zip(self.params, saved):
+                        p.copy_(s0)                           # the warm-up closures did not move them, the capture neither
+            dev = self._state.device
+            # torch.optim.LBFGS defaults of the reference call: lr 1, max_iter 20, max_eval 25, tolerance_grad 1e-7
+            check(lib.gsx_window_opt_init(self._state.data_ptr(), self.n, 0, 0.0, 1.0, 10, 20, self.max_eval, 1e-7, 1e-7,
+                                          stream_ptr(dev)), "gsx_window_opt_init")
+            for _ in range(self.max_eval + 1):
+                self.graph.replay()
+            check(lib.gsx_window_opt_report(self._state.data_ptr(), self._report.data_ptr(), stream_ptr(dev)),
+                  "gsx_window_opt_report")
+            rep = self._report.cpu()
+            if self._validate(signature=self._sig):
+                return float(rep[4]), int(rep[1])
+            with torch.no_grad():                             # tile lists outgrew the captured capacity: redo
+                for p, s0 in zip(self.params, saved):
+                    p.copy_(s0)
+            self.graph = None
+        raise RuntimeError("intersection buffers kept overflowing")
+
+
 class GraphedBundleAdjuster:
     """A BA iteration over a FIXED window captured into HIP graphs and replayed: the ~45 launches of a step (pose
     chain, K1, binning, sort, K8, SSIM, loss, K9, K2, Adam, decay) cost one graph launch on the host.  Multi-GPU: two

@@ -268,6 +268,14 @@ int gsx_track_opt_init(void *state, int n_params, int n_adam, float lr_adam, dou
 int gsx_track_opt_advance(void *state, int n_tensors, float *const *params, const float *const *grads,
                           const int *numels, const float *loss, void *stream);
 int gsx_track_opt_report(const void *state, float *out8, void *stream);
+/* The same state machine sized for the backend's window pose refinement (gslam/backend.py:447-506): up to 80 parameters
+ * in up to 16 tensors, L-BFGS history up to 10; n_adam = 0 skips the Adam phase.  Arguments as above. */
+int64_t gsx_window_opt_state_bytes(void);
+int gsx_window_opt_init(void *state, int n_params, int n_adam, float lr_adam, double lr_lbfgs, int history, int max_iter,
+                        int max_eval, double tol_grad, double tol_change, void *stream);
+int gsx_window_opt_advance(void *state, int n_tensors, float *const *params, const float *const *grads,
+                           const int *numels, const float *loss, void *stream);
+int gsx_window_opt_report(const void *state, float *out8, void *stream);
 
 /* ---- map maintenance: every per-Gaussian array re-packed in ONE launch.
  * gsx_gather_rows: dst[k][r] = src[k][index[r]] for r < n_out, k < n_tensors (<= 32); the masked re-allocation of

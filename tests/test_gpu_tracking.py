@@ -156,3 +156,36 @@ def test_optimize_poses_lbfgs(dev):
     assert torch.equal(window[0].pose().detach(), p0)
     assert after[1] < 0.6 * before[1] and after[2] < 0.6 * before[2], (before, after)
     assert all(not p.requires_grad for p in m.parameters())   # frozen-map state restored as it was
+
+
+def test_device_pose_refiner_matches_host_lbfgs(dev):
+    """SURVEY 8f rank 2, backend side: the window pose L-BFGS of gslam/backend.py:447-506 as a device state machine
+    (mapping.GraphedPoseRefiner, csrc/window_opt.hip) against torch.optim.LBFGS on the host over the same closure."""
+    from gslam_amd.mapping import GraphedPoseRefiner, optimize_poses_lbfgs
+    m, cam, frame = _setup(dev)
+
+    def make():
+        w = [frame(0, 0), frame(2, 1), frame(4, 3)]
+        w[0].index = 0
+        return w
+    wh, wd = make(), make()
+    before = [_pose_err(f) for f in wd]
+    last_h = optimize_poses_lbfgs(m, wh, max_eval=25)
+    p0 = wd[0].pose().detach().clone()
+    ref = GraphedPoseRefiner(m, wd, max_eval=25)
+    assert ref.n == 18 and len(ref.params) == 4
+    last_d, n_evals = ref.run()
+    torch.cuda.synchronize()
+    assert torch.equal(wd[0].pose().detach(), p0)                       # frame 0 stays fixed (backend.py:459-462)
+    assert 2 <= n_evals <= 26 and np.isfinite(last_d)
+    after_d, after_h = [_pose_err(f) for f in wd], [_pose_err(f) for f in wh]
+    assert after_d[1] < 0.6 * before[1] and after_d[2] < 0.6 * before[2], (before, after_d)
+    # same optimiser, same closure: the two runs end at the same poses up to float noise in the line search
+    assert abs(last_d - last_h) < 2e-2 * abs(last_h), (last_d, last_h)
+    for fd, fh in zip(wd[1:], wh[1:]):
+        assert (fd.pose().detach() - fh.pose().detach()).abs().max() < 5e-3
+    # a second refinement of the same window replays the same graph
+    g = ref.graph
+    last2, _ = ref.run()
+    assert ref.graph is g and last2 <= last_d * 1.001
+    assert all(not p.requires_grad for p in m.parameters())
