@@ -17,6 +17,7 @@ import math
 import random
 import time
 from collections import defaultdict
+import os
 from copy import deepcopy
 from dataclasses import dataclass
 from itertools import combinations
@@ -195,7 +196,8 @@ class Backend:
         captured closure per window composition); the host version remains for CPU tensors and oversized windows."""
         window = self.optimization_window()
         learn = [x for x in window if x.index != 0]
-        if not self.splats.means.is_cuda or not learn or 9 * len(learn) > 80:
+        if (not self.splats.means.is_cuda or not learn or 9 * len(learn) > 80
+                or os.environ.get("GSX_POSE_REFINER", "device") == "host"):
             return optimize_poses_lbfgs(self.splats, window, self.conf)
         key = (tuple(id(x) for x in window), int(self.splats.means.shape[0]), self.splats.means.data_ptr())
         cached = getattr(self, "_pose_refiner", None)
