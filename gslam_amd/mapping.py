@@ -378,6 +378,16 @@ class GraphedPoseRefiner:
             with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
                 self.loss = self._closure(True)
 
+    def run_async(self):
+        """one refinement without any read-back (the caller polls gslam_amd.rasterization.validate later): the
+        graph must have been captured by an earlier run()"""
+        assert self.graph is not None
+        dev = self._state.device
+        check(lib.gsx_window_opt_init(self._state.data_ptr(), self.n, 0, 0.0, 1.0, 10, 20, self.max_eval, 1e-7, 1e-7,
+                                      stream_ptr(dev)), "gsx_window_opt_init")
+        for _ in range(self.max_eval + 1):
+            self.graph.replay()
+
     def run(self):
         """-> (last closure loss, number of closure evaluations), poses updated in place"""
         with torch.no_grad():

@@ -29,6 +29,9 @@ def main():
                     help="run mapping and tracking one after the other on one stream (default: the BA iterations of a "
                          "keyframe run on their own HIP stream while the next frames are tracked, as the reference's "
                          "backend process does beside its frontend process)")
+    ap.add_argument("--pose-lbfgs", action="store_true",
+                    help="after the BA iterations of a keyframe also run the backend's window pose refinement "
+                         "(backend.py:447-506: L-BFGS, <= 25 closures over the 8 keyframes) on the mapping stream")
     ap.add_argument("--host-optimizer", action="store_true",
                     help="keep torch.optim.Adam / LBFGS on the host (one loss.item() per closure, as the reference)")
     args = ap.parse_args()
@@ -67,10 +70,15 @@ def main():
         gba = GraphedBundleAdjuster(ba, keyframes)
     else:
         ba.step(keyframes)
+    refiner = None
+    if args.pose_lbfgs and not args.no_graph:
+        from gslam_amd.mapping import GraphedPoseRefiner
+        refiner = GraphedPoseRefiner(backend_map, keyframes)
+        refiner.run()                                       # capture
     torch.cuda.synchronize()
     assert validate(dev)
 
-    n_closures, n_ba = 0, 0
+    n_closures, n_ba, n_refine = 0, 0, 0
     t_track = t_map = 0.0
     overlap = not (args.serial or args.no_graph)
     map_stream = torch.cuda.Stream() if overlap else None
@@ -97,6 +105,9 @@ def main():
                     for _ in range(args.ba_iters):
                         gba.step()
                         n_ba += 1
+                    if refiner is not None:
+                        refiner.run_async()
+                        n_refine += 1
             else:
                 for _ in range(args.ba_iters):                 # same window object: images/poses updated in place
                     (gba.step() if gba is not None else ba.step(keyframes))
@@ -112,7 +123,7 @@ def main():
         "metric": "tracking+mapping fps @640x480", "gaussians": N, "frames": args.frames, "fps": round(args.frames / elapsed, 2),
         "ms_per_frame": round(elapsed / args.frames * 1e3, 2), "closures_per_frame": round(n_closures / args.frames, 1),
         "ms_per_closure": None if overlap else round(t_track / max(n_closures, 1) * 1e3, 3), "ba_iters": n_ba,
-        "ba_window": args.window, "ms_per_ba_iter": None if overlap else round(t_map / max(n_ba, 1) * 1e3, 3),
+        "pose_lbfgs_runs": n_refine, "ba_window": args.window, "ms_per_ba_iter": None if overlap else round(t_map / max(n_ba, 1) * 1e3, 3),
         "tracking_share": None if overlap else round(t_track / elapsed, 3),
         "launch": "eager" if args.no_graph else "hip-graph", "mapping": "own stream, overlapped" if overlap else "serial",
         "optimizer": "device state machine" if tracker.device_optimizer else "host torch.optim", "capacity_ok": ok}))
