@@ -231,47 +231,68 @@ struct FinishArgs {
 constexpr int FIN_WAVES = 16;
 
 __global__ __launch_bounds__(64 * FIN_WAVES) void loss_finish_kernel(FinishArgs a) {
-    __shared__ float s_sum[5];
+    // Work items = (camera, segment of its partial rows): S segments per camera so that a window of few cameras still
+    // uses all 16 wavefronts; an item sums all five columns of its rows (one 24-byte row per load group, four rows in
+    // flight per lane).  Wide windows (C > 16): one item per camera, the wavefronts take the cameras round-robin.
+    __shared__ float s_glob[FIN_WAVES][3];                   // per-wavefront sums of the three window-wide terms
+    __shared__ float s_exp[2 * FIN_WAVES][2];                // exposure-gradient pieces of (camera, segment), C * S <= 32
+    __shared__ float s_aux[FIN_WAVES][2];                    // SSIM / isotropic pieces
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 5) s_sum[threadIdx.x] = 0.f;
-    __syncthreads();
-    const int n_jobs = 5 + 2 * a.C;
-    // strided sum with four loads in flight per lane (a dependent load per trip made this launch 9 us at 1200 rows)
-    auto strided = [&](const float *p, int64_t n, int64_t stride) -> float {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int64_t i = lane;
-        for (; i + 192 < n; i += 256) {
-            a0 += p[i * stride]; a1 += p[(i + 64) * stride]; a2 += p[(i + 128) * stride]; a3 += p[(i + 192) * stride];
+    const int S = a.C >= FIN_WAVES ? 1 : (FIN_WAVES + a.C - 1) / a.C;
+    const int n_items = a.C * S;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    for (int it = wave; it < n_items; it += FIN_WAVES) {
+        const int c = it / S, seg = it - c * S;
+        const int r0 = (int)((int64_t)a.bpc * seg / S), r1 = (int)((int64_t)a.bpc * (seg + 1) / S);
+        const float *base = a.map_part + (int64_t)c * a.bpc * NPART;
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        int i = r0 + lane;
+        for (; i + 192 < r1; i += 256) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float *row = base + (int64_t)(i + 64 * u) * NPART;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) acc[k] += row[k];
+            }
         }
-        for (; i < n; i += 64) a0 += p[i * stride];
-        return (a0 + a1) + (a2 + a3);
-    };
-    for (int j = wave; j < n_jobs; j += FIN_WAVES) {
-        float acc = 0.f;
-        if (j < 3) {
-            acc = strided(a.map_part + j, (int64_t)a.C * a.bpc, NPART);
-        } else if (j == 3) {
-            if (a.ssim_part) acc = strided(a.ssim_part, a.n_ssim, 1);
-        } else if (j == 4) {
-            if (a.iso_part) acc = strided(a.iso_part, a.n_iso, 1);
-        } else {
-            const int c = (j - 5) >> 1, k = 3 + ((j - 5) & 1);
-            acc = strided(a.map_part + (int64_t)c * a.bpc * NPART + k, a.bpc, NPART);
+        for (; i < r1; i += 64) {
+            const float *row = base + (int64_t)i * NPART;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[k] += row[k];
         }
-        const float tot = gsx_wave_sum(acc);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] = gsx_wave_sum(acc[k]);
+        g0 += acc[0]; g1 += acc[1]; g2 += acc[2];
         if (lane == 0) {
-            if (j < 5) s_sum[j] = tot;
-            else if (a.v_exposure) a.v_exposure[j - 5] = tot;
+            if (S == 1) { if (a.v_exposure) { a.v_exposure[2 * c] = acc[3]; a.v_exposure[2 * c + 1] = acc[4]; } }
+            else { s_exp[it][0] = acc[3]; s_exp[it][1] = acc[4]; }
         }
     }
+    // SSIM and isotropic partials: every wavefront takes a slice
+    float sa = 0.f, ia = 0.f;
+    if (a.ssim_part) for (int64_t i = threadIdx.x; i < a.n_ssim; i += 64 * FIN_WAVES) sa += a.ssim_part[i];
+    if (a.iso_part) for (int64_t i = threadIdx.x; i < a.n_iso; i += 64 * FIN_WAVES) ia += a.iso_part[i];
+    sa = gsx_wave_sum(sa); ia = gsx_wave_sum(ia);
+    if (lane == 0) { s_glob[wave][0] = g0; s_glob[wave][1] = g1; s_glob[wave][2] = g2; s_aux[wave][0] = sa; s_aux[wave][1] = ia; }
     __syncthreads();
+    if (S > 1 && a.v_exposure && threadIdx.x < 2 * a.C) {   // (camera, component): add the camera's segments
+        const int c = threadIdx.x >> 1, k = threadIdx.x & 1;
+        float acc = 0.f;
+        for (int seg = 0; seg < S; ++seg) acc += s_exp[c * S + seg][k];
+        a.v_exposure[2 * c + k] = acc;
+    }
     if (threadIdx.x == 0) {
+        float sum5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < FIN_WAVES; ++w) {
+            sum5[0] += s_glob[w][0]; sum5[1] += s_glob[w][1]; sum5[2] += s_glob[w][2];
+            sum5[3] += s_aux[w][0]; sum5[4] += s_aux[w][1];
+        }
         float o0 = a.bias0, o1 = a.bias1;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { o0 += a.c0[k] * s_sum[k]; o1 += a.c1[k] * s_sum[k]; }
+        for (int k = 0; k < 5; ++k) { o0 += a.c0[k] * sum5[k]; o1 += a.c1[k] * sum5[k]; }
         a.out2[0] = o0; a.out2[1] = o1;
+        if (a.sums5) for (int k = 0; k < 5; ++k) a.sums5[k] = sum5[k];
     }
-    if (threadIdx.x < 5 && a.sums5) a.sums5[threadIdx.x] = s_sum[threadIdx.x];
 }
 
 __global__ __launch_bounds__(LB) void opacity_decay_kernel(float *__restrict__ logit_opac,

@@ -304,20 +304,35 @@ __global__ __launch_bounds__(PBWD_THREADS) void project_bwd_kernel(
         if (active && radii[idx] > 0 && project_core(mean, S, cam, W, H, eps2d, near_p, far_p, p)) {
             const float fx = cam.fx, fy = cam.fy;
             float vdepth = v_depths ? v_depths[idx] : 0.f;
+            // the usual case: v_means2d / v_conics are the xy / conic columns of the same gradient record: the 48-byte
+            // row comes in as three 16-byte loads instead of twelve scalar ones
+            float row[12];
+            const bool fused_row = v_rec && RS == 12 && v_means2d == v_rec && m2d_stride == 12 && v_conics == v_rec + 2 &&
+                                   con_stride == 12;
+            if (fused_row) {
+                const float4 *r4 = reinterpret_cast<const float4 *>(v_rec + idx * 12);
+                const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2];
+                row[0] = q0.x; row[1] = q0.y; row[2] = q0.z; row[3] = q0.w; row[4] = q1.x; row[5] = q1.y; row[6] = q1.z;
+                row[7] = q1.w; row[8] = q2.x; row[9] = q2.y; row[10] = q2.z; row[11] = q2.w;
+            } else {
+                row[0] = v_means2d[idx * m2d_stride]; row[1] = v_means2d[idx * m2d_stride + 1];
+                row[2] = v_conics[idx * con_stride]; row[3] = v_conics[idx * con_stride + 1];
+                row[4] = v_conics[idx * con_stride + 2];
+#pragma unroll
+                for (int k = 5; k < 12; ++k) row[k] = (v_rec && k < RS) ? v_rec[idx * RS + k] : 0.f;
+            }
             if (v_rec) {
-                const float *vr = v_rec + idx * RS;
                 if (!POSE_ONLY) {
-                    v_opac_sum += vr[5];
-                    v_col_sum[0] += vr[6]; v_col_sum[1] += vr[7]; v_col_sum[2] += vr[8];
+                    v_opac_sum += row[5];
+                    v_col_sum[0] += row[6]; v_col_sum[1] += row[7]; v_col_sum[2] += row[8];
                 }
                 int n = 9;
-                if (flags & GSX_PROJ_RENDER_DEPTH) vdepth += vr[n++];
-                if (!POSE_ONLY && (flags & GSX_PROJ_BETAS)) v_beta_sum += vr[n++];
+                if (flags & GSX_PROJ_RENDER_DEPTH) vdepth += row[n++];
+                if (!POSE_ONLY && (flags & GSX_PROJ_BETAS)) v_beta_sum += row[n++];
             }
             // 1. conic = inverse(blurred cov2d): GX = -Y G Y
             const float a = p.conic[0], b = p.conic[1], cc = p.conic[2];
-            const float va = v_conics[idx * con_stride], vb = 0.5f * v_conics[idx * con_stride + 1],
-                        vc = v_conics[idx * con_stride + 2];
+            const float va = row[2], vb = 0.5f * row[3], vc = row[4];
             const float P00 = va * a + vb * b, P01 = va * b + vb * cc;
             const float P10 = vb * a + vc * b, P11 = vb * b + vc * cc;
             float G00 = -(a * P00 + b * P10), G01 = -(a * P01 + b * P11), G11 = -(b * P01 + cc * P11);
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(PBWD_THREADS) void project_bwd_kernel(
                     vJ[i * 3 + j] = 2.0f * (GJ[i * 3 + 0] * symget(p.Sc, 0, j) + GJ[i * 3 + 1] * symget(p.Sc, 1, j) +
                                             GJ[i * 3 + 2] * symget(p.Sc, 2, j));
             const float x = p.pc[0], y = p.pc[1], rz = p.rz, rz2 = rz * rz, rz3 = rz2 * rz;
-            const float vmx = v_means2d[idx * m2d_stride], vmy = v_means2d[idx * m2d_stride + 1];
+            const float vmx = row[0], vmy = row[1];
             vpc[0] = fx * rz * vmx;
             vpc[1] = fy * rz * vmy;
             vpc[2] = -(fx * x * vmx + fy * y * vmy) * rz2 + vdepth;
