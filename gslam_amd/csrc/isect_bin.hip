@@ -728,6 +728,10 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
                                                                        int32_t *__restrict__ flatten_ids) {
     // 36 KiB: [a | b | 1024 cursors] in the LDS regime, [window | 4096 cursors] in the streaming one
     __shared__ __attribute__((aligned(16))) unsigned long long s_keys[2 * CNT_MAXN + CNT_NB / 2];
+    // Ranked keys are parked here and leave as coalesced runs: storing every key straight to its final position is a
+    // 4-byte write to a random slot of the window, and each such write travelled to memory as its own 32-byte request
+    // (WRITE_SIZE 2.6 GB for 0.9 GB of output at 5M Gaussians / 1080p).  The LDS regime reuses `a` for this.
+    __shared__ __attribute__((aligned(16))) unsigned long long s_out[CNT_MAXN];
     __shared__ unsigned int s_red[2 * (SORT_THREADS / 64)];
     __shared__ int s_wtot[SORT_THREADS / 64];
     const int tile = blockIdx.x;
@@ -804,15 +808,17 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
             s_b[atomicAdd(&s_cur[bucket_of(k)], 1)] = k;
         }
         __syncthreads();
-        // 3. exact position inside the bucket, and out
+        // 3. exact position inside the bucket (into `a`, no longer needed), and out in order
         for (int i = t; i < n; i += SORT_THREADS) {
             const unsigned long long k = s_b[i];
             const int b = bucket_of(k);
             const int bs = bucket_start(b), be = s_cur[b];
             int rank = 0;
             for (int j = bs; j < be; ++j) rank += (s_b[j] < k) ? 1 : 0;
-            emit(start + bs + rank, k);
+            s_a[bs + rank] = k;
         }
+        __syncthreads();
+        for (int i = t; i < n; i += SORT_THREADS) emit(start + i, s_a[i]);
         return;
     }
     for (int i = t; i < n; i += SORT_THREADS) {
@@ -840,9 +846,10 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
             const int bs = bucket_start(b) - ws, be = s_cur[b] - ws;
             int rank = 0;
             for (int j = bs; j < be; ++j) rank += (s_win[j] < k) ? 1 : 0;
-            emit(start + ws + bs + rank, k);
+            s_out[bs + rank] = k;
         }
         __syncthreads();
+        for (int i = t; i < len; i += SORT_THREADS) emit(start + ws + i, s_out[i]);
         b0 = b1;
     }
 }

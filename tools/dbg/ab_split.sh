@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+for v in 0 1 2 4; do
+  GSX_PLACE_SPLIT=$v timeout -k 10 300 python tools/ab_raster.py 100000 500000 2000000 C=8 2>&1 | grep -E "^N=|isect_bin_sort" | sed -e 's/ 640x480.*//' -e 's/.*sync-free): //' | paste -sd' ' | sed "s/^/split=$v: /"
+done
