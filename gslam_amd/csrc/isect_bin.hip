@@ -766,6 +766,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
             dmin = min(dmin, d); dmax = max(dmax, d);
         }
     } else {
+#pragma unroll 4
         for (int i = t; i < n; i += 4 * SORT_THREADS) {
             const unsigned int d = (unsigned int)(seg[i] >> 32);
             dmin = min(dmin, d); dmax = max(dmax, d);
@@ -792,7 +793,18 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
     };
     // 2. histogram, scan
     if (small) for (int i = t; i < n; i += SORT_THREADS) atomicAdd(&s_cur[bucket_of(s_a[i])], 1);
-    else for (int i = t; i < n; i += SORT_THREADS) atomicAdd(&s_cur[bucket_of(seg[i])], 1);
+    else {
+        // four keys in flight per thread: with one dependent load per trip this pass ran at the latency of L2, not at
+        // its bandwidth (the tile sort spent 74 % of its wave cycles waiting, SQ_WAIT_ANY)
+        int i = t;
+        for (; i + 3 * SORT_THREADS < n; i += 4 * SORT_THREADS) {
+            const unsigned long long k0 = seg[i], k1 = seg[i + SORT_THREADS], k2 = seg[i + 2 * SORT_THREADS],
+                                     k3 = seg[i + 3 * SORT_THREADS];
+            atomicAdd(&s_cur[bucket_of(k0)], 1); atomicAdd(&s_cur[bucket_of(k1)], 1);
+            atomicAdd(&s_cur[bucket_of(k2)], 1); atomicAdd(&s_cur[bucket_of(k3)], 1);
+        }
+        for (; i < n; i += SORT_THREADS) atomicAdd(&s_cur[bucket_of(seg[i])], 1);
+    }
     __syncthreads();
     const bool degenerate = small ? bucket_scan<CNT_NB>(s_cur, s_wtot, CNT_MAX_BUCKET)
                                   : bucket_scan<BIG_NB>(s_cur, s_wtot, BIG_MAX_BUCKET);
@@ -821,9 +833,19 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
         for (int i = t; i < n; i += SORT_THREADS) emit(start + i, s_a[i]);
         return;
     }
-    for (int i = t; i < n; i += SORT_THREADS) {
-        const unsigned long long k = seg[i];
-        grp[atomicAdd(&s_cur[bucket_of(k)], 1)] = k;
+    {
+        int i = t;
+        for (; i + 3 * SORT_THREADS < n; i += 4 * SORT_THREADS) {
+            const unsigned long long k0 = seg[i], k1 = seg[i + SORT_THREADS], k2 = seg[i + 2 * SORT_THREADS],
+                                     k3 = seg[i + 3 * SORT_THREADS];
+            const int p0 = atomicAdd(&s_cur[bucket_of(k0)], 1), p1 = atomicAdd(&s_cur[bucket_of(k1)], 1);
+            const int p2 = atomicAdd(&s_cur[bucket_of(k2)], 1), p3 = atomicAdd(&s_cur[bucket_of(k3)], 1);
+            grp[p0] = k0; grp[p1] = k1; grp[p2] = k2; grp[p3] = k3;
+        }
+        for (; i < n; i += SORT_THREADS) {
+            const unsigned long long k = seg[i];
+            grp[atomicAdd(&s_cur[bucket_of(k)], 1)] = k;
+        }
     }
     __syncthreads();                                         // the grouped keys are read back by other lanes below
     unsigned long long *s_win = s_keys;
@@ -838,7 +860,19 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
         }
         const int b1 = lo;
         const int len = s_cur[b1 - 1] - ws;
-        for (int i = t; i < len; i += SORT_THREADS) s_win[i] = grp[ws + i];
+        {                                                    // <= 4 keys per thread, all loads in flight together
+            unsigned long long kk[CNT_MAXN / SORT_THREADS];
+#pragma unroll
+            for (int q = 0; q < CNT_MAXN / SORT_THREADS; ++q) {
+                const int i = t + q * SORT_THREADS;
+                kk[q] = (i < len) ? grp[ws + i] : 0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < CNT_MAXN / SORT_THREADS; ++q) {
+                const int i = t + q * SORT_THREADS;
+                if (i < len) s_win[i] = kk[q];
+            }
+        }
         __syncthreads();
         for (int i = t; i < len; i += SORT_THREADS) {
             const unsigned long long k = s_win[i];

@@ -1,5 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-timeout -k 10 300 python tools/bench_configs.py
-timeout -k 10 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline | cut -c1-200
+timeout -k 10 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_parity.py tests/test_gpu_ba_step.py -x -q -k "isect or hot_tile or tile_lists or binning or sync_free" 2>&1 | tail -3
+bash tools/dbg/ab_pad.sh
+timeout -k 10 300 python tools/bench_configs.py 2>&1 | tail -3
