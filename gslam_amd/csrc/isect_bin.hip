@@ -437,18 +437,23 @@ __device__ __forceinline__ Rect unpack_rec(const uint4 &v, int n_tiles, int &bas
 // atomic per (record, tile) piles up on a handful of addresses (384 us at 5M / 1080p).  Here every rectangle adds +-1 at
 // its four corners of a per-camera (tile_h + 1) x (tile_w + 1) difference grid in LDS - 4 atomics per record instead of
 // ~15 - and the grid is integrated once per workgroup (rows, then columns).
-__global__ __launch_bounds__(BIN_THREADS) void fine_count_kernel(const PreRec *__restrict__ recs,
+constexpr int FINE_THREADS = 512;     // the tile-level passes of the pre-sorted path: few, fat workgroups (<= GB_MAX)
+
+__global__ __launch_bounds__(FINE_THREADS) void fine_count_kernel(const PreRec *__restrict__ recs,
                                                                  const int64_t *__restrict__ n_inst, int chunk,
                                                                  int tile_w, int tile_h, int C,
                                                                  int32_t *__restrict__ cnt /*[gblocks][C * tiles]*/) {
     extern __shared__ int s_grid[];  // [C][tile_h + 1][tile_w + 1]
     const int gw = tile_w + 1, gh = tile_h + 1, G = gw * gh;
     const int n_tiles = tile_w * tile_h;
-    for (int i = threadIdx.x; i < C * G; i += BIN_THREADS) s_grid[i] = 0;
+    for (int i = threadIdx.x; i < C * G; i += FINE_THREADS) s_grid[i] = 0;
     __syncthreads();
     const int64_t n = n_inst[0];
-    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += BIN_THREADS) {
+    // equal shares of the records that exist (n is only known on the device; the grid is sized for the capacity C x N,
+    // and with fixed-size chunks the workgroups beyond the visible instances - a third of them - had nothing to do)
+    const int64_t lo = n * blockIdx.x / gridDim.x, hi = n * (blockIdx.x + 1) / gridDim.x;
+    (void)chunk;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += FINE_THREADS) {
         int base = 0;
         const Rect r = unpack_rec(reinterpret_cast<const uint4 *>(recs)[i], n_tiles, base);
         int *g = s_grid + (base / n_tiles) * G;
@@ -458,27 +463,27 @@ __global__ __launch_bounds__(BIN_THREADS) void fine_count_kernel(const PreRec *_
         atomicAdd(&g[r.y1 * gw + r.x1], 1);
     }
     __syncthreads();
-    for (int row = threadIdx.x; row < C * gh; row += BIN_THREADS) {          // prefix along x
+    for (int row = threadIdx.x; row < C * gh; row += FINE_THREADS) {          // prefix along x
         int *p = s_grid + (row / gh) * G + (row % gh) * gw;
         int run = 0;
         for (int x = 0; x < gw; ++x) { run += p[x]; p[x] = run; }
     }
     __syncthreads();
-    for (int col = threadIdx.x; col < C * gw; col += BIN_THREADS) {          // prefix along y
+    for (int col = threadIdx.x; col < C * gw; col += FINE_THREADS) {          // prefix along y
         int *p = s_grid + (col / gw) * G + (col % gw);
         int run = 0;
         for (int y = 0; y < gh; ++y) { run += p[y * gw]; p[y * gw] = run; }
     }
     __syncthreads();
     int32_t *row_out = cnt + (int64_t)blockIdx.x * C * n_tiles;
-    for (int i = threadIdx.x; i < C * n_tiles; i += BIN_THREADS) {
+    for (int i = threadIdx.x; i < C * n_tiles; i += FINE_THREADS) {
         const int c = i / n_tiles, tl = i - c * n_tiles;
         const int y = tl / tile_w, x = tl - y * tile_w;
         row_out[i] = s_grid[c * G + y * gw + x];
     }
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void fine_place_kernel(const PreRec *__restrict__ recs,
+__global__ __launch_bounds__(FINE_THREADS) void fine_place_kernel(const PreRec *__restrict__ recs,
                                                                  const int64_t *__restrict__ n_inst, int chunk,
                                                                  int tile_w, int n_tiles, int T, int64_t M_cap,
                                                                  const int32_t *__restrict__ offsets,
@@ -486,11 +491,14 @@ __global__ __launch_bounds__(BIN_THREADS) void fine_place_kernel(const PreRec *_
                                                                  unsigned long long *__restrict__ entries) {
     extern __shared__ int s_cur[];  // [T]
     const int32_t *row = cnt + (int64_t)blockIdx.x * T;
-    for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cur[i] = offsets[i] + row[i];
+    for (int i = threadIdx.x; i < T; i += FINE_THREADS) s_cur[i] = offsets[i] + row[i];
     __syncthreads();
     const int64_t n = n_inst[0];
-    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (int64_t i0 = lo; i0 < hi; i0 += BIN_THREADS) {
+    // equal shares of the records that exist (n is only known on the device; the grid is sized for the capacity C x N,
+    // and with fixed-size chunks the workgroups beyond the visible instances - a third of them - had nothing to do)
+    const int64_t lo = n * blockIdx.x / gridDim.x, hi = n * (blockIdx.x + 1) / gridDim.x;
+    (void)chunk;
+    for (int64_t i0 = lo; i0 < hi; i0 += FINE_THREADS) {
         const int64_t i = i0 + threadIdx.x;
         Rect r = {0, 0, 0, 0};
         int base = 0;
@@ -1008,7 +1016,7 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
             const int64_t inst_cap = rec_cap;
             while ((inst_cap + chunk - 1) / chunk > GB_MAX) chunk *= 2;
             const unsigned gb2 = (unsigned)((inst_cap + chunk - 1) / chunk);
-            hipLaunchKernelGGL(fine_count_kernel, dim3(gb2), dim3(BIN_THREADS), (size_t)(C * G * 4), st, recs, n_inst,
+            hipLaunchKernelGGL(fine_count_kernel, dim3(gb2), dim3(FINE_THREADS), (size_t)(C * G * 4), st, recs, n_inst,
                                (int)chunk, tile_w, tile_h, (int)C, cnt);
             GSX_CHECK_LAUNCH();
             hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((T + 63) / 64), 1u), dim3(64 * CS_GROUPS), 0, st, cnt,
@@ -1017,7 +1025,7 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
             hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, (int)T, M_cap, offsets, M_dev, status, tile_order);
             GSX_CHECK_LAUNCH();
             if (M_cap > 0) {
-                hipLaunchKernelGGL(fine_place_kernel, dim3(gb2), dim3(BIN_THREADS), (size_t)(T * 4), st, recs, n_inst,
+                hipLaunchKernelGGL(fine_place_kernel, dim3(gb2), dim3(FINE_THREADS), (size_t)(T * 4), st, recs, n_inst,
                                    (int)chunk, tile_w, (int)n_tiles, (int)T, M_cap, offsets, cnt, entries);
                 GSX_CHECK_LAUNCH();
             }
