@@ -988,12 +988,10 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
         const bool presort_ok = N > 0 && M_cap > 0 && workspace_bytes >= L.total + rec_cap * 16 && T <= 16000 &&
                                 C * G * 4 <= 65536 && C <= 255 && tile_w < 4096 && tile_h < 4096 &&
                                 S * (int64_t)sizeof(int) <= 65536;
-        // measured (MI355X): 5M Gaussians at 1920x1080 (8160 tiles per camera): count + placement 1.70 -> 1.14 ms;
-        // 2M x 8 cameras at 640x480 (1200 tiles per camera): 1.08 -> 1.23 ms - with few tiles per camera the direct
-        // placement already writes long enough runs (after the counting pass moved to a difference grid the pre-sort
-        // wins from ~8M instances on: 2M x 8: tile lists 1.83 -> 1.71 ms; 500 k x 8 still loses, 318 -> 357 us)
-        const bool presort = presort_ok && (ps ? ps[0] == '1' : ((C * N >= ((int64_t)1 << 21) && n_tiles >= 4096) ||
-                                                                  C * N >= ((int64_t)1 << 23)));
+        // measured (MI355X, tools/dbg/ab_presort.sh, whole tile-list build): 100 k x 8 cameras 138 vs 145 us (direct vs
+        // pre-sorted), 250 k x 8: 209 vs 178, 1M x 1: 143 vs 121, 500 k x 8: 330 vs 262, 2M x 8: 1774 vs 1123, 5M at
+        // 1080p: count + placement 1.70 ms vs 0.6 - the pre-sort pays from about a million instances on
+        const bool presort = presort_ok && (ps ? ps[0] == '1' : C * N >= ((int64_t)1 << 20));
         if (presort) {
             const unsigned gblocks = (unsigned)((N + BIN_THREADS * items - 1) / (BIN_THREADS * items));
             int32_t *coff = cursor;                          // [C * S + 1] (S <= tiles per camera)
