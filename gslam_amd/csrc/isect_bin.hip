@@ -185,6 +185,35 @@ __device__ __forceinline__ void walk_rects(const Rect &r, int tile_w, unsigned i
     }
 }
 
+// walk_rects for the placement passes: appends the lane's key to every tile of its rectangle through the LDS cursors.
+// Small rectangles take two tiles per trip - both returning LDS adds are issued before the first result is waited
+// for - because the chain add -> wait -> store -> next tile ran at the LDS round-trip latency per tile.
+__device__ __forceinline__ void place_rects(const Rect &r, int tile_w, unsigned int lo, unsigned int hi, int *s_cur,
+                                            int64_t M_cap, unsigned long long *__restrict__ entries, int base = 0) {
+    const int w = r.x1 - r.x0, h = r.y1 - r.y0;
+    const int area = (w > 0 && h > 0) ? w * h : 0;
+    const unsigned long long key = ((unsigned long long)hi << 32) | lo;
+    if (area > 0 && area <= COOP_AREA) {
+        int x = r.x0, y = r.y0;
+        for (int k = 0; k < area; k += 2) {
+            const int t0 = base + y * tile_w + x;
+            if (++x == r.x1) { x = r.x0; ++y; }
+            const bool two = k + 1 < area;
+            const int t1 = base + y * tile_w + x;
+            if (++x == r.x1) { x = r.x0; ++y; }
+            const int p0 = atomicAdd(&s_cur[t0], 1);
+            const int p1 = two ? atomicAdd(&s_cur[t1], 1) : -1;
+            if ((uint64_t)(uint32_t)p0 < (uint64_t)M_cap) entries[p0] = key;
+            if (two && (uint64_t)(uint32_t)p1 < (uint64_t)M_cap) entries[p1] = key;
+        }
+    }
+    const Rect none = {0, 0, 0, 0};
+    walk_rects(area > COOP_AREA ? r : none, tile_w, lo, hi, [&](int tile, unsigned int l, unsigned int hh) {
+        const int pos = atomicAdd(&s_cur[tile], 1);
+        if ((uint64_t)(uint32_t)pos < (uint64_t)M_cap) entries[pos] = ((unsigned long long)hh << 32) | l;
+    }, base);
+}
+
 // ---- 3b. binning without global atomics --------------------------------------------------------------------------
 // emit_binned_kernel reserves a range per (workgroup, touched tile) with a global atomic; a workgroup of 1024 random
 // Gaussians touches most tiles with ~3 entries each, so that is one contended atomic per ~3 entries (3.5 M atomics on
@@ -350,10 +379,7 @@ __global__ __launch_bounds__(BIN_THREADS) void place_kernel(const float *__restr
         const Rect r = load_rect(means2d, radii, idx, tile_w, tile_h, g < N);
         const bool has = (r.x1 > r.x0) && (r.y1 > r.y0);
         const unsigned int klo = (unsigned int)idx, khi = has ? __float_as_uint(depths[idx]) : 0u;
-        walk_rects(r, tile_w, klo, khi, [&](int tile, unsigned int lo, unsigned int hi) {
-            const int pos = atomicAdd(&s_cur[tile], 1);
-            if ((uint64_t)(uint32_t)pos < (uint64_t)M_cap) entries[pos] = ((unsigned long long)hi << 32) | lo;
-        });
+        place_rects(r, tile_w, klo, khi, s_cur, M_cap, entries);
     }
 }
 
@@ -498,20 +524,20 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_place_kernel(const PreRec *
     // and with fixed-size chunks the workgroups beyond the visible instances - a third of them - had nothing to do)
     const int64_t lo = n * blockIdx.x / gridDim.x, hi = n * (blockIdx.x + 1) / gridDim.x;
     (void)chunk;
+    uint4 v_nxt = make_uint4(0u, 0u, 0u, 0u);               // the record of the next trip is in flight during this one
+    if (lo + threadIdx.x < hi) v_nxt = reinterpret_cast<const uint4 *>(recs)[lo + threadIdx.x];
     for (int64_t i0 = lo; i0 < hi; i0 += FINE_THREADS) {
         const int64_t i = i0 + threadIdx.x;
+        const uint4 v = v_nxt;
+        if (i + FINE_THREADS < hi) v_nxt = reinterpret_cast<const uint4 *>(recs)[i + FINE_THREADS];
         Rect r = {0, 0, 0, 0};
         int base = 0;
         unsigned int klo = 0u, khi = 0u;
         if (i < hi) {
-            const uint4 v = reinterpret_cast<const uint4 *>(recs)[i];
             r = unpack_rec(v, n_tiles, base);
             klo = v.w; khi = v.z;
         }
-        walk_rects(r, tile_w, klo, khi, [&](int tile, unsigned int l, unsigned int h) {
-            const int pos = atomicAdd(&s_cur[tile], 1);
-            if ((uint64_t)(uint32_t)pos < (uint64_t)M_cap) entries[pos] = ((unsigned long long)h << 32) | l;
-        }, base);
+        place_rects(r, tile_w, klo, khi, s_cur, M_cap, entries, base);
     }
 }
 
@@ -767,11 +793,20 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
     // two end buckets can suffer, and the degenerate-bucket check covers that).
     unsigned int dmin = 0xffffffffu, dmax = 0u;
     if (small) {
-        for (int i = t; i < n; i += SORT_THREADS) {
-            const unsigned long long k = seg[i];
-            s_a[i] = k;
-            const unsigned int d = (unsigned int)(k >> 32);
-            dmin = min(dmin, d); dmax = max(dmax, d);
+        unsigned long long kk[CNT_MAXN / SORT_THREADS];      // <= 4 keys per thread, all loads in flight together
+#pragma unroll
+        for (int q = 0; q < CNT_MAXN / SORT_THREADS; ++q) {
+            const int i = t + q * SORT_THREADS;
+            kk[q] = (i < n) ? seg[i] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < CNT_MAXN / SORT_THREADS; ++q) {
+            const int i = t + q * SORT_THREADS;
+            if (i < n) {
+                s_a[i] = kk[q];
+                const unsigned int d = (unsigned int)(kk[q] >> 32);
+                dmin = min(dmin, d); dmax = max(dmax, d);
+            }
         }
     } else {
 #pragma unroll 4
