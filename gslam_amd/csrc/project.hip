@@ -573,6 +573,8 @@ extern "C" int gsx_project_fwd(const float *means, const float *quats, const flo
     return GSX_OK;
 }
 
+extern "C" int64_t gsx_project_bwd_blocks(int64_t N) { return (N + PBWD_THREADS - 1) / PBWD_THREADS; }
+
 extern "C" int64_t gsx_project_bwd_workspace_bytes(int64_t N, int64_t C) {
     const int64_t blocks = (N + PBWD_THREADS - 1) / PBWD_THREADS;
     return gsx_align256(blocks * C * 12 * (int64_t)sizeof(float)) + 256;
@@ -590,7 +592,8 @@ extern "C" int gsx_project_bwd(const float *means, const float *quats, const flo
     GSX_CHECK_ARG(N >= 0 && C >= 1 && W > 0 && H > 0);
     GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && radii && v_means2d && v_conics);
     const bool pose_only = !v_means && !v_quats && !v_scales;     // Gaussian gradients not wanted (tracking)
-    GSX_CHECK_ARG(pose_only ? (v_viewmats != nullptr) : (v_means && v_quats && v_scales));
+    const bool partials_only = (flags & GSX_PROJ_VIEW_PARTIALS) != 0;   // leave the pose partials for a fused consumer
+    GSX_CHECK_ARG(pose_only ? (v_viewmats != nullptr || partials_only) : (v_means && v_quats && v_scales));
     GSX_CHECK_ARG(v_means2d_stride >= 2 && v_conics_stride >= 3);
     if (v_rec && !pose_only) GSX_CHECK_ARG(logit_opacities && logit_colors && v_logit_opacities && v_logit_colors);
     if (v_rec && !pose_only && (flags & GSX_PROJ_BETAS)) GSX_CHECK_ARG(log_uncertainties && v_log_unc);
@@ -601,7 +604,7 @@ extern "C" int gsx_project_bwd(const float *means, const float *quats, const flo
     }
     const unsigned blocks = (unsigned)((N + PBWD_THREADS - 1) / PBWD_THREADS);
     float *partials = nullptr;
-    if (v_viewmats) {
+    if (v_viewmats || partials_only) {
         if (workspace_bytes < gsx_project_bwd_workspace_bytes(N, C) || !workspace) {
             gsx_set_error("gsx_project_bwd: workspace too small");
             return GSX_E_WORKSPACE;
@@ -618,7 +621,7 @@ extern "C" int gsx_project_bwd(const float *means, const float *quats, const flo
         hipLaunchKernelGGL(project_bwd_kernel<false>, dim3(blocks), dim3(PBWD_THREADS), 0, st, GSX_PBWD_ARGS);
 #undef GSX_PBWD_ARGS
     GSX_CHECK_LAUNCH();
-    if (v_viewmats) {
+    if (v_viewmats && !partials_only) {
         hipLaunchKernelGGL(project_bwd_finish_kernel, dim3((unsigned)C), dim3(256), 0, st, partials, (int)blocks,
                            (int)C, v_viewmats);
         GSX_CHECK_LAUNCH();

@@ -2,6 +2,7 @@
 // closure evaluation replaces the host-side torch.optim.Adam / torch.optim.LBFGS logic of
 // gslam/frontend.py:604-662 and its per-closure `loss.item()` (frontend.py:648).
 #include "gsx_common.h"
+#include "pose_math.h"
 #include "track_opt.h"
 
 #define TO_ENTRY(name) gsx_track_opt_##name

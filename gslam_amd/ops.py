@@ -69,6 +69,9 @@ class _Projection(torch.autograd.Function):
         accumulates its gradient records into it (pass the same tensor to _RasterizeRecords), which saves the separate
         zero-fill launch in front of every backward."""
         means, quats, scales = _f32c(means, "means"), _f32c(quats, "quats"), _f32c(scales, "scales")
+        # a caller that consumes the pose gradient itself (tracking.GraphedTracker's fused closure tail) marks its view
+        # matrices: the backward then leaves the per-workgroup partials in the "proj_bwd" workspace and returns no grad
+        ctx.view_partials = bool(getattr(viewmats, "_gsx_partials_only", False))
         viewmats, Ks = _f32c(viewmats, "viewmats"), _f32c(Ks, "Ks")
         N, Cn = means.shape[0], viewmats.shape[0]
         dev = means.device
@@ -130,12 +133,15 @@ class _Projection(torch.autograd.Function):
         if v_rec is not None:
             v_rec = v_rec.contiguous()
         need_view = ctx.needs_input_grad[3]
+        partials_only = need_view and ctx.view_partials
+        if partials_only:
+            flags |= 8                                          # GSX_PROJ_VIEW_PARTIALS
         # tracking (frozen map): only the pose gradient is wanted; the kernel then skips the per-Gaussian chain and stores
         need_gauss = any(ctx.needs_input_grad[i] for i in (0, 1, 2, 5, 6, 7)) or not need_view
         v_means = torch.empty_like(means) if need_gauss else None
         v_quats = torch.empty_like(quats) if need_gauss else None
         v_scales = torch.empty_like(scales) if need_gauss else None
-        v_view = torch.empty(Cn, 4, 4, dtype=torch.float32, device=dev) if need_view else None
+        v_view = torch.empty(Cn, 4, 4, dtype=torch.float32, device=dev) if (need_view and not partials_only) else None
         v_lo = v_lc = v_lu = None
         if want_rec and need_gauss:
             v_lo = torch.empty_like(logit_opac)

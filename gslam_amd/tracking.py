@@ -6,6 +6,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import torch
 
 from .map import GaussianSplattingData
@@ -145,12 +147,18 @@ class GraphedTracker:
         self.device_optimizer = device_optimizer
         self.max_eval = max_eval
         self._state = self._report = None
+        self.fused_tail = bool(device_optimizer) and os.environ.get("GSX_TRACK_TAIL", "fused") != "split"
         if device_optimizer:
             from ._lib import lib
             self._state = torch.zeros(int(lib.gsx_track_opt_state_bytes()), dtype=torch.uint8, device=dev)
             self._report = torch.zeros(8, dtype=torch.float32, device=dev)
+            # the view matrix the fused closure renders with: written by the closure's own tail for the next evaluation
+            self._viewmat = torch.zeros(1, 4, 4, device=dev, requires_grad=True)
+            self._viewmat._gsx_partials_only = True
 
     def _closure_body(self, advance: bool = False):
+        if advance and self.fused_tail:
+            return self._closure_fused()
         for p in self.params:
             p.grad = None               # AccumulateGrad then adopts the fresh gradient tensor (no accumulate kernel)
         # the reference renders the depth channel in its tracking closure too (frontend.py:627-631) but only reads it
@@ -172,6 +180,25 @@ class GraphedTracker:
                 stream_ptr(loss.device)), "gsx_track_opt_advance")
         return loss
 
+    def _closure_fused(self):
+        """the captured closure of the device optimiser: renders with the persistent view matrix, and ONE launch takes
+        the projection backward's pose partials through the PoseZhou backward, the optimiser step and the PoseZhou
+        forward of the new parameters (csrc/track_opt_impl.inc: track_opt_tail_kernel) - no autograd node and no
+        launch of its own for the pose on either side of the render"""
+        from ._lib import check, lib, stream_ptr
+        from .ops import workspace
+        out = self.splats._render([self.camera], self._viewmat, 'RGB', 0.5, need_n_touched=False)
+        out2, v_render, v_exposure = self._loss_fn(out, self.img, self.exposure)
+        torch.autograd.backward([out._render], [v_render])      # ends with the pose partials in the workspace
+        loss = out2[0:1]
+        N = int(self.splats.means.shape[0])
+        ws = workspace(lib.gsx_project_bwd_workspace_bytes(N, 1), loss.device, "proj_bwd")
+        check(lib.gsx_track_opt_tail(self._state.data_ptr(), ws.data_ptr(), int(lib.gsx_project_bwd_blocks(N)),
+                                     self.pose.Rt.data_ptr(), self.pose.dt.data_ptr(), self.pose.dR.data_ptr(),
+                                     self.exposure.data_ptr(), v_exposure.data_ptr(), loss.data_ptr(),
+                                     self._viewmat.data_ptr(), stream_ptr(loss.device)), "gsx_track_opt_tail")
+        return loss
+
     def load(self, frame: Frame, prev_exposure: Optional[torch.Tensor] = None):
         with torch.no_grad():
             self.pose.Rt.copy_(frame.pose())
@@ -179,6 +206,8 @@ class GraphedTracker:
             self.pose.dt.zero_()
             self.img.copy_(frame.img)
             self.exposure.copy_(frame.exposure_params if prev_exposure is None else prev_exposure)
+            if self.device_optimizer:
+                self._viewmat.copy_(self.pose.Rt[None])               # dR = dt = 0: the first evaluation's view matrix
 
     def capture(self):
         from ._sync import capture_lock

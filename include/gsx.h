@@ -45,6 +45,9 @@ extern "C" {
 /* projection flags */
 #define GSX_PROJ_LOG_SCALES 1     /* `scales` holds log-scales; exp() is fused (gslam/rasterization.py:147) */
 #define GSX_PROJ_RENDER_DEPTH 2   /* gslam record: append camera depth channel (rasterization.py:234-240)   */
+#define GSX_PROJ_VIEW_PARTIALS 8  /* gsx_project_bwd only: leave the per-workgroup pose-gradient partials
+                                     ([gsx_project_bwd_blocks(N)][C][12] floats at the start of the workspace) for a fused
+                                     consumer (gsx_track_opt_tail) and skip the finishing launch; v_viewmats is ignored */
 #define GSX_PROJ_BETAS 4          /* gslam record: append beta=clamp(exp(log_unc),0.01) (rasterization.py:149,249-256) */
 
 int gsx_version(void);
@@ -81,6 +84,7 @@ int gsx_project_fwd(const float *means, const float *quats, const float *scales,
  * workspace: gsx_project_bwd_workspace_bytes(N, C).
  */
 int64_t gsx_project_bwd_workspace_bytes(int64_t N, int64_t C);
+int64_t gsx_project_bwd_blocks(int64_t N);
 int gsx_project_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
                     const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
                     float far_plane, int flags, const int32_t *radii, const float *v_means2d,
@@ -268,6 +272,12 @@ int gsx_track_opt_init(void *state, int n_params, int n_adam, float lr_adam, dou
 int gsx_track_opt_advance(void *state, int n_tensors, float *const *params, const float *const *grads,
                           const int *numels, const float *loss, void *stream);
 int gsx_track_opt_report(const void *state, float *out8, void *stream);
+/* The tail of the tracker's closure in one launch (one camera): reduces the pose-gradient partials that
+ * gsx_project_bwd(flags | GSX_PROJ_VIEW_PARTIALS) left in its workspace, runs the PoseZhou backward (gslam/primitives.py:
+ * 82-92), advances the state machine on the 11 parameters (dt[3], dR[6], exposure[2], in this order; v_exposure from the
+ * loss block), writes them back and writes the PoseZhou forward of the new parameters to viewmat [4,4]. */
+int gsx_track_opt_tail(void *state, const void *pose_partials, int64_t n_blocks, const float *Rt, float *dt, float *dR,
+                       float *exposure, const float *v_exposure, const float *loss, float *viewmat, void *stream);
 /* The same state machine sized for the backend's window pose refinement (gslam/backend.py:447-506): up to 80 parameters
  * in up to 16 tensors, L-BFGS history up to 10; n_adam = 0 skips the Adam phase.  Arguments as above. */
 int64_t gsx_window_opt_state_bytes(void);
@@ -276,6 +286,8 @@ int gsx_window_opt_init(void *state, int n_params, int n_adam, float lr_adam, do
 int gsx_window_opt_advance(void *state, int n_tensors, float *const *params, const float *const *grads,
                            const int *numels, const float *loss, void *stream);
 int gsx_window_opt_report(const void *state, float *out8, void *stream);
+int gsx_window_opt_tail(void *state, const void *pose_partials, int64_t n_blocks, const float *Rt, float *dt, float *dR,
+                        float *exposure, const float *v_exposure, const float *loss, float *viewmat, void *stream);
 
 /* ---- map maintenance: every per-Gaussian array re-packed in ONE launch.
  * gsx_gather_rows: dst[k][r] = src[k][index[r]] for r < n_out, k < n_tensors (<= 32); the masked re-allocation of

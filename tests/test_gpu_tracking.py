@@ -189,3 +189,28 @@ def test_device_pose_refiner_matches_host_lbfgs(dev):
     last2, _ = ref.run()
     assert ref.graph is g and last2 <= last_d * 1.001
     assert all(not p.requires_grad for p in m.parameters())
+
+
+def test_fused_closure_tail_equals_split_launches(dev, monkeypatch):
+    """the tracker's one-launch closure tail (pose partials -> PoseZhou backward -> optimiser step -> PoseZhou forward)
+    against the separate finish / pose_bwd / advance / pose_fwd launches: same tracked poses (the float atomics of the
+    rasteriser backward already make two runs of ONE variant differ in the last bits, and with them the line search's
+    branch near the optimum, so evaluation counts and poses are compared with that slack)"""
+    from gslam_amd.tracking import GraphedTracker
+    m, cam, frame = _setup(dev)
+    res = {}
+    for mode in ("split", "fused"):
+        monkeypatch.setenv("GSX_TRACK_TAIL", mode)
+        tr = GraphedTracker(m, cam, device_optimizer=True)
+        assert tr.fused_tail == (mode == "fused")
+        out = []
+        for i in (1, 2):
+            f = frame(i, i - 1)
+            loss, n = tr.track(f)
+            torch.cuda.synchronize()
+            out.append((f.pose().detach().clone(), f.exposure_params.detach().clone(), loss, n))
+        res[mode] = out
+    for (pa, ea, la, na), (pb, eb, lb, nb) in zip(res["split"], res["fused"]):
+        assert abs(na - nb) <= 3 and 11 <= nb <= 37
+        assert (pa - pb).abs().max() < 2e-3 and (ea - eb).abs().max() < 2e-2
+        assert max(la, lb) <= 1.5 * min(la, lb) + 1e-4
