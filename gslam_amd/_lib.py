@@ -72,13 +72,13 @@ PROTOTYPES = {
     "gsx_track_opt_init": (i32, [vp, i32, i32, f32, C.c_double, i32, i32, i32, C.c_double, C.c_double, vp]),
     "gsx_track_opt_advance": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, vp]),
     "gsx_track_opt_report": (i32, [vp, vp, vp]),
-    "gsx_track_opt_tail": (i32, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gsx_track_opt_tail": (i32, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp]),
     "gsx_project_bwd_blocks": (i64, [i64]),
     "gsx_window_opt_state_bytes": (i64, []),
     "gsx_window_opt_init": (i32, [vp, i32, i32, f32, C.c_double, i32, i32, i32, C.c_double, C.c_double, vp]),
     "gsx_window_opt_advance": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, vp]),
     "gsx_window_opt_report": (i32, [vp, vp, vp]),
-    "gsx_window_opt_tail": (i32, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gsx_window_opt_tail": (i32, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp]),
     "gsx_gather_rows": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, i64, i64, vp]),
     "gsx_concat_rows": (i32, [i32, C.POINTER(vp), i64, C.POINTER(vp), i64, C.POINTER(vp), C.POINTER(i32), vp]),
     "gsx_selftest": (i32, [vp, i64, vp]),

@@ -20,7 +20,7 @@ from .ssim import _strides
 
 
 def loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo, w_ssim, w_iso,
-                   w_tv, mode, backward_fn=None, iso_grad_fn=None):
+                   w_tv, mode, backward_fn=None, iso_grad_fn=None, finish=True):
     """Raw fused block (no autograd): returns (out2, v_render, v_exposure, v_log_scales) where out2[0] = total =
     w_photo * photometric + w_ssim * (1 - ssim) + w_iso * isotropic + w_tv * tv and out2[1] = photometric, all on the
     device; the v_* are d total / d input.
@@ -34,11 +34,13 @@ def loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_in
         if log_scales is not None:
             log_scales = log_scales.detach()
         return _loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo,
-                               w_ssim, w_iso, w_tv, mode, backward_fn, iso_grad_fn)
+                               w_ssim, w_iso, w_tv, mode, backward_fn, iso_grad_fn, finish)
 
 
 def _loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_index, beta_index, w_photo, w_ssim, w_iso,
-                    w_tv, mode, backward_fn=None, iso_grad_fn=None):
+                    w_tv, mode, backward_fn=None, iso_grad_fn=None, finish=True):
+    """finish=False (photometric term only): the finishing launch is left to the caller - returns
+    ((map_loss workspace, number of partial rows, loss coefficient), v_render, None, None)"""
     exposure = exposure.contiguous()
     Cn, H, W, CH = render.shape
     dev = render.device
@@ -87,9 +89,14 @@ def _loss_and_grads(render, alphas, gt, exposure, log_scales, vis_count, depth_i
             v_scales = torch.empty_like(log_scales)
             check(lib.gsx_isotropic_loss(ptr(log_scales), ptr(vis_count.contiguous()), n_iso, w_iso, None,
                                          ptr(v_scales), ptr(iso_ws), iso_ws.numel(), st), "gsx_isotropic_loss")
+    pm = 1.0 / denom
+    if not finish:
+        if n_ssim or iso_ws is not None or w_tv != 0.0:
+            raise ValueError("finish=False supports the photometric term alone")
+        rows = Cn * ((H * W + 255) // 256)
+        return (map_ws, rows, w_photo * pm), v_render, None, None
     # total / photometric from the raw sums (photometric, log-beta, tv, ssim, isotropic), on the device
     out2 = torch.empty(2, dtype=torch.float32, device=dev)
-    pm = 1.0 / denom
     c0 = (C.c_float * 5)(w_photo * pm, w_photo * pm, w_tv, -w_ssim / numel_ssim if n_ssim else 0.0,
                          w_iso if iso_ws is not None else 0.0)
     c1 = (C.c_float * 5)(pm, pm, 0.0, 0.0, 0.0)
@@ -163,13 +170,15 @@ def mapping_loss_and_grads(outputs, gt_imgs: Tensor, exposure_params: Tensor, lo
                           0 if active_gs else 1, backward_fn, iso_grad_fn)
 
 
-def tracking_loss_and_grads(outputs, gt_img: Tensor, exposure_params: Tensor):
+def tracking_loss_and_grads(outputs, gt_img: Tensor, exposure_params: Tensor, finish: bool = True):
     """The tracking loss without the autograd node: (out2[loss, loss], v_render, v_exposure [2]); the caller seeds the
-    backward with ``torch.autograd.backward([outputs._render], [v_render])`` (no multiply-by-one kernels, no clones)."""
+    backward with ``torch.autograd.backward([outputs._render], [v_render])`` (no multiply-by-one kernels, no clones).
+    finish=False: ((partial rows workspace, n rows, loss coefficient), v_render, None) for gsx_track_opt_tail."""
     out2, v_render, v_exposure, _ = loss_and_grads(
         outputs._render, None, gt_img[None] if gt_img.dim() == 3 else gt_img, exposure_params.reshape(1, 2), None, None,
-        -1 if outputs._depth_index is None else outputs._depth_index, outputs._betas_index, 1.0, 0.0, 0.0, 0.0, 2)
-    return out2, v_render, v_exposure.reshape(-1)
+        -1 if outputs._depth_index is None else outputs._depth_index, outputs._betas_index, 1.0, 0.0, 0.0, 0.0, 2,
+        finish=finish)
+    return out2, v_render, (v_exposure.reshape(-1) if v_exposure is not None else None)
 
 
 def fused_tracking_loss(outputs, gt_img: Tensor, exposure_params: Tensor):

@@ -188,16 +188,16 @@ class GraphedTracker:
         from ._lib import check, lib, stream_ptr
         from .ops import workspace
         out = self.splats._render([self.camera], self._viewmat, 'RGB', 0.5, need_n_touched=False)
-        out2, v_render, v_exposure = self._loss_fn(out, self.img, self.exposure)
+        (loss_ws, n_rows, coef), v_render, _ = self._loss_fn(out, self.img, self.exposure, finish=False)
         torch.autograd.backward([out._render], [v_render])      # ends with the pose partials in the workspace
-        loss = out2[0:1]
         N = int(self.splats.means.shape[0])
-        ws = workspace(lib.gsx_project_bwd_workspace_bytes(N, 1), loss.device, "proj_bwd")
+        dev = v_render.device
+        ws = workspace(lib.gsx_project_bwd_workspace_bytes(N, 1), dev, "proj_bwd")
         check(lib.gsx_track_opt_tail(self._state.data_ptr(), ws.data_ptr(), int(lib.gsx_project_bwd_blocks(N)),
                                      self.pose.Rt.data_ptr(), self.pose.dt.data_ptr(), self.pose.dR.data_ptr(),
-                                     self.exposure.data_ptr(), v_exposure.data_ptr(), loss.data_ptr(),
-                                     self._viewmat.data_ptr(), stream_ptr(loss.device)), "gsx_track_opt_tail")
-        return loss
+                                     self.exposure.data_ptr(), None, None, self._viewmat.data_ptr(),
+                                     loss_ws.data_ptr(), n_rows, coef, stream_ptr(dev)), "gsx_track_opt_tail")
+        return None
 
     def load(self, frame: Frame, prev_exposure: Optional[torch.Tensor] = None):
         with torch.no_grad():

@@ -275,9 +275,13 @@ int gsx_track_opt_report(const void *state, float *out8, void *stream);
 /* The tail of the tracker's closure in one launch (one camera): reduces the pose-gradient partials that
  * gsx_project_bwd(flags | GSX_PROJ_VIEW_PARTIALS) left in its workspace, runs the PoseZhou backward (gslam/primitives.py:
  * 82-92), advances the state machine on the 11 parameters (dt[3], dR[6], exposure[2], in this order; v_exposure from the
- * loss block), writes them back and writes the PoseZhou forward of the new parameters to viewmat [4,4]. */
+ * loss block), writes them back and writes the PoseZhou forward of the new parameters to viewmat [4,4].
+ * loss_rows != NULL: the tracking loss is finished here too - the n_loss_rows per-workgroup rows that
+ * gsx_map_loss(sums = NULL, C = 1) left in its workspace give loss = loss_coef * (col 0 + col 1) and the exposure
+ * gradient (col 3, col 4); v_exposure / loss are then ignored and gsx_loss_finish is not needed. */
 int gsx_track_opt_tail(void *state, const void *pose_partials, int64_t n_blocks, const float *Rt, float *dt, float *dR,
-                       float *exposure, const float *v_exposure, const float *loss, float *viewmat, void *stream);
+                       float *exposure, const float *v_exposure, const float *loss, float *viewmat,
+                       const void *loss_rows, int64_t n_loss_rows, float loss_coef, void *stream);
 /* The same state machine sized for the backend's window pose refinement (gslam/backend.py:447-506): up to 80 parameters
  * in up to 16 tensors, L-BFGS history up to 10; n_adam = 0 skips the Adam phase.  Arguments as above. */
 int64_t gsx_window_opt_state_bytes(void);
@@ -287,7 +291,8 @@ int gsx_window_opt_advance(void *state, int n_tensors, float *const *params, con
                            const int *numels, const float *loss, void *stream);
 int gsx_window_opt_report(const void *state, float *out8, void *stream);
 int gsx_window_opt_tail(void *state, const void *pose_partials, int64_t n_blocks, const float *Rt, float *dt, float *dR,
-                        float *exposure, const float *v_exposure, const float *loss, float *viewmat, void *stream);
+                        float *exposure, const float *v_exposure, const float *loss, float *viewmat,
+                        const void *loss_rows, int64_t n_loss_rows, float loss_coef, void *stream);
 
 /* ---- map maintenance: every per-Gaussian array re-packed in ONE launch.
  * gsx_gather_rows: dst[k][r] = src[k][index[r]] for r < n_out, k < n_tensors (<= 32); the masked re-allocation of
