@@ -188,6 +188,37 @@ __device__ __forceinline__ float gsx_xrow_sum(float v) {
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
+// Cross-row step of the reduce-scatter for NR = 2 or 3 registers (value sets): instead of summing every register over
+// the four rows (3 instructions per register and level), the swaps hand each row ONE value set to total:
+//   v_permlane32_swap(a, b): a' = [a.lo, b.lo], b' = [a.hi, b.hi]          -> a' + b' = [a.lo + a.hi | b.lo + b.hi]
+//   v_permlane16_swap(a, b): a' = [a.r0, b.r0, a.r2, b.r2], b' = [a.r1, b.r1, a.r3, b.r3]
+// (probed on gfx950: tools/ubench/permlane_test.hip).  Result: row 0 = total of set 0, row 2 = total of set 1, row 1
+// (and 3) = total of set 2 (NR = 3) or copies of rows 0 / 2 (NR = 2).  7 (5) instructions instead of 18 (12).
+__device__ __forceinline__ float gsx_add_swapped(unsigned a, unsigned b, bool rows16) {
+    if (rows16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int NR>
+__device__ __forceinline__ float gsx_xrow_scatter(const float *v) {
+    static_assert(NR == 2 || NR == 3, "gsx_xrow_scatter: 2 or 3 value sets");
+    const float t = gsx_add_swapped(__float_as_uint(v[0]), __float_as_uint(v[1]), false);
+    const float u = (NR == 3) ? gsx_add_swapped(__float_as_uint(v[2]), __float_as_uint(v[2]), false) : t;
+    return gsx_add_swapped(__float_as_uint(t), __float_as_uint(u), true);
+}
+// column (value index) a lane of row `row`, bank `bank` holds after gsx_reduce_scatter + gsx_xrow_scatter, or -1
+template <int NR>
+__device__ __forceinline__ int gsx_xrow_column(int lane) {
+    const int row = lane >> 4, bank = (lane >> 2) & 3;
+    if ((lane & 3) != 0) return -1;
+    if (row == 0) return bank;
+    if (row == 2) return 4 + bank;
+    return (NR == 3 && row == 1) ? 8 + bank : -1;
+}
+
 // 48-byte splat record fetched through the scalar data cache into SGPRs (uniform address): the broadcast of a
 // Gaussian to all 64 pixel lanes costs no VALU instruction and no LDS traffic.
 typedef float gsx_f4 __attribute__((ext_vector_type(4)));
