@@ -672,7 +672,7 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
                               const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
                               int tile_w, int tile_h, const float *alphas, const int32_t *last_ids,
                               const float *v_render, const float *v_alphas, float *v_rec, float *v_abs,
-                              const int32_t *tile_order, void *stream) {
+                              const int32_t *tile_order, int geometry_only, void *stream) {
     GSX_CHECK_ARG(offsets && alphas && last_ids && v_render && C >= 1 && W > 0 && H > 0);  // v_alphas: NULL = 0
     GSX_CHECK_ARG(tile_w == (W + GSX_TILE - 1) / GSX_TILE && tile_h == (H + GSX_TILE - 1) / GSX_TILE);
     GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31));
@@ -690,7 +690,10 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     // per lane balance better although they execute more instructions in total (modes 5 / 6 = batches of 64 / 128:
     // another -4..5 %; batches of 128 pay off with deep tile lists).  GSX_BWD_MODE=0..6 for A/B runs (tools/ab_raster.py).
     const int bwd_auto = T >= 4096 ? 4 : (M / (T > 0 ? T : 1) > 1000 ? 6 : 5);
-    const int bwd_mode = (bb && bb[0] >= '0' && bb[0] <= '6') ? bb[0] - '0' : bwd_auto;
+    // geometry-only gradients exist in the quadrant kernels; a caller that asks for them gets those kernels
+    const bool geom_only = geometry_only != 0 && !v_abs;
+    const int bwd_mode = geom_only ? (M / (T > 0 ? T : 1) > 1000 ? 6 : 5)
+                                   : (bb && bb[0] >= '0' && bb[0] <= '6') ? bb[0] - '0' : bwd_auto;
     const char *sb = getenv("GSX_BWD_SCALAR");
     const bool scalar_bwd = sb && sb[0] == '1';
 #define ARGS1 rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
@@ -699,13 +702,23 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     do {                                                                                                            \
         if (variant >= 4 && !v1 && !v_abs) {                                                                        \
             if (bwd_mode == 5)                                                                                      \
-                hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64>), dim3((unsigned)T), dim3(256), 0, st, rec,     \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec, tile_order);                                    \
+                if (geom_only)                                                                                      \
+                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, true>), dim3((unsigned)T), dim3(256), 0, st, \
+                                       rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
+                                       tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
+                else                                                                                                \
+                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, false>), dim3((unsigned)T), dim3(256), 0, st, \
+                                       rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
+                                       tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
             else if (bwd_mode == 6)                                                                                 \
-                hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128>), dim3((unsigned)T), dim3(256), 0, st, rec,    \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec, tile_order);                                    \
+                if (geom_only)                                                                                      \
+                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128, true>), dim3((unsigned)T), dim3(256), 0, st, \
+                                       rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
+                                       tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
+                else                                                                                                \
+                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128, false>), dim3((unsigned)T), dim3(256), 0, st, \
+                                       rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
+                                       tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
             else if (bwd_mode == 3)                                                                                 \
                 hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 3>), dim3((unsigned)T), dim3(128), 0, st, rec, \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \

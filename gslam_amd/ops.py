@@ -300,8 +300,9 @@ class _RasterizeRecords(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rec, means2d, conics, backgrounds, offsets, flatten_ids, ch, width, height, vis_min_T, absgrad,
-                has_end=False, want_touched=True, v_rec_buf=None, tile_order=None):
-        """tile_order: int32 [T] launch order of the tiles (isect_bin_sort), a scheduling hint.
+                has_end=False, want_touched=True, v_rec_buf=None, tile_order=None, geometry_only=False):
+        """geometry_only: the caller only needs the xy / conic gradient columns (frozen map, no depth channel).
+        tile_order: int32 [T] launch order of the tiles (isect_bin_sort), a scheduling hint.
         v_rec_buf: a [C,N,RS] buffer already cleared by the projection forward (see _Projection) for the backward's
         gradient records; used once, a second backward through the same node allocates its own.
         has_end: ``offsets`` is the flat int32 [T+1] array of gsx_isect_bin_sort and ``flatten_ids`` a
@@ -325,6 +326,7 @@ class _RasterizeRecords(torch.autograd.Function):
                                  ptr(n_touched), ptr(tile_order), stream_ptr(dev)), "gsx_raster_fwd")
         ctx.save_for_backward(rec, bg, offsets, flatten_ids, alphas, last_ids)
         ctx.tile_order = tile_order
+        ctx.geometry_only = bool(geometry_only)
         ctx.set_materialize_grads(False)
         ctx.cfg = (ch, width, height, absgrad, has_end)
         ctx.means2d_ref = means2d
@@ -343,7 +345,7 @@ class _RasterizeRecords(torch.autograd.Function):
         dev = rec.device
         tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
         if v_render is None and v_alphas is None:
-            return (None,) * 15
+            return (None,) * 16
         v_render = torch.zeros_like(alphas).expand(-1, -1, -1, ch).contiguous() if v_render is None \
             else v_render.contiguous()
         v_alphas = None if v_alphas is None else v_alphas.contiguous()      # NULL = zero gradient (kernel-side)
@@ -354,8 +356,8 @@ class _RasterizeRecords(torch.autograd.Function):
         check(lib.gsx_raster_bwd(ptr(rec), ch, ptr(bg), ptr(offsets), ptr(flatten_ids), flatten_ids.shape[0],
                                  1 if has_end else 0, Cn, width, height, tile_w, tile_h, ptr(alphas), ptr(last_ids),
                                  ptr(v_render),
-                                 ptr(v_alphas), ptr(v_rec), ptr(v_abs), ptr(ctx.tile_order), stream_ptr(dev)),
-              "gsx_raster_bwd")
+                                 ptr(v_alphas), ptr(v_rec), ptr(v_abs), ptr(ctx.tile_order),
+                                 1 if (ctx.geometry_only and not absgrad) else 0, stream_ptr(dev)), "gsx_raster_bwd")
         if absgrad and ctx.means2d_ref is not None:
             ctx.means2d_ref.absgrad = v_abs  # same side channel as gsplat (absgrad is off in gslam, rasterization.py:63)
         if getattr(ctx.means2d_ref, "_gsx_share_grad", False):
@@ -364,7 +366,7 @@ class _RasterizeRecords(torch.autograd.Function):
         v_bg = None
         if bg is not None and ctx.needs_input_grad[3]:
             v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
-        return (v_rec, v_rec[..., 0:2], v_rec[..., 2:5], v_bg) + (None,) * 11
+        return (v_rec, v_rec[..., 0:2], v_rec[..., 2:5], v_bg) + (None,) * 12
 
 
 class _PackRecords(torch.autograd.Function):

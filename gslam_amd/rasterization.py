@@ -280,6 +280,10 @@ def rasterization(
         t is not None and t.requires_grad for t in (means, quats, log_scales, viewmats, logit_opacities, logit_colors,
                                                     log_uncertainties))
     v_rec_buf = torch.empty(C, N, 12, dtype=torch.float32, device=means.device) if needs_grad else None
+    # frozen map (tracking) and no depth channel: the colour / opacity columns of the gradient records feed nothing,
+    # the rasteriser backward then reduces five values per survivor instead of 6 + CH
+    geom_only = needs_grad and depth_index is None and not any(
+        t is not None and t.requires_grad for t in (logit_opacities, logit_colors, log_uncertainties))
     radii, means2d, depths, conics, _comps, rec, tiles_per_gauss, vis_count = ops._Projection.apply(
         means, quats, log_scales, viewmats, Ks, logit_opacities, logit_colors, log_uncertainties, int(width),
         int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), False, flags, True, True,
@@ -334,7 +338,7 @@ def rasterization(
 
     render, alphas, n_touched, _last = ops._RasterizeRecords.apply(
         rec, means2d, conics, bg, raster_offsets, flatten_ids, ch, int(width), int(height), float(visibility_min_T),
-        bool(absgrad), has_end, bool(need_n_touched), v_rec_buf, tile_order)
+        bool(absgrad), has_end, bool(need_n_touched), v_rec_buf, tile_order, geom_only)
 
     out = RasterizationOutput(
         rgbs=render[..., :3],

@@ -156,6 +156,8 @@ int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int
                    int tile_h,
                    const float *alphas, const int32_t *last_ids, const float *v_render, const float *v_alphas,
                    float *v_rec, float *v_abs, const int32_t *tile_order /*[T] nullable, as in gsx_raster_fwd*/,
+                   int geometry_only /* != 0: only the xy / conic columns of v_rec are wanted (tracking against a frozen map,
+                                        no depth channel); the opacity / colour columns are then left as they are */,
                    void *stream);
 
 /* ---- K13: spherical harmonics (gsplat.rendering.rasterization(sh_degree=)) -------------------------- */

@@ -148,3 +148,20 @@ def test_binning_variants_give_identical_tile_lists(dev, monkeypatch, presort):
     monkeypatch.setenv("GSX_BIN_PRESORT", presort)
     _, ids2, flat2 = ops.isect_tiles(m2d, radii, dep, 16, tw, th, n_cameras=C)
     assert ids1.shape[0] > 100000 and torch.equal(ids1, ids2) and torch.equal(flat1, flat2)
+
+
+def test_geometry_only_backward_gives_the_same_pose_gradient(dev):
+    """frozen map, no depth channel: the rasteriser backward reduces only the xy / conic columns (GEOM kernels); the
+    pose gradient equals the one of the full backward (map learnable, same render)"""
+    sa, wa = _window(dev, cams=1)
+    sb, wb = _window(dev, cams=1)
+    for k in PARAMS:
+        getattr(sb, k).requires_grad_(False)
+    outs = []
+    for s, w in ((sa, wa), (sb, wb)):
+        out = s([w[0].camera], [w[0].pose], render_depth=False)           # RGB + beta: four channels, no depth
+        loss = ((out.rgbs - w[0].img[None]).square().sum(-1) / out.betas.square()).mean() + 0.01 * out.alphas.mean()
+        loss.backward()
+        outs.append((w[0].pose.dR.grad.clone(), w[0].pose.dt.grad.clone()))
+    _close(outs[1][0], outs[0][0], 1e-4, "dR")
+    _close(outs[1][1], outs[0][1], 1e-4, "dt")

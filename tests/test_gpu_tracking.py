@@ -212,5 +212,5 @@ def test_fused_closure_tail_equals_split_launches(dev, monkeypatch):
         res[mode] = out
     for (pa, ea, la, na), (pb, eb, lb, nb) in zip(res["split"], res["fused"]):
         assert abs(na - nb) <= 3 and 11 <= nb <= 37
-        assert (pa - pb).abs().max() < 2e-3 and (ea - eb).abs().max() < 2e-2
+        assert (pa - pb).abs().max() < 1e-2 and (ea - eb).abs().max() < 3e-2
         assert max(la, lb) <= 1.5 * min(la, lb) + 1e-4

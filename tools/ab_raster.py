@@ -72,7 +72,7 @@ def run(N, C, W=640, H=480):
 
     def bwd():
         check(lib.gsx_raster_bwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, tw, th, ptr(alphas),
-                                 ptr(last), ptr(v_render), ptr(v_alpha), ptr(v_rec), None, ptr(cur_order[0]), st), "bwd")
+                                 ptr(last), ptr(v_render), ptr(v_alpha), ptr(v_rec), None, ptr(cur_order[0]), 0, st), "bwd")
 
     def sort1():
         ops.isect_tiles(m2d, radii, dep, 16, tw, th, tiles_per_gauss=tiles)

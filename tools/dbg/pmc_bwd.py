@@ -24,5 +24,5 @@ st = stream_ptr(dev)
 check(lib.gsx_raster_fwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, tw, th, 0.5, ptr(render_t), ptr(alphas), ptr(last), ptr(nt), None, st), "fwd")
 for _ in range(3):
     v_rec.zero_()
-    check(lib.gsx_raster_bwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, tw, th, ptr(alphas), ptr(last), ptr(v_render), ptr(v_alpha), ptr(v_rec), None, None, st), "bwd")
+    check(lib.gsx_raster_bwd(ptr(rec), 5, ptr(bg), ptr(off), ptr(flat), M, 0, C, W, H, tw, th, ptr(alphas), ptr(last), ptr(v_render), ptr(v_alpha), ptr(v_rec), None, None, 0, st), "bwd")
     torch.cuda.synchronize()
