@@ -430,8 +430,8 @@ def test_adam_matches_torch_and_oracle(dev, oracle32):
         assert np.abs(_np(p) - cp).max() < 1e-6
 
 
-@pytest.mark.parametrize("regularize", [True, False])
-def test_fused_mapping_loss_matches_reference_formulation(dev, regularize):
+@pytest.mark.parametrize("regularize,c", [(True, 2), (False, 2), (True, 17)])
+def test_fused_mapping_loss_matches_reference_formulation(dev, regularize, c):
     """csrc/loss.hip (one pass, analytic gradient) vs the reference's own torch formulation of
     gslam/backend.py:273-318 (gslam_amd.mapping.mapping_loss) - values and every gradient."""
     from gslam_amd.map import GaussianSplattingData
@@ -439,7 +439,7 @@ def test_fused_mapping_loss_matches_reference_formulation(dev, regularize):
     from gslam_amd.losses import fused_mapping_loss
     from gslam_amd.primitives import Camera, PoseZhou
     from gslam_amd.synthetic import make_cameras, make_scene
-    n, c, W, H = 3000, 2, 200, 152
+    n, W, H = 3000, 200, 152          # c=17: more cameras than gsx_loss_finish's split path handles in one row
     sc = make_scene(n, 21)
     sc["scales"] = sc["scales"] + 0.6
     viewmats, Ks = make_cameras(c, W, H)
@@ -451,7 +451,8 @@ def test_fused_mapping_loss_matches_reference_formulation(dev, regularize):
         splats = GaussianSplattingData.from_dict(sc, dev)
         cams = [Camera(Ks[i].to(dev), H, W) for i in range(c)]
         poses = [PoseZhou(viewmats[i].to(dev)).to(dev) for i in range(c)]
-        exposure = torch.tensor([[0.1, -0.05], [-0.2, 0.03]], device=dev).requires_grad_(True)
+        exposure = (torch.tensor([[0.1, -0.05], [-0.2, 0.03]]).repeat((c + 1) // 2, 1)[:c]
+                    * torch.linspace(1.0, 0.5, c)[:, None]).to(dev).requires_grad_(True)
         out = splats(cams, poses, render_depth=True)
         if fused:
             total, pm = fused_mapping_loss(out, gt, exposure, splats.scales, ssim_weight=conf.ssim_weight,
