@@ -104,15 +104,17 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__
             const float s1q = e11 - m1 * m1, s2q = e22 - m2 * m2, s12 = e12 - m1 * m2;
             const float A = 2.0f * m1 * m2 + GSX_SSIM_C1, B = 2.0f * s12 + GSX_SSIM_C2;
             const float Cq = m1 * m1 + m2 * m2 + GSX_SSIM_C1, D = s1q + s2q + GSX_SSIM_C2;
-            const float m = (A * B) / (Cq * D);
+            // One division: with icd = 1/(Cq D), 1/D = icd Cq and 1/Cq = icd D, so the four quotients of d(map)/d(mu1)
+            // collapse to 2 icd (m2 (B - A) + m1 m (Cq - D)) (the IEEE divides were a quarter of the kernel's VALU work).
+            const float icd = 1.0f / (Cq * D);
+            const float m = (A * B) * icd;
             const bool in_crop = gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;
             if (in_crop) val += m;
             if (dm_dmu1) {
                 const int64_t o_ = ((int64_t)plane * H + gy) * W + gx;
-                dm_dmu1[o_] = (m2 * 2.0f * B) / (Cq * D) - (m2 * 2.0f * A) / (Cq * D) - (m1 * 2.0f * A * B) / (Cq * Cq * D) +
-                              (m1 * 2.0f * A * B) / (Cq * D * D);
-                dm_ds1[o_] = (-A * B) / (Cq * D * D);
-                dm_ds12[o_] = (2.0f * A) / (Cq * D);
+                dm_dmu1[o_] = 2.0f * icd * (m2 * (B - A) + m1 * m * (Cq - D));
+                dm_ds1[o_] = -m * (icd * Cq);
+                dm_ds12[o_] = 2.0f * A * icd;
             }
         }
     }
