@@ -80,7 +80,7 @@ __device__ __forceinline__ SRec<RS> bcast_record(const float (&v)[RS], int j) {
     SRec<RS> r;
     r.a = gsx_f4{bcast(v[0], j), bcast(v[1], j), bcast(v[2], j), bcast(v[3], j)};
     r.b = gsx_f4{bcast(v[4], j), bcast(v[5], j), bcast(v[6], j), bcast(v[7], j)};
-    if (RS > 8) r.c = gsx_f4{bcast(v[8], j), bcast(v[9], j), bcast(v[10], j), 0.f};
+    if constexpr (RS > 8) r.c = gsx_f4{bcast(v[8], j), bcast(v[9], j), bcast(v[10], j), 0.f};
     else r.c = gsx_f4{0.f, 0.f, 0.f, 0.f};
     return r;
 }
