@@ -2,7 +2,7 @@
 // torch.optim.LBFGS(line_search_fn='strong_wolfe').step() of gslam/frontend.py:604-662, restated as a state machine
 // that is advanced once per closure evaluation.  The reference runs this logic on the host and pays one
 // `loss.item()` synchronisation per closure (frontend.py:648); here the whole logic lives in one small device struct
-// and one single-lane kernel per evaluation, so a tracked frame is a fixed sequence of graph launches with no
+// and one single-wavefront kernel per evaluation, so a tracked frame is a fixed sequence of graph launches with no
 // read-back.
 //
 // The algorithm is torch's (torch/optim/lbfgs.py: `LBFGS.step`, `_strong_wolfe`, `_cubic_interpolate`; Adam with

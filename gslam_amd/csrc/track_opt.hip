@@ -1,4 +1,4 @@
-// track_opt.hip — device-resident tracking optimiser (track_opt.h) behind the C ABI: one single-lane launch per
+// track_opt.hip — device-resident tracking optimiser (track_opt.h) behind the C ABI: one single-wavefront launch per
 // closure evaluation replaces the host-side torch.optim.Adam / torch.optim.LBFGS logic of
 // gslam/frontend.py:604-662 and its per-closure `loss.item()` (frontend.py:648).
 #include "gsx_common.h"

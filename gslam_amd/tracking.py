@@ -122,7 +122,7 @@ class GraphedTracker:
     every closure of every frame: ~12 kernel launches become one graph launch.
 
     ``device_optimizer=True`` (default) also moves the optimiser of frontend.py:613-658 - 10 Adam steps, then one
-    strong-Wolfe L-BFGS step - onto the device (csrc/track_opt.h): the state machine is advanced by one single-lane
+    strong-Wolfe L-BFGS step - onto the device (csrc/track_opt.h): the state machine is advanced by one single-wavefront
     kernel at the end of the captured closure, so a tracked frame is ``n_adam + max_eval + 1`` graph launches and ONE
     read-back at the end instead of one ``loss.item()`` per closure (frontend.py:648).  With ``False`` the optimiser
     logic stays on the host exactly as in the reference (torch.optim.Adam / torch.optim.LBFGS)."""
