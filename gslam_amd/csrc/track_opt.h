@@ -26,13 +26,36 @@
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 #define TO_LANE ((int)(threadIdx.x & 63u))
 #define TO_LANES 64
+/* Lane exchange inside a row of 16 by DPP on the two halves of the double (quad swaps, then the two mirrors: after the
+ * four steps all 16 lanes of a row hold the row's result), rows combined through v_readlane in a fixed order.  An
+ * L-BFGS iteration makes ~16 such reductions; through ds_bpermute they were most of the closure tail's time. */
+template <int CTRL>
+static __device__ __forceinline__ double to_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double to_row_value(double v, int row) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), row * 16),
+                            __builtin_amdgcn_readlane(__double2loint(v), row * 16));
+}
 TO_FN double to_lanes_sum(double v) {
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += to_dpp<0xB1>(v);                      /* quad_perm [1,0,3,2] */
+    v += to_dpp<0x4E>(v);                      /* quad_perm [2,3,0,1] */
+    v += to_dpp<0x141>(v);                     /* row_half_mirror */
+    v += to_dpp<0x140>(v);                     /* row_mirror */
+    return (to_row_value(v, 0) + to_row_value(v, 1)) + (to_row_value(v, 2) + to_row_value(v, 3));
 }
 TO_FN double to_lanes_max(double v) {
-    for (int o = 32; o >= 1; o >>= 1) { const double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
-    return v;
+    double w;
+    w = to_dpp<0xB1>(v); v = w > v ? w : v;
+    w = to_dpp<0x4E>(v); v = w > v ? w : v;
+    w = to_dpp<0x141>(v); v = w > v ? w : v;
+    w = to_dpp<0x140>(v); v = w > v ? w : v;
+    const double a = to_row_value(v, 0), b = to_row_value(v, 1), c = to_row_value(v, 2), d = to_row_value(v, 3);
+    const double ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 #else
 #define TO_LANE 0
