@@ -60,6 +60,8 @@ PROTOTYPES = {
     "gsx_pose_zhou_fwd": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, vp]),
     "gsx_pose_zhou_bwd": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, C.POINTER(vp),
                                 C.POINTER(vp), vp]),
+    "gsx_pose_zhou_bwd_partials": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, i64, vp,
+                                         C.POINTER(vp), C.POINTER(vp), vp]),
     "gsx_adam_multi": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
                              C.POINTER(f32), f32, f32, f32, i64, vp, vp]),
     "gsx_adam_multi_steps": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),

@@ -72,6 +72,15 @@ class _Projection(torch.autograd.Function):
         # a caller that consumes the pose gradient itself (tracking.GraphedTracker's fused closure tail) marks its view
         # matrices: the backward then leaves the per-workgroup partials in the "proj_bwd" workspace and returns no grad
         ctx.view_partials = bool(getattr(viewmats, "_gsx_partials_only", False))
+        # viewmats that come straight out of primitives.pose_batch carry a link object: the backward then leaves its
+        # pose partials to the PoseZhou backward (one launch instead of finishing pass + pose backward).  Only the
+        # first projection that consumes a given viewmats tensor takes the link; any other one returns v_viewmats.
+        link = getattr(viewmats, "_gsx_pose_link", None)
+        if link is not None and not ctx.view_partials and not link.claimed and viewmats.shape[0] == link.count:
+            link.claimed = True
+            ctx.pose_link = link
+        else:
+            ctx.pose_link = None
         viewmats, Ks = _f32c(viewmats, "viewmats"), _f32c(Ks, "Ks")
         N, Cn = means.shape[0], viewmats.shape[0]
         dev = means.device
@@ -133,7 +142,8 @@ class _Projection(torch.autograd.Function):
         if v_rec is not None:
             v_rec = v_rec.contiguous()
         need_view = ctx.needs_input_grad[3]
-        partials_only = need_view and ctx.view_partials
+        link = ctx.pose_link if need_view else None
+        partials_only = need_view and (ctx.view_partials or link is not None)
         if partials_only:
             flags |= 8                                          # GSX_PROJ_VIEW_PARTIALS
         # tracking (frozen map): only the pose gradient is wanted; the kernel then skips the per-Gaussian chain and stores
@@ -148,7 +158,11 @@ class _Projection(torch.autograd.Function):
             v_lc = torch.empty_like(logit_colors)
             v_lu = torch.empty_like(log_unc) if log_unc is not None else None
         ws_bytes = lib.gsx_project_bwd_workspace_bytes(N, Cn)
-        ws = workspace(ws_bytes, dev, "proj_bwd")
+        if link is not None:        # the partials outlive this call: their own buffer, not the shared workspace
+            ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
+            link.partials = (ws, int(lib.gsx_project_bwd_blocks(N)))
+        else:
+            ws = workspace(ws_bytes, dev, "proj_bwd")
         check(lib.gsx_project_bwd(ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), N, Cn, width, height,
                                   eps2d, near_plane, far_plane, flags, ptr(radii), ptr(v_means2d), s_m2d,
                                   ptr(v_depths), ptr(v_conics), s_con, ptr(v_comps), ptr(logit_opac),

@@ -44,13 +44,25 @@ class PoseZhou(torch.nn.Module):
 Pose = PoseZhou  # gslam/map.py:5 imports the pose type under this name
 
 
+class _PoseLink:
+    """hand-over between the projection backward and the pose backward of one pose_batch() result (see ops._Projection):
+    ``partials`` = (buffer, n_blocks) of per-workgroup pose-gradient partials, set by the projection backward and
+    consumed by _PoseBatch.backward"""
+    __slots__ = ("count", "claimed", "partials")
+
+    def __init__(self, count: int):
+        self.count, self.claimed, self.partials = count, False, None
+
+
 class _PoseBatch(torch.autograd.Function):
     """viewmats [C,4,4] of C PoseZhou modules in one launch (csrc/pose.hip); inputs are (Rt_0, dR_0, dt_0, Rt_1, ...)."""
 
     @staticmethod
-    def forward(ctx, learnable, *tensors):
+    def forward(ctx, link, learnable, *tensors):
         import ctypes as C
         from ._lib import check, lib, stream_ptr
+        ctx.link = link
+        ctx.set_materialize_grads(False)          # a projection that took the link returns no v_viewmats at all
         n = len(learnable)
         Rts, dRs, dts = tensors[0::3], tensors[1::3], tensors[2::3]
         dev = Rts[0].device
@@ -70,14 +82,27 @@ class _PoseBatch(torch.autograd.Function):
         learnable = ctx.learnable
         n = len(learnable)
         Rts, dRs, dts = tensors[0::3], tensors[1::3], tensors[2::3]
-        dev = v_view.device
+        link = ctx.link
+        partials, link.partials = link.partials, None
+        if v_view is None and partials is None:
+            return (None, None) + (None,) * len(tensors)
+        dev = Rts[0].device
         v_dR = [torch.empty_like(t) for t in dRs]
         v_dt = [torch.empty_like(t) for t in dts]
         arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
-        check(lib.gsx_pose_zhou_bwd(n, arr(Rts), arr(dRs), arr(dts), (C.c_int * n)(*learnable),
-                                    v_view.contiguous().data_ptr(), arr(v_dR), arr(v_dt), stream_ptr(dev)),
-              "gsx_pose_zhou_bwd")
-        grads = [None]
+        if partials is not None:
+            # the projection backward left its per-workgroup pose partials (ops._Projection.backward): summed and
+            # pushed through the pose algebra in one launch; v_view holds what reached the view matrices otherwise
+            buf, n_blocks = partials
+            extra = None if v_view is None else v_view.contiguous()
+            check(lib.gsx_pose_zhou_bwd_partials(n, arr(Rts), arr(dRs), arr(dts), (C.c_int * n)(*learnable),
+                                                 buf.data_ptr(), n_blocks, None if extra is None else extra.data_ptr(),
+                                                 arr(v_dR), arr(v_dt), stream_ptr(dev)), "gsx_pose_zhou_bwd_partials")
+        else:
+            check(lib.gsx_pose_zhou_bwd(n, arr(Rts), arr(dRs), arr(dts), (C.c_int * n)(*learnable),
+                                        v_view.contiguous().data_ptr(), arr(v_dR), arr(v_dt), stream_ptr(dev)),
+                  "gsx_pose_zhou_bwd")
+        grads = [None, None]
         for i in range(n):
             grads += [None, v_dR[i] if learnable[i] else None, v_dt[i] if learnable[i] else None]
         return tuple(grads)
@@ -92,7 +117,11 @@ def pose_batch(poses) -> torch.Tensor:
     flat = []
     for p in poses:
         flat += [p.Rt.contiguous(), p.dR, p.dt]
-    return _PoseBatch.apply(tuple(1 if p.is_learnable else 0 for p in poses), *flat)
+    link = _PoseLink(len(poses))
+    out = _PoseBatch.apply(link, tuple(1 if p.is_learnable else 0 for p in poses), *flat)
+    if out.requires_grad:
+        out._gsx_pose_link = link
+    return out
 
 
 @dataclass

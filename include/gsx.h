@@ -235,6 +235,14 @@ int gsx_pose_zhou_fwd(int C, const float *const *Rt, const float *const *dR, con
 int gsx_pose_zhou_bwd(int C, const float *const *Rt, const float *const *dR, const float *const *dt,
                       const int *learnable, const float *v_viewmats, float *const *v_dR, float *const *v_dt,
                       void *stream);
+/* The same backward fed by the pose-gradient partials gsx_project_bwd(flags | GSX_PROJ_VIEW_PARTIALS) left in its
+ * workspace ([n_blocks][C][12], n_blocks = gsx_project_bwd_blocks(N)): sums them (the order of the projection's own
+ * finishing pass), adds v_viewmats_extra [C,4,4] if not NULL, and runs the PoseZhou backward - one launch instead of
+ * the finishing pass plus gsx_pose_zhou_bwd. */
+int gsx_pose_zhou_bwd_partials(int C, const float *const *Rt, const float *const *dR, const float *const *dt,
+                               const int *learnable, const float *partials, int64_t n_blocks,
+                               const float *v_viewmats_extra /*nullable*/, float *const *v_dR, float *const *v_dt,
+                               void *stream);
 
 /* ---- fused Adam (torch.optim.Adam(fused=True) defaults; gslam/backend.py:565-602).  Up to 32 tensors per launch
  * (every numel >= 1).

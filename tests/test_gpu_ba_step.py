@@ -165,3 +165,35 @@ def test_geometry_only_backward_gives_the_same_pose_gradient(dev):
         outs.append((w[0].pose.dR.grad.clone(), w[0].pose.dt.grad.clone()))
     _close(outs[1][0], outs[0][0], 1e-4, "dR")
     _close(outs[1][1], outs[0][1], 1e-4, "dt")
+
+
+@pytest.mark.parametrize("second_use", [False, True])
+def test_pose_gradient_through_the_projection_partials_equals_the_two_launch_path(dev, second_use):
+    """primitives.pose_batch links its view matrices to the projection backward (the pose partials go straight into
+    gsx_pose_zhou_bwd_partials); torch.stack of the module forwards (primitives.PoseZhou.forward, torch ops) takes the
+    finishing pass + torch autograd instead.  With ``second_use`` the view matrices also feed the loss directly, so
+    that a second gradient reaches them beside the projection's."""
+    from gslam_amd.primitives import pose_batch
+    splats, window = _window(dev, n=3000, W=160, H=128, cams=3, seed=57)
+    cams = [f.camera for f in window]
+    wmat = torch.randn(len(window), 4, 4, generator=torch.Generator().manual_seed(3)).to(dev)
+    gen = torch.Generator().manual_seed(9)
+    for f in window:                                    # away from the identity: the pose Jacobian is not trivial
+        with torch.no_grad():
+            f.pose.dR.add_(0.05 * torch.randn(6, generator=gen).to(dev))
+            f.pose.dt.add_(0.05 * torch.randn(3, generator=gen).to(dev))
+    grads = []
+    for linked in (True, False):
+        for f in window:
+            f.pose.dR.grad = f.pose.dt.grad = None
+        viewmats = pose_batch([f.pose for f in window]) if linked else torch.stack([f.pose() for f in window])
+        assert (getattr(viewmats, "_gsx_pose_link", None) is not None) == linked
+        out = splats._render(cams, viewmats, "RGB+D", 0.5)
+        loss = (out.rgbs * out.rgbs).sum() + out.depthmaps.sum()
+        if second_use:
+            loss = loss + (viewmats * wmat).sum()
+        loss.backward()
+        grads.append([(f.pose.dR.grad.clone(), f.pose.dt.grad.clone()) for f in window])
+    for (a_r, a_t), (b_r, b_t) in zip(*grads):
+        _close(a_r, b_r, 2e-4, "dR")
+        _close(a_t, b_t, 2e-4, "dt")
