@@ -84,6 +84,19 @@ PROTOTYPES = {
     "gsx_gather_rows": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, i64, i64, vp]),
     "gsx_concat_rows": (i32, [i32, C.POINTER(vp), i64, C.POINTER(vp), i64, C.POINTER(vp), C.POINTER(i32), vp]),
     "gsx_selftest": (i32, [vp, i64, vp]),
+    "gsx_stream_create": (i32, [C.POINTER(vp)]),
+    "gsx_stream_destroy": (i32, [vp]),
+    "gsx_stream_synchronize": (i32, [vp]),
+    "gsx_stream_wait_stream": (i32, [vp, vp]),
+    "gsx_graph_begin": (i32, [vp, i32]),
+    "gsx_graph_end": (i32, [vp, C.POINTER(vp), C.POINTER(i64)]),
+    "gsx_graph_abort": (i32, [vp]),
+    "gsx_graph_launch": (i32, [vp, vp]),
+    "gsx_graph_launch_n": (i32, [vp, i32, vp]),
+    "gsx_graph_destroy": (i32, [vp]),
+    "gsx_host_alloc": (i32, [C.POINTER(vp), C.POINTER(vp), i64]),
+    "gsx_host_free": (i32, [vp]),
+    "gsx_zero_words": (i32, [vp, i64, vp]),
 }
 
 

@@ -96,7 +96,7 @@ class Backend:
         return None if self.ba is None else self.ba.optimizers
 
     def initialize_optimizers(self):
-        self.ba = BundleAdjuster(self.splats, self.conf)
+        self.ba = BundleAdjuster(self.splats, self.conf, capturable=True)
 
     # ---- window selection (backend.py:193-247) -----------------------------------------------------------------------
     def optimization_window(self) -> List[Frame]:
@@ -126,51 +126,103 @@ class Backend:
 
     # ---- mapping (backend.py:249-407) --------------------------------------------------------------------------------
     def optimize_map(self, n_iters: Optional[int] = None, prune: bool = True, regularize: bool = True):
+        """backend.py:249-407.  An iteration is one replay of the window's launch plan (gslam_amd.plan.MappingStep: render,
+        loss, backward, [all-reduce], six splat Adams + pose Adam in one launch); the photometric term is read back once
+        per iteration for the early stop, as in the reference (:351), and the opacity decay (:356-359) follows that
+        decision as its own launch.  Multi-GPU: every rank runs this loop on its replica; the plan shards the window's
+        cameras and its one all-reduce makes update, loss and early-stop decision identical on all ranks."""
         conf = self.conf
         n_iters = conf.num_iters_mapping if n_iters is None else n_iters
         early_stopper = StopOnPlateau(3, 0.012)
         window = self.optimization_window()
-        outputs = None
+        plan = None
         for _ in range(n_iters):
             self.total_step += 1
             window = self.optimization_window()
-            # render + loss + backward ...
-            total, photometric = self.ba.render_backward(window, regularize)
-            outputs = self.ba.last_outputs
+            plan = self.ba.plan(window, regularize, decay_opacity=False)
             if (self.total_step % conf.densify_every) == 0:
-                # densification by image-plane gradients; the gradients of this iteration belong to the old rows, so
-                # this iteration's update is dropped and the loop goes on with the grown map
-                self.insertion_3dgs.step(self.splats, self.splat_optimizers, outputs, None, None)
+                # densification by image-plane gradients (:329-337): render + loss + backward, grow the map from
+                # means2d.grad, then the reference's optimiser step - the re-packed map tensors carry no gradient, so
+                # only the poses move
+                plan.render_backward()
+                self._densify(plan)
+                plan.step_poses()
+                pm = float(plan.out2[1].item())
                 self.ba.map_changed()
-                self.ba.optimizers.zero_grad()
                 prune = False
-                continue
-            # ... + Adam + opacity decay
-            self.ba.reduce()
-            self.ba.update()
-            if early_stopper.stop(photometric.item()):
+                decay = False          # the reference's mask has the old N here (it would fail on a grown map)
+            else:
+                for _attempt in range(3):
+                    plan.step()
+                    pm = float(plan.out2[1].item())                   # backend.py:351 (the sync the reference has too)
+                    if plan.capacity_ok():
+                        break
+                    # tile lists outgrew the plan's buffers: grown + re-captured by the next step().  The truncated
+                    # render already stepped the optimisers once; the redo replaces a silently wrong update by a second
+                    # small one (poses / map moved by one Adam step), which the loop tolerates.
+                decay = True
+            if early_stopper.stop(pm):
                 self.pause_map_optim = True
                 break
-        if outputs is None or outputs.depthmaps.shape[0] != len(window):
-            with torch.no_grad():
-                outputs = self.splats([f.camera for f in window], [f.pose for f in window], render_depth=True)
-        for f, d in zip(window, outputs.depthmaps):
-            f.est_depths = d.detach().clone()
+            if decay:
+                plan.decay_opacities()
+        outputs = self._window_outputs(plan, window)
+        if outputs is not None:
+            mine = plan.mine if (plan is not None and plan.matches(self.splats, window)) else range(len(window))
+            for i, d in zip(mine, outputs.depthmaps):
+                window[i].est_depths = d.detach().clone()
         if prune:
             self._prune(outputs, len(window) >= 2)
         self._render_last_keyframe()
 
-    def _prune(self, outputs: RasterizationOutput, visibility_ok: bool):
-        """size / opacity (/ conditioning) pruning, backend.py:364-392 and :409-437"""
+    def _window_outputs(self, plan, window):
+        """the last render of the window: the plan's buffers while they still describe the map, a fresh render otherwise
+        (the map was re-packed by the densification of the last iteration)"""
+        if plan is not None and plan.matches(self.splats, window):
+            return plan.as_output()
+        with torch.no_grad():
+            return self.splats([f.camera for f in window], [f.pose for f in window], render_depth=True,
+                               need_n_touched=self.ba.need_n_touched)
+
+    def _densify(self, plan):
+        outputs = plan.as_output()
+        shard = self.ba.shard
+        if outputs is None:                                         # a rank without cameras: zeros into the reduction
+            n = self.splats.means.shape[0]
+            dev = self.splats.means.device
+            outputs = RasterizationOutput(radii=torch.zeros(0, n, dtype=torch.int32, device=dev),
+                                          means2d=torch.zeros(0, n, 2, device=dev), width=plan.W, height=plan.H,
+                                          n_cameras=0)
+            outputs.means2d.grad = torch.zeros(0, n, 2, device=dev)
+        self.insertion_3dgs.step(self.splats, self.splat_optimizers, outputs, None, None,
+                                 window_cameras=plan.Cw, reduce_sum=shard.all_reduce_sum if shard.world_size > 1 else None)
+
+    def _prune(self, outputs: Optional[RasterizationOutput], visibility_ok: bool):
+        """size / opacity (/ conditioning) pruning, backend.py:364-392 and :409-437.  Multi-GPU: the per-Gaussian
+        statistics over the window's cameras are reduced over ranks first (max of the screen radii, sum of the
+        ill-conditioned view counts), so that every replica removes the same Gaussians."""
         conf = self.conf
+        shard = self.ba.shard
         n = self.splats.means.shape[0]
-        radii = outputs.radii[:, :n]
-        remove = torch.zeros(n, dtype=torch.bool, device=self.splats.means.device)
-        if conf.enable_visibility_pruning and visibility_ok and outputs.n_touched is not None:
+        dev = self.splats.means.device
+        if outputs is not None and outputs.radii.shape[0] > 0:
+            radii = outputs.radii[:, :n]
+            max_radii = torch.max(radii, dim=0).values
+        else:
+            radii = torch.zeros(0, n, dtype=torch.int32, device=dev)
+            max_radii = torch.zeros(n, dtype=torch.int32, device=dev)
+        shard.all_reduce_max(max_radii)
+        remove = torch.zeros(n, dtype=torch.bool, device=dev)
+        if conf.enable_visibility_pruning and visibility_ok:
             k = conf.optim_window_last_n_keyframes
-            remove |= self.pruning_conditioning.step(self.splats, self.splat_optimizers, radii[:k],
-                                                     outputs.n_touched[:k, :n])
-        remove |= self.pruning_size.step(self.splats, self.splat_optimizers, torch.max(radii, dim=0).values)
+            nt = None if outputs is None else outputs.n_touched
+            if nt is not None and radii.shape[0] > 0:
+                bad_views = ((radii[:k] > 0) & (nt[:k, :n] == 0)).sum(dim=0).to(torch.int32)
+            else:
+                bad_views = torch.zeros(n, dtype=torch.int32, device=dev)
+            shard.all_reduce_sum(bad_views)
+            remove |= bad_views > self.pruning_conditioning.max_frames_thing      # = PruneIllConditionedGaussians.step
+        remove |= self.pruning_size.step(self.splats, self.splat_optimizers, max_radii)
         remove |= self.pruning_opacity.step(self.splats, self.splat_optimizers)
         if prune_using_mask(self.splats, self.splat_optimizers, ~remove) > 0:
             self.ba.map_changed()
@@ -199,13 +251,14 @@ class Backend:
         if (not self.splats.means.is_cuda or not learn or 9 * len(learn) > 80
                 or os.environ.get("GSX_POSE_REFINER", "device") == "host"):
             return optimize_poses_lbfgs(self.splats, window, self.conf)
-        key = (tuple(id(x) for x in window), int(self.splats.means.shape[0]), self.splats.means.data_ptr())
-        cached = getattr(self, "_pose_refiner", None)
-        if cached is None or cached[0] != key:
+        # one refiner (buffers + captured closure) per window SHAPE over the current map tensors: the window's poses,
+        # images and exposure are copied into its slots, so sliding the window does not re-capture; a re-packed map does
+        refiner = getattr(self, "_pose_refiner", None)
+        if refiner is None or not refiner.matches(self.splats, window):
             from .mapping import GraphedPoseRefiner
-            cached = (key, GraphedPoseRefiner(self.splats, window, self.conf))
-            self._pose_refiner = cached
-        return cached[1].run()[0]
+            refiner = GraphedPoseRefiner(self.splats, window, self.conf)
+            self._pose_refiner = refiner
+        return refiner.run(window)[0]
 
     # ---- messages out (backend.py:508-552) ---------------------------------------------------------------------------
     def sync(self):

@@ -30,6 +30,7 @@ SOURCES = {
     "track_opt.hip": [],
     "window_opt.hip": [],
     "maintain.hip": [],
+    "runtime.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result", "-DNDEBUG"]

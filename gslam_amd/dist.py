@@ -4,10 +4,11 @@
 
 Partitioning: the map (60 B/Gaussian params + 60 B grads + 120 B Adam state) is replicated; rank r renders the
 keyframes {c : c mod G == r} of the BA window.  Per iteration there is exactly ONE data-path collective: an
-all-reduce(sum) of a single contiguous fp32 bucket [N*15] that the six parameter ``.grad`` tensors are views of
-(means3+quats4+scales3+opac1+colors3+log_unc1), plus one small int32 [N] all-reduce of per-Gaussian visible-camera
-counts (isotropic term / opacity decay, backend.py:287,357).  xGMI is point-to-point (7 links x ~153 GB/s per GPU):
-one large bucket lets RCCL drive all links; many small per-tensor all-reduces would be latency-bound.
+all-reduce(sum) of a single contiguous fp32 bucket (``StepBucket``: map gradients, visibility counts, pose gradients,
+loss terms).  xGMI is point-to-point (7 links x ~153 GB/s per GPU): one large bucket lets RCCL drive all links; many
+small per-tensor all-reduces would be latency-bound.  Between iterations: all-reduce(max) of the screen radii before
+size pruning (backend.py:364) and all-reduce(sum) of the densification statistic (insertion.py:298-308), both
+``KeyframeShard`` helpers called by gslam_amd.backend.
 """
 from __future__ import annotations
 
@@ -69,36 +70,55 @@ class KeyframeShard:
                 td.broadcast(t, src=src, group=self.group)
 
 
-class GradBucket:
-    """One flat fp32 buffer that the six splat ``.grad`` tensors are views of: autograd accumulates straight into
-    it, a single all-reduce sums it across ranks and the fused Adam reads the views - no cat/split copies."""
+class StepBucket:
+    """Everything one BA iteration sums over ranks, in ONE flat fp32 buffer:
 
-    def __init__(self, splats, group=None):
+        [ N*15 map gradients | N visible-camera counts | Cw*3 pose dt gradients | Cw*6 pose dR gradients | 2 loss values ]
+
+    (means3 + quats4 + scales3 + opac1 + colors3 + log_unc1 = 15 columns; Cw = cameras of the whole BA window).  The
+    kernels of a launch plan (gslam_amd.plan.MappingStep) write their outputs straight into the views below - no
+    cat / split copies - and ``reduce()`` is the single all-reduce(sum) of the iteration: it carries the map gradients,
+    the per-Gaussian visibility counts (isotropic term backend.py:287, opacity decay :357; exact in fp32: counts <= C),
+    the pose gradients (each rank fills the rows of the cameras it rendered, the rest are zero) and the loss terms
+    (each rank's share of the window means), so every rank can apply the identical update to the map and to ALL window
+    poses and take the identical early-stop decision without a second collective or a pose broadcast."""
+
+    def __init__(self, shapes: Sequence[Sequence[int]], n_window_cams: int, device, group=None):
         self.group = group
-        self.splats = splats
-        self._alloc()
-
-    def _alloc(self):
-        params = [getattr(self.splats, n) for n in GRAD_PARAMS]
-        self._shapes = [tuple(p.shape) for p in params]
-        total = sum(p.numel() for p in params)
-        n = params[0].shape[0]
-        # [N*15] gradients + [N] per-Gaussian visible-camera counts riding as a 16th fp32 column (exact: counts <= C)
-        self.flat = torch.zeros(total + n, dtype=torch.float32, device=params[0].device)
+        shapes = [tuple(int(x) for x in s) for s in shapes]
+        self.N = n = shapes[0][0]
+        self.Cw = cw = int(n_window_cams)
+        numels = [int(torch.Size(s).numel()) for s in shapes]
+        n_map = sum(numels)
+        self.flat = torch.zeros(n_map + n + cw * 9 + 2, dtype=torch.float32, device=device)
         self.views, off = [], 0
-        for p in params:
-            self.views.append(self.flat[off:off + p.numel()].view(p.shape))
-            off += p.numel()
-        self.counts = self.flat[off:off + n]
+        for s, k in zip(shapes, numels):
+            self.views.append(self.flat[off:off + k].view(s))
+            off += k
+        self.map_part = self.flat[:n_map]
+        self.counts = self.flat[off:off + n]; off += n
+        self.tail = self.flat[off:]                       # pose rows + loss slots: re-zeroed every iteration when sharded
+        self.g_dt = self.flat[off:off + cw * 3].view(cw, 3); off += cw * 3
+        self.g_dR = self.flat[off:off + cw * 6].view(cw, 6); off += cw * 6
+        self.out2 = self.flat[off:off + 2]
+        self.vis_i32 = torch.zeros(n, dtype=torch.int32, device=device)   # window-wide counts after the reduction
 
-    def attach_zeroed(self):
-        params = [getattr(self.splats, n) for n in GRAD_PARAMS]
-        if [tuple(p.shape) for p in params] != self._shapes:
-            self._alloc()                                   # map was densified / pruned
-        self.flat.zero_()
-        for p, v in zip(params, self.views):
-            p.grad = v
+    @property
+    def world_size(self) -> int:
+        return td.get_world_size(self.group) if (td.is_available() and td.is_initialized()) else 1
 
-    def all_reduce(self):
-        if td.is_available() and td.is_initialized() and td.get_world_size(self.group) > 1:
-            td.all_reduce(self.flat, op=td.ReduceOp.SUM, group=self.group)
+    @torch.no_grad()
+    def reduce(self, local_vis: torch.Tensor | None):
+        """local_vis: this rank's int32 [N] visible-camera counts, or None when it rendered no camera of the window (a
+        window shorter than the world size): it then contributes zeros and still joins the collective"""
+        if self.world_size == 1:
+            if local_vis is not None:
+                self.vis_i32.copy_(local_vis)
+            return
+        if local_vis is not None:
+            self.counts.copy_(local_vis)
+        else:
+            self.map_part.zero_()
+            self.counts.zero_()
+        td.all_reduce(self.flat, op=td.ReduceOp.SUM, group=self.group)
+        self.vis_i32.copy_(self.counts)

@@ -171,12 +171,22 @@ class InsertUsingImagePlaneGradients(InsertionStrategy):
 
     @torch.no_grad()
     def step(self, splats: GaussianSplattingData, optimizers, rasterization_output: RasterizationOutput, frame: Frame,
-             N: int):
+             N: int, window_cameras: Optional[int] = None, reduce_sum=None):
+        """window_cameras / reduce_sum (keyframe-sharded BA): ``rasterization_output`` then holds only this rank's cameras of
+        a window of ``window_cameras``; the per-Gaussian statistic - a mean over the window's cameras - is summed over
+        ranks with ``reduce_sum`` (an all-reduce) so that every replica densifies the same Gaussians"""
+        n_cams = rasterization_output.n_cameras if window_cameras is None else int(window_cameras)
         grads = rasterization_output.means2d.grad.clone()
         # normalize grads by image size (insertion.py:300-306)
-        grads[..., 0] *= rasterization_output.width / 2.0 * rasterization_output.n_cameras
-        grads[..., 1] *= rasterization_output.height / 2.0 * rasterization_output.n_cameras
-        grads = grads.norm(dim=-1).mean(dim=0)
+        grads[..., 0] *= rasterization_output.width / 2.0 * n_cams
+        grads[..., 1] *= rasterization_output.height / 2.0 * n_cams
+        if reduce_sum is None and window_cameras is None:
+            grads = grads.norm(dim=-1).mean(dim=0)
+        else:
+            grads = grads.norm(dim=-1).sum(dim=0)
+            if reduce_sum is not None:
+                reduce_sum(grads)
+            grads = grads / n_cams
         high = grads > self.grow_grad2d
         is_small = torch.exp(splats.scales.detach()).max(dim=-1).values <= self.grow_scale3d
         to_duplicate = high & is_small

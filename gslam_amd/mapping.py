@@ -2,8 +2,8 @@
 ``Backend.optimize_map`` (gslam/backend.py:249-407, 554-602), without the process / viewer / rerun shell.
 
 Multi-GPU: the window's keyframes are sharded over ranks (gslam_amd.dist.KeyframeShard); every rank holds a replica
-of the map, renders its own cameras and the per-Gaussian gradients are summed with one RCCL all-reduce of a single
-[N,15] bucket.  With world_size == 1 the code path is identical minus the collective.
+of the map, renders its own cameras and everything that is summed over cameras travels in one RCCL all-reduce of a
+single bucket (gslam_amd.dist.StepBucket) - on the launch-plan path (gslam_amd.plan.MappingStep).
 """
 from __future__ import annotations
 
@@ -113,12 +113,19 @@ class MapOptimizers:
 
 
 class BundleAdjuster:
-    """One object per process/GPU.  ``step(window)`` is one iteration of the loop at backend.py:260-359."""
+    """One object per process/GPU.  Two ways to run one iteration of the loop at backend.py:260-359 over a window:
+
+    * ``step(window)`` - the reference-shaped path: ``splats(cameras, poses)`` through the autograd operators of this
+      package, the fused loss, ``backward()``, fused Adam.  Single GPU; kept as the independent implementation the
+      launch plan is tested against.
+    * ``plan(window).step()`` - the production path: the same launches as a plan over persistent buffers replayed from a
+      HIP graph (gslam_amd.plan.MappingStep), sharded over ranks when torch.distributed is initialised."""
 
     def __init__(self, splats: GaussianSplattingData, conf: Optional[MapConfig] = None, fused_loss: bool = True,
                  capturable: bool = False, need_n_touched: Optional[bool] = None):
         """need_n_touched: keep the rasteriser's touched-pixel counts in ``last_outputs`` (read by visibility pruning
-        only, backend.py:370-375); default = the configuration's ``enable_visibility_pruning`` (off, backend.py:94)."""
+        only, backend.py:370-375); default = the configuration's ``enable_visibility_pruning`` (off, backend.py:94).
+        capturable: device-side Adam step counters (needed by ``plan()``)."""
         self.splats = splats
         self.conf = conf or MapConfig()
         self.need_n_touched = bool(getattr(self.conf, "enable_visibility_pruning", False)) \
@@ -126,47 +133,55 @@ class BundleAdjuster:
         self.fused_loss = fused_loss
         self.optimizers = MapOptimizers(splats, self.conf, capturable=capturable)
         self.shard = gdist.KeyframeShard()
-        self.bucket = gdist.GradBucket(splats) if self.shard.world_size > 1 else None
         self.total_step = 0
         self.last_outputs: Optional[RasterizationOutput] = None
+        self._plans: dict = {}
 
     def map_changed(self):
-        """call after gslam_amd.pruning / gslam_amd.insertion re-packed the map (new parameter tensors, new N): the
-        multi-GPU gradient bucket is rebuilt for the new size; captured graphs of the old map must be discarded."""
-        if self.bucket is not None:
-            self.bucket = gdist.GradBucket(self.splats)
+        """call after gslam_amd.pruning / gslam_amd.insertion re-packed the map (new parameter tensors, new N): launch
+        plans and their captured graphs describe the old tensors and are dropped"""
+        self._plans.clear()
         self.last_outputs = None
 
+    def plan(self, window: List[Frame], regularize: bool = True, decay_opacity: bool = True):
+        """the launch plan of one BA iteration over ``window`` (cached while the window's frames and the map's tensors stay
+        the same objects); needs capturable=True"""
+        from .plan import MappingStep
+        key = (tuple(id(f) for f in window), bool(regularize), bool(decay_opacity))
+        p = self._plans.get(key)
+        if p is None or not p.matches(self.splats, window):
+            if len(self._plans) >= 4:
+                self._plans.clear()
+            p = MappingStep(self.splats, self.optimizers, window, self.conf, regularize=regularize, shard=self.shard,
+                            need_n_touched=self.need_n_touched, decay_opacity=decay_opacity)
+            self._plans[key] = p
+        return p
+
     def step(self, window: List[Frame], regularize: bool = True, decay_opacity: bool = True):
-        """window = ALL keyframes of the BA window (every rank passes the same list); this rank renders its shard.
-        = render_backward() -> reduce() -> update(); the three phases are separately callable so that the two
-        compute phases can be replayed from HIP graphs around the one eager collective."""
+        """reference-shaped iteration (autograd operators), single GPU"""
         total, photometric = self.render_backward(window, regularize)
-        self.reduce()
         self.update(decay_opacity)
         return total, photometric
 
     def render_backward(self, window: List[Frame], regularize: bool = True):
+        if self.shard.world_size > 1:
+            raise RuntimeError("the autograd-shaped step is single-GPU; sharded BA runs on BundleAdjuster.plan()")
         conf = self.conf
         self.total_step += 1
-        mine = self.shard.select(window)
-        multi = self.shard.world_size > 1
-        for f in mine:
+        for f in window:
             self.optimizers.add_pose(f.pose)
         self.optimizers.zero_grad()
-        if self.bucket is not None:
-            self.bucket.attach_zeroed()
-        cameras = [f.camera for f in mine]
-        poses = [f.pose for f in mine]
+        cameras = [f.camera for f in window]
+        poses = [f.pose for f in window]
         # the keyframes' images do not change between iterations: stack them once per window (the reference, and the
         # first version here, re-stacked 29 MB per iteration at 8 keyframes)
-        key = tuple((f.img.data_ptr(), f.img._version) for f in mine)
+        key = tuple((f.img.data_ptr(), f.img._version) for f in window)
         cached = getattr(self, "_gt_cache", None)
         if cached is None or cached[0] != key:
-            cached = (key, create_batch(mine, lambda f: f.img))
+            cached = (key, create_batch(window, lambda f: f.img))
             self._gt_cache = cached
         gt_imgs = cached[1]
-        exposure = create_batch(mine, lambda f: f.exposure_params)
+        exposure = create_batch(window, lambda f: f.exposure_params)
         outputs = self.splats(cameras, poses, render_depth=True, need_n_touched=self.need_n_touched)
         vis_count = outputs._vis_count                                  # = (radii > 0).sum(0), from K1
         # backend.py:326 means2d.retain_grad(): the rasteriser's backward hands the same values over as a view of its
@@ -175,52 +190,33 @@ class BundleAdjuster:
         if self.fused_loss:
             # value and analytic gradient in one pass (csrc/loss.hip); the backward is seeded at the render tensor and
             # runs as soon as that gradient exists, so that the isotropic term can be added into scales.grad in place.
-            # Multi-GPU: the isotropic term needs the window-wide visibility, so it moves behind the all-reduce.
             out2, v_render, v_exposure, v_scales = mapping_loss_and_grads(
                 outputs, gt_imgs, exposure, self.splats.scales, ssim_weight=conf.ssim_weight,
-                iso_weight=0.0 if multi else conf.isotropic_regularization_weight,
+                iso_weight=conf.isotropic_regularization_weight,
                 tv_weight=conf.depth_regularization_weight if regularize else 0.0, active_gs=conf.active_gs,
-                shard=len(mine) / float(len(window)), vis_count=vis_count,
+                shard=1.0, vis_count=vis_count,
                 backward_fn=lambda v: torch.autograd.backward([outputs._render], [v]),
                 iso_grad_fn=lambda: self.splats.scales.grad)
             total, photometric = out2[0], out2[1]
             if v_scales is not None:
                 self.splats.scales.grad.add_(v_scales)
-            for i, f in enumerate(mine):
+            for i, f in enumerate(window):
                 if f.exposure_params.requires_grad:
                     f.exposure_params.grad = v_exposure[i] if f.exposure_params.grad is None \
                         else f.exposure_params.grad + v_exposure[i]
         else:
-            assert not multi, "the torch-formulated loss is the single-GPU reference path"
             total, photometric = mapping_loss(self.splats, outputs, gt_imgs, exposure, conf, regularize,
                                               c_total=len(window), visible_gaussians=vis_count > 0)
             total.backward()
-        if self.bucket is not None:
-            self.bucket.counts.copy_(vis_count)                         # int32 -> fp32 column of the bucket
         self._vis_count = vis_count
         self.last_outputs = outputs
         return total.detach(), photometric.detach()
 
-    def reduce(self):
-        """the ONE data-path collective of an iteration: sum of the [N*15 + N] bucket over ranks (RCCL / xGMI)"""
-        if self.bucket is not None:
-            self.bucket.all_reduce()
-
     def update(self, decay_opacity: bool = True):
         conf = self.conf
         vis_count = self._vis_count
-        if self.bucket is not None:
-            vis_count = self.bucket.counts.to(torch.int32)              # window-wide visible-camera counts
-            w = conf.isotropic_regularization_weight
-            if w != 0.0:                                                # identical on every rank (replicated map)
-                sc = self.splats.scales
-                N = sc.shape[0]
-                from .ops import workspace
-                ws = workspace(lib.gsx_isotropic_workspace_bytes(N), sc.device, "iso")
-                check(lib.gsx_isotropic_loss_acc(ptr(sc.data), ptr(vis_count), N, w, None, ptr(sc.grad), ptr(ws),
-                                                 ws.numel(), stream_ptr(sc.device)), "gsx_isotropic_loss_acc")
         # backend.py:356-359: opacities of Gaussians seen by more than one camera decay after the update; the masked
-        # multiply rides in the Adam launch when that launch is device-stepped (graph-capturable)
+        # multiply rides in the Adam launch when that launch is device-stepped
         op = self.splats.opacities
         decay = (op, vis_count.contiguous(), 1, conf.opacity_decay) if (decay_opacity and op.grad is not None) else None
         done = self.optimizers.step(decay) and decay is not None
@@ -231,22 +227,18 @@ class BundleAdjuster:
 
     def optimize_map(self, window: List[Frame], n_iters: Optional[int] = None, regularize: bool = True,
                      early_stop: bool = True):
-        """backend.py:249-362 without pruning/insertion."""
+        """backend.py:249-362 without pruning / insertion, on the autograd-shaped step."""
         n_iters = self.conf.num_iters_mapping if n_iters is None else n_iters
         stopper = StopOnPlateau(3, 0.012)
         last = None
         for _ in range(n_iters):
             total, photometric = self.step(window, regularize)
             last = (total, photometric)
-            if early_stop:
-                pm = photometric
-                if self.shard.world_size > 1:
-                    pm = self.shard.all_reduce_sum(pm * (len(self.shard.select(window)) / len(window)))
-                if stopper.stop(pm.item()):
-                    break
+            if early_stop and stopper.stop(photometric.item()):
+                break
         outputs = self.last_outputs
         if outputs is not None:
-            for f, d in zip(self.shard.select(window), outputs.depthmaps):
+            for f, d in zip(window, outputs.depthmaps):
                 f.est_depths = d.detach().clone()
         return last
 
@@ -302,170 +294,106 @@ class GraphedPoseRefiner:
     """`Backend.optimize_poses_lbfgs` (gslam/backend.py:447-506) with the optimiser on the device:
     torch.optim.LBFGS(history_size=10, strong_wolfe, tolerance_change=1e-7) over the poses of the window (the pose of
     frame 0 stays fixed, :459-462) restated as the state machine of csrc/track_opt.h (sized for 80 parameters in
-    csrc/window_opt.hip) and advanced by one single-wave launch at the end of the captured closure.  One refinement is
-    ``max_eval + 1`` replays of one HIP graph and ONE read-back, instead of a `.item()` per closure (backend.py:501)
-    and ~40 eager launches each.  The closure is the host version's: C <= 8 cameras rendered against the frozen map,
-    photometric term only, pose-only backward.  Build one per window composition (the graph holds the addresses of the
-    window's pose parameters and images); ``run()`` may be called repeatedly while the same keyframes are in it."""
+    csrc/window_opt.hip) and advanced by one single-wave launch at the end of the closure.  The closure is a launch plan
+    (gslam_amd.plan.WindowClosure: C <= 8 cameras against the frozen map, photometric term only, pose-only backward)
+    over the plan's OWN pose / exposure / image slots, recorded into a HIP graph on the plan's own stream: one refinement
+    is ``max_eval + 1`` replays and ONE read-back instead of a `.item()` per closure (backend.py:501).  The window's
+    poses are copied into the slots before and out of them after a run, so the same refiner serves every window of the
+    same shape (number of cameras, which of them are learnable, image size) over the same map tensors."""
 
     def __init__(self, splats: GaussianSplattingData, window: List[Frame], conf: Optional[MapConfig] = None,
                  max_eval: int = 25):
-        from .rasterization import validate
-        self.splats, self.window, self.conf, self.max_eval = splats, list(window), conf or MapConfig(), int(max_eval)
-        self.params = [p for x in self.window if x.index != 0 for p in x.pose.parameters() if p.requires_grad]
-        self.n = sum(p.numel() for p in self.params)
-        if self.n == 0:
-            raise ValueError("no learnable pose in the window")
-        if self.n > 80 or len(self.params) > 16:
-            raise ValueError("window too large for the device optimiser (80 parameters in 16 tensors)")
-        dev = splats.means.device
-        self.cameras = [x.camera for x in self.window]
-        self.poses = [x.pose for x in self.window]
-        self.gt_imgs = create_batch(self.window, lambda x: x.img)
-        self.exposure = create_batch(self.window, lambda x: x.exposure_params).detach().clone()
-        self._state = torch.zeros(int(lib.gsx_window_opt_state_bytes()), dtype=torch.uint8, device=dev)
-        self._report = torch.zeros(8, dtype=torch.float32, device=dev)
-        self._validate = validate
-        self._sig = (int(splats.means.shape[0]), len(self.window), int(self.cameras[0].width), int(self.cameras[0].height))
-        self.graph = None
-        self.loss = None
+        from .plan import WindowClosure
+        self.splats, self.conf, self.max_eval = splats, conf or MapConfig(), int(max_eval)
+        self.window = list(window)
+        learnable = self.learnable_flags(self.window)
+        self.plan = WindowClosure(splats, [x.camera for x in self.window], learnable, active_gs=self.conf.active_gs)
+        self.n = self.plan.n_params
+        self.params = [p for x, l in zip(self.window, learnable) if l for p in x.pose.parameters()]
+        self.loss = self.plan.out2[0:1]
 
-    def _closure(self, advance: bool):
-        from .losses import loss_and_grads
-        for x in self.window:
-            for p in x.pose.parameters():
-                p.grad = None
-        out = self.splats(self.cameras, self.poses, render_depth=False, need_n_touched=False)
-        out2, v_render, _v_exp, _ = loss_and_grads(out._render, out.alphas, self.gt_imgs, self.exposure, None, None, -1,
-                                                   -1 if out._betas_index is None else out._betas_index, 1.0, 0.0, 0.0,
-                                                   0.0, 0 if self.conf.active_gs else 1)
-        torch.autograd.backward([out._render], [v_render])
-        loss = out2[0:1]
-        if advance:
-            import ctypes as C
-            n = len(self.params)
-            check(lib.gsx_window_opt_advance(
-                self._state.data_ptr(), n, (C.c_void_p * n)(*[p.data_ptr() for p in self.params]),
-                (C.c_void_p * n)(*[p.grad.data_ptr() for p in self.params]),
-                (C.c_int * n)(*[p.numel() for p in self.params]), loss.data_ptr(), stream_ptr(loss.device)),
-                "gsx_window_opt_advance")
-        return loss
+    @staticmethod
+    def learnable_flags(window: List[Frame]):
+        return [bool(x.index != 0 and getattr(x.pose, "is_learnable", True)
+                     and all(p.requires_grad for p in x.pose.parameters())) for x in window]
 
-    def _frozen_map(self):
-        import contextlib
+    def shape_key(self):
+        c = self.plan
+        return (c.C, tuple(c.slots.learnable), c.r.W, c.r.H, c.r.N)
 
-        @contextlib.contextmanager
-        def cm():
-            flags = [p.requires_grad for p in self.splats.parameters()]
-            for p in self.splats.parameters():
-                p.requires_grad_(False)                       # only the poses move: pose-only projection backward
-            try:
-                yield
-            finally:
-                for p, r in zip(self.splats.parameters(), flags):
-                    p.requires_grad_(r)
-        return cm()
+    def matches(self, splats, window: List[Frame]) -> bool:
+        """this refiner (and its captured graph) can serve ``window`` over ``splats`` as it is"""
+        c = self.plan
+        return (c.r.matches(splats) and len(window) == c.C and self.learnable_flags(window) == c.slots.learnable
+                and all(int(x.camera.width) == c.r.W and int(x.camera.height) == c.r.H for x in window))
+
+    @property
+    def graph(self):
+        return self.plan.graph if self.plan.graph.captured else None
 
     def capture(self):
         from ._sync import capture_lock
-        with capture_lock, self._frozen_map():
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _attempt in range(4):
-                    for _ in range(2):
-                        self._closure(False)
-                    if self._validate(signature=self._sig):
-                        break
-                else:
-                    raise RuntimeError("intersection capacity keeps changing during warm-up")
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
-                self.loss = self._closure(True)
+        with capture_lock:
+            self.plan.prepare()
 
-    def run_async(self):
-        """one refinement without any read-back (the caller polls gslam_amd.rasterization.validate later): the
-        graph must have been captured by an earlier run()"""
-        assert self.graph is not None
-        dev = self._state.device
-        check(lib.gsx_window_opt_init(self._state.data_ptr(), self.n, 0, 0.0, 1.0, 10, 20, self.max_eval, 1e-7, 1e-7,
-                                      stream_ptr(dev)), "gsx_window_opt_init")
-        for _ in range(self.max_eval + 1):
-            self.graph.replay()
+    def _issue(self):
+        self.plan.init_optimizer(self.max_eval)
+        self.plan.graph.launch(count=self.max_eval + 1)
 
-    def run(self):
-        """-> (last closure loss, number of closure evaluations), poses updated in place"""
-        with torch.no_grad():
-            self.exposure.copy_(create_batch(self.window, lambda x: x.exposure_params).detach())
-        for attempt in range(2):
-            saved = [p.detach().clone() for p in self.params]
-            if self.graph is None:
+    def run_async(self, window: Optional[List[Frame]] = None):
+        """one refinement without any read-back (the caller polls ``capacity_ok()`` later): the graph must have been
+        captured by an earlier run()"""
+        window = self.window if window is None else list(window)
+        assert self.plan.graph.captured
+        self.plan.load(window)
+        self._issue()
+        self.plan.store(window)
+
+    def capacity_ok(self) -> bool:
+        return self.plan.r.check_capacity()
+
+    def run(self, window: Optional[List[Frame]] = None):
+        """-> (last closure loss, number of closure evaluations); the poses of ``window`` (default: the window given at
+        construction) are updated in place"""
+        window = self.window if window is None else list(window)
+        for _attempt in range(3):
+            self.plan.load(window)
+            if not self.plan.graph.captured or self.plan.r.stale:
                 self.capture()
-                with torch.no_grad():
-                    for p, s0 in zip(self.params, saved):
-                        p.copy_(s0)                           # the warm-up closures did not move them, the capture neither
-            dev = self._state.device
-            # torch.optim.LBFGS defaults of the reference call: lr 1, max_iter 20, max_eval 25, tolerance_grad 1e-7
-            check(lib.gsx_window_opt_init(self._state.data_ptr(), self.n, 0, 0.0, 1.0, 10, 20, self.max_eval, 1e-7, 1e-7,
-                                          stream_ptr(dev)), "gsx_window_opt_init")
-            for _ in range(self.max_eval + 1):
-                self.graph.replay()
-            check(lib.gsx_window_opt_report(self._state.data_ptr(), self._report.data_ptr(), stream_ptr(dev)),
-                  "gsx_window_opt_report")
-            rep = self._report.cpu()
-            if self._validate(signature=self._sig):
+            self._issue()
+            rep = self.plan.read_report().cpu()
+            if self.plan.r.check_capacity():
+                self.plan.store(window)
                 return float(rep[4]), int(rep[1])
-            with torch.no_grad():                             # tile lists outgrew the captured capacity: redo
-                for p, s0 in zip(self.params, saved):
-                    p.copy_(s0)
-            self.graph = None
+            # the tile lists outgrew the captured capacity: buffers were grown, re-capture and redo from the saved poses
         raise RuntimeError("intersection buffers kept overflowing")
 
 
 class GraphedBundleAdjuster:
-    """A BA iteration over a FIXED window captured into HIP graphs and replayed: the ~45 launches of a step (pose
-    chain, K1, binning, sort, K8, SSIM, loss, K9, K2, Adam, decay) cost one graph launch on the host.  Multi-GPU: two
-    graphs (render+loss+backward | isotropic+Adam+decay) around the one eager all-reduce.  Needs a BundleAdjuster
-    built with capturable=True; the window's tensors (images, poses, exposure) are updated in place between replays.
-    ``validate()`` (gslam_amd.rasterization) must be polled by the caller: the intersection capacity is baked in."""
+    """A BA iteration over a FIXED window replayed from HIP graphs: thin facade over ``BundleAdjuster.plan(window)``
+    (gslam_amd.plan.MappingStep) - pose chain, K1, binning, sort, K8, SSIM, loss, K9, K2, Adam, decay are one graph launch
+    on the host.  Multi-GPU: two graphs (render + loss + backward | isotropic + Adam + decay) around the one eager
+    all-reduce.  Needs a BundleAdjuster built with capturable=True; the window's poses are updated in place, its images
+    and exposure parameters are constants of the plan (``plan.refresh_inputs()`` after changing them).
+    ``warmup`` plan iterations run eagerly (real updates) before the capture; ``capacity_ok()`` must be polled by the
+    caller now and then: the tile-list capacity is baked into the graph."""
 
-    def __init__(self, ba: BundleAdjuster, window: List[Frame], warmup: int = 3, regularize: bool = True):
+    def __init__(self, ba: BundleAdjuster, window: List[Frame], warmup: int = 0, regularize: bool = True,
+                 decay_opacity: bool = True):
         assert ba.optimizers.capturable, "build the BundleAdjuster with capturable=True"
-        from .rasterization import validate
         self.ba, self.window = ba, window
-        self.multi = ba.shard.world_size > 1
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(warmup, 2)):
-                ba.step(window, regularize)
-            if not validate():                      # capacity grew: one more eager pass with the final capacity
-                ba.step(window, regularize)
-                assert validate()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        # warm-up and capture share one side stream (autograd pins AccumulateGrad nodes to the stream of first use)
-        self.graph = torch.cuda.CUDAGraph()
-        self.graph2 = None
-        # thread_local: the RCCL watchdog thread may query events while this thread captures
-        mode = "thread_local" if self.multi else "global"
-        if not self.multi:
-            with torch.cuda.graph(self.graph, stream=side, capture_error_mode=mode):
-                self.total, self.photometric = ba.step(window, regularize)
-        else:
-            with torch.cuda.graph(self.graph, stream=side, capture_error_mode=mode):
-                self.total, self.photometric = ba.render_backward(window, regularize)
-            ba.reduce()
-            self.graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph2, pool=self.graph.pool(), stream=side, capture_error_mode=mode):
-                ba.update()
+        self.plan = ba.plan(window, regularize, decay_opacity)
+        self.multi = self.plan.world > 1
+        for _ in range(int(warmup)):
+            self.plan.step(graphed=False)
+            ba.total_step += 1
+        self.plan.prepare()
+        self.total, self.photometric = self.plan.out2[0], self.plan.out2[1]
 
     def step(self):
-        self.graph.replay()
-        if self.multi:
-            self.ba.reduce()
-            self.graph2.replay()
+        self.plan.step()
         self.ba.total_step += 1
         return self.total, self.photometric
+
+    def capacity_ok(self) -> bool:
+        return self.plan.capacity_ok()

@@ -25,15 +25,14 @@ PROJ_LOG_SCALES, PROJ_RENDER_DEPTH, PROJ_BETAS = 1, 2, 4
 # workspace cache: one growing byte buffer per (device, tag); reuse is safe because all work is stream ordered
 # ---------------------------------------------------------------------------------------------------------------
 _ws: dict = {}
-_ws_retired: list = []   # outgrown buffers stay alive: a captured HIP graph may have their addresses baked in
 
 
 def workspace(nbytes: int, device, tag: str = "default") -> Tensor:
+    """scratch of the eager operators (the launch plans of gslam_amd.plan own theirs): an outgrown buffer is simply
+    dropped - the caching allocator keeps it alive until the launches already queued on its stream have run"""
     key = (torch.device(device).index, tag, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
-        if buf is not None:
-            _ws_retired.append(buf)     # geometric growth keeps the retired total below ~4x the live size
         buf = torch.empty(max(int(nbytes * 1.5), 1 << 16), dtype=torch.uint8, device=device)
         _ws[key] = buf
     return buf

@@ -120,3 +120,94 @@ def step_all(optimizers, decay=None):
             else:
                 check(lib.gsx_adam_multi(*common, int(step), None, stream_ptr(dev)), "gsx_adam_multi")
     return decayed
+
+
+class AdamPack:
+    """The update of ``step_all`` with every argument resolved ahead of time, for launch plans (gslam_amd.plan): the
+    gradient of each parameter is a caller-owned persistent buffer (``grad_of[id(p)]``) instead of ``p.grad``, the Adam
+    moments and the device step counters of the (capturable) optimisers are created up front, and ``launch(stream)``
+    issues one gsx_counters_add plus one multi-tensor launch per (betas, eps) class - nothing is allocated, so the call
+    can be recorded into a HIP graph.  ``decay`` as in step_all.  Parameters without an entry in ``grad_of`` are skipped."""
+
+    def __init__(self, optimizers, grad_of: dict, decay=None):
+        self._groups = []
+        counters: dict = {}
+        classes: dict = {}
+        for opt in optimizers:
+            if opt is None:
+                continue
+            if not opt.capturable:
+                raise RuntimeError("AdamPack needs FusedAdam(capturable=True): the step counters must live on the device")
+            for group in opt.param_groups:
+                live = [p for p in group["params"] if id(p) in grad_of]
+                if not live:
+                    continue
+                dev0 = live[0].device
+                if group["_shared"]:
+                    if opt._shared_step is None:
+                        opt._shared_step = torch.full((1,), group["_host_step"], dtype=torch.int64, device=dev0)
+                    step_dev = opt._shared_step
+                else:
+                    if group["_step_dev"] is None:
+                        group["_step_dev"] = torch.full((1,), group["_host_step"], dtype=torch.int64, device=dev0)
+                    step_dev = group["_step_dev"]
+                counters.setdefault(id(step_dev), step_dev)
+                self._groups.append(group)
+                for p in live:
+                    g = grad_of[id(p)]
+                    if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32):
+                        raise RuntimeError("FusedAdam needs contiguous float32 parameters on the GPU (no CPU fallback)")
+                    if not (g.is_contiguous() and g.dtype == torch.float32 and g.numel() == p.numel()):
+                        raise RuntimeError("AdamPack: gradient buffers must be contiguous float32 of the parameter's size")
+                    st = opt.state[p]
+                    if not st:
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    key = (tuple(group["betas"]), float(group["eps"]), p.device)
+                    classes.setdefault(key, []).append((p, g, st, float(group["lr"]), step_dev))
+        self._keep = (counters, classes)
+        ctrs = list(counters.values())
+        self._counter_calls = []
+        for i in range(0, len(ctrs), _MAX_COUNTERS):
+            part = ctrs[i:i + _MAX_COUNTERS]
+            self._counter_calls.append((len(part), (C.c_void_p * len(part))(*[t.data_ptr() for t in part])))
+        self._adam_calls = []
+        self.decay_applied = False
+        for (betas, eps, _dev), items in classes.items():
+            for i in range(0, len(items), _MAX):
+                chunk = items[i:i + _MAX]
+                n = len(chunk)
+                arr = lambda xs: (C.c_void_p * n)(*xs)
+                common = (n, arr([c_[0].data_ptr() for c_ in chunk]), arr([c_[1].data_ptr() for c_ in chunk]),
+                          arr([c_[2]["exp_avg"].data_ptr() for c_ in chunk]),
+                          arr([c_[2]["exp_avg_sq"].data_ptr() for c_ in chunk]),
+                          (C.c_int64 * n)(*[c_[0].numel() for c_ in chunk]),
+                          (C.c_float * n)(*[c_[3] for c_ in chunk]), float(betas[0]), float(betas[1]), float(eps))
+                steps = arr([c_[4].data_ptr() for c_ in chunk])
+                k = -1
+                if decay is not None:
+                    k = next((j for j, c_ in enumerate(chunk) if c_[0] is decay[0]), -1)
+                if k >= 0:
+                    mask = decay[1]
+                    if not (mask.dtype == torch.int32 and mask.is_contiguous() and mask.numel() == decay[0].numel()):
+                        raise RuntimeError("decay mask must be a contiguous int32 tensor with one entry per element")
+                    self._adam_calls.append((common, steps, (k, mask.data_ptr(), int(decay[2]), float(decay[3]))))
+                    self._keep = self._keep + (mask,)
+                    self.decay_applied = True
+                else:
+                    self._adam_calls.append((common, steps, None))
+
+    def launch(self, stream_ptr_: int):
+        for n, ptrs in self._counter_calls:
+            check(lib.gsx_counters_add(n, ptrs, 1, stream_ptr_), "gsx_counters_add")
+        for common, steps, dec in self._adam_calls:
+            if dec is not None:
+                check(lib.gsx_adam_multi_steps_decay(*common, steps, dec[0], dec[1], dec[2], dec[3], stream_ptr_),
+                      "gsx_adam_multi_steps_decay")
+            else:
+                check(lib.gsx_adam_multi_steps(*common, steps, stream_ptr_), "gsx_adam_multi_steps")
+
+    def note_steps(self, n: int = 1):
+        """host-side bookkeeping for ``n`` issued updates (the counters that matter are on the device)"""
+        for g in self._groups:
+            g["_host_step"] += n

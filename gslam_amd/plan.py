@@ -1,0 +1,851 @@
+"""Launch plans: the closures of the tracking and mapping optimisers as fixed chains of libgsx launches over persistent
+device buffers, recorded once into a HIP graph (csrc/runtime.hip) and replayed.
+
+The reference evaluates every closure from Python through autograd - ~60 kernel launches, a dozen allocations and a
+``loss.item()`` per evaluation (gslam/frontend.py:621-649, gslam/backend.py:260-359,465-504).  The autograd-shaped
+operators of this package (``gslam_amd.rasterization`` etc.) keep that interface for drop-in use; the optimisation loops
+themselves run on the plans below, which issue the SAME C-ABI calls in the same order with every buffer allocated up
+front:
+
+* no autograd graph, no AccumulateGrad nodes, no allocator traffic inside the closure - nothing that can tie a captured
+  graph to the stream a tensor was first used on, and nothing that is allocated or freed while a stream captures;
+* capture / instantiate / launch are plain HIP calls on a stream the plan owns (``HipGraph``);
+* sizes stay on the device: the tile-list capacity is a property of the plan, overflow is a sticky device status word
+  that ``check_capacity()`` reads once per frame / refinement / BA round, and a plan that overflowed grows its buffers and
+  is re-captured by its owner.
+
+``RenderPlan`` is one differentiable render of a fixed shape (N, C, W, H, CH); ``TrackClosure`` (tracking,
+frontend.py:604-662), ``WindowClosure`` (window pose refinement, backend.py:447-506) and ``MappingStep`` (one BA
+iteration, backend.py:260-359) put the loss, the pose algebra and the optimiser step around it."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from ._lib import check, lib
+from .ops import PROJ_BETAS, PROJ_LOG_SCALES, PROJ_RENDER_DEPTH
+
+TILE = 16
+_VIEW_PARTIALS = 8      # GSX_PROJ_VIEW_PARTIALS
+
+
+def _arr(ptrs: Sequence[Optional[int]]):
+    return (C.c_void_p * len(ptrs))(*ptrs)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class HipGraph:
+    """An instantiated hipGraph of one launch chain (csrc/runtime.hip)."""
+
+    def __init__(self):
+        self._exec = None
+        self.nodes = 0
+
+    @property
+    def captured(self) -> bool:
+        return self._exec is not None
+
+    def capture(self, stream: torch.cuda.Stream, enqueue, mode: int = 1):
+        """records ``enqueue(stream_ptr)`` - kernel launches only - from ``stream`` (never the legacy default stream)"""
+        st = stream.cuda_stream
+        if st == 0:
+            raise RuntimeError("the default stream cannot capture; pass a plan-owned stream")
+        self.destroy()
+        check(lib.gsx_graph_begin(st, mode), "gsx_graph_begin")
+        try:
+            enqueue(st)
+        except BaseException:
+            lib.gsx_graph_abort(st)
+            raise
+        ex, n = C.c_void_p(), C.c_int64(0)
+        check(lib.gsx_graph_end(st, C.byref(ex), C.byref(n)), "gsx_graph_end")
+        self._exec, self.nodes = ex, int(n.value)
+
+    def launch(self, stream_ptr: Optional[int] = None, count: int = 1):
+        if self._exec is None:
+            raise RuntimeError("graph not captured")
+        st = current_stream_ptr() if stream_ptr is None else stream_ptr
+        if count == 1:
+            check(lib.gsx_graph_launch(self._exec, st), "gsx_graph_launch")
+        else:
+            check(lib.gsx_graph_launch_n(self._exec, int(count), st), "gsx_graph_launch_n")
+
+    def replay(self):
+        """one launch on torch's current stream (the name torch.cuda.CUDAGraph uses)"""
+        self.launch()
+
+    def destroy(self):
+        if self._exec is not None:
+            ex, self._exec = self._exec, None
+            lib.gsx_graph_destroy(ex)
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def _map_tensors(splats):
+    ts = [splats.means, splats.quats, splats.scales, splats.opacities, splats.colors, splats.log_uncertainties]
+    out = []
+    for t in ts:
+        d = t.detach()
+        if not (d.is_cuda and d.dtype == torch.float32 and d.is_contiguous()):
+            raise RuntimeError("plans need contiguous float32 map tensors on the GPU (no CPU fallback)")
+        out.append(d)
+    return out
+
+
+class RenderPlan:
+    """One render of gslam ``rasterization()`` (gslam/rasterization.py:44-360 with the live argument set of
+    gslam/map.py:88-103) and its backward, as launches over buffers owned by the plan.
+
+    grads: 'none' (forward only), 'pose' (frozen map: geometry-only rasteriser backward when no depth channel is rendered,
+    pose-only projection backward that leaves its per-workgroup pose partials for a fused consumer), 'full' (gradients
+    of all six map arrays written to ``self.v_*`` / the tensors given in ``grad_out``, plus the pose partials)."""
+
+    GROW = 1.5
+
+    def __init__(self, splats, n_cams: int, width: int, height: int, *, render_depth: bool, grads: str = 'pose',
+                 Ks: Optional[torch.Tensor] = None, capacity: Optional[int] = None, need_n_touched: bool = False,
+                 visibility_min_T: float = 0.5, grad_out: Optional[Dict[str, torch.Tensor]] = None,
+                 near_plane: float = 0.01, far_plane: float = 1e10, eps2d: float = 0.3):
+        assert grads in ('none', 'pose', 'full')
+        self.splats = splats
+        self.map = _map_tensors(splats)
+        dev = self.map[0].device
+        self.dev = dev
+        self.N = N = int(self.map[0].shape[0])
+        self.C = Cn = int(n_cams)
+        self.W, self.H = int(width), int(height)
+        self.tile_w, self.tile_h = math.ceil(self.W / TILE), math.ceil(self.H / TILE)
+        self.T = Cn * self.tile_w * self.tile_h
+        self.grads = grads
+        self.near, self.far, self.eps2d, self.vis_min_T = float(near_plane), float(far_plane), float(eps2d), float(visibility_min_T)
+        self.flags = PROJ_LOG_SCALES | PROJ_BETAS | (PROJ_RENDER_DEPTH if render_depth else 0)
+        self.CH = 3 + (1 if render_depth else 0) + 1
+        self.depth_index = 3 if render_depth else -1
+        self.betas_index = self.CH - 1
+        # frozen map and no depth channel: only the xy / conic columns of the gradient records are consumed
+        self.geom_only = grads == 'pose' and not render_depth
+        f32, i32 = torch.float32, torch.int32
+        e = lambda *s, dtype=f32: torch.empty(*s, dtype=dtype, device=dev)
+        self.viewmats = torch.eye(4, device=dev).repeat(Cn, 1, 1).contiguous()
+        self.Ks = e(Cn, 3, 3)
+        if Ks is not None:
+            self.Ks.copy_(Ks.reshape(-1, 3, 3).expand(Cn, 3, 3))
+        self.radii, self.tiles = e(Cn, N, dtype=i32), e(Cn, N, dtype=i32)
+        self.means2d, self.depths, self.conics = e(Cn, N, 2), e(Cn, N), e(Cn, N, 3)
+        self.vis_count = e(N, dtype=i32)
+        self.rec = e(Cn, N, 12)
+        self.v_rec = e(Cn, N, 12) if grads != 'none' else None
+        self.offsets = torch.zeros(self.T + 1, dtype=i32, device=dev)
+        self.M_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.status = torch.zeros(1, dtype=i32, device=dev)
+        self.render, self.alphas = e(Cn, self.H, self.W, self.CH), e(Cn, self.H, self.W, 1)
+        self.last_ids = e(Cn, self.H, self.W, dtype=i32)
+        self.n_touched = torch.zeros(Cn, N, dtype=i32, device=dev) if need_n_touched else None
+        bg = torch.zeros(Cn, self.CH, device=dev)                 # [0,0,0] (+0 depth) + e^1 for beta (rasterization.py:236-255)
+        bg[:, self.betas_index] = math.e
+        self.backgrounds = bg
+        self.v_render = e(Cn, self.H, self.W, self.CH) if grads != 'none' else None
+        self.pose_ws = None
+        if grads != 'none':
+            self.pose_ws = torch.empty(int(lib.gsx_project_bwd_workspace_bytes(N, Cn)), dtype=torch.uint8, device=dev)
+            self.pose_blocks = int(lib.gsx_project_bwd_blocks(N))
+        self.v_map: Optional[List[torch.Tensor]] = None
+        if grads == 'full':
+            names = ('means', 'quats', 'scales', 'opacities', 'colors', 'log_uncertainties')
+            self.v_map = []
+            for name, t in zip(names, self.map):
+                g = None if grad_out is None else grad_out.get(name)
+                if g is None:
+                    g = torch.empty_like(t)
+                if not (g.is_contiguous() and g.shape == t.shape and g.dtype == f32 and g.device == dev):
+                    raise RuntimeError(f"grad_out[{name}] must be a contiguous float32 tensor shaped like the parameter")
+                self.v_map.append(g)
+        self.capacity = 0
+        self.flat = self.tile_order = self.isect_ws = None
+        self.last_M = 0
+        self.stale = False          # set when the buffers were re-allocated: graphs over the old ones must be re-captured
+        if capacity is not None:
+            self._alloc_lists(int(capacity))
+
+    # ---- tile-list capacity ------------------------------------------------------------------------------------------
+    def _alloc_lists(self, capacity: int):
+        self.capacity = cap = max(int(capacity), 4096)
+        dev = self.dev
+        self.flat = torch.empty(cap, dtype=torch.int32, device=dev)
+        # heaviest-first launch order pays off while the tile lists are short (see rasterization.rasterization)
+        self.tile_order = torch.empty(self.T, dtype=torch.int32, device=dev) if cap < 1000 * self.T else None
+        nbytes = int(lib.gsx_isect_bin_workspace_bytes_n(self.C, self.N, self.tile_w, self.tile_h, cap))
+        self.isect_ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        self.stale = True
+
+    def probe(self, stream_ptr: Optional[int] = None):
+        """sizes the tile lists from the current map and poses with ONE synchronous read of sum(tiles_per_gauss) (an upper
+        bound of M that the projection produces anyway); later drift is caught by check_capacity()"""
+        st = current_stream_ptr(self.dev) if stream_ptr is None else stream_ptr
+        self._project(st)
+        if stream_ptr is not None:
+            check(lib.gsx_stream_synchronize(st), "gsx_stream_synchronize")
+        m = int(self.tiles.sum().item())
+        want = int(m * self.GROW) + 4096
+        if want > self.capacity:
+            self._alloc_lists(want)
+        return m
+
+    def check_capacity(self) -> bool:
+        """after the launches have been issued: True iff no render since the last check overflowed the tile lists.  On
+        False the capacity has been grown (``stale`` is set): re-capture and redo.  One blocking read of 12 bytes."""
+        st, m = int(self.status.item()), int(self.M_dev.item())
+        self.last_M = m
+        if st & 1:
+            self.status.zero_()
+            self._alloc_lists(int(max(m, self.capacity) * self.GROW) + 4096)
+            return False
+        return True
+
+    def matches(self, splats) -> bool:
+        """the plan still describes this map: same tensors (addresses are baked into captured graphs), same N"""
+        ts = [splats.means, splats.quats, splats.scales, splats.opacities, splats.colors, splats.log_uncertainties]
+        return all(a.data_ptr() == b.data_ptr() and a.shape == b.shape for a, b in zip(ts, self.map))
+
+    def as_output(self):
+        """the plan's buffers seen as the reference's RasterizationOutput (views, no copies): what pruning, insertion and
+        the SYNC payload read after a render (gslam/rasterization.py:17-41).  ``means2d.grad`` is the view of the
+        gradient records that ``means2d.retain_grad()`` would have produced (backend.py:326)."""
+        from .rasterization import RasterizationOutput
+        means2d = self.means2d
+        if self.v_rec is not None:
+            means2d = self.means2d.view(self.C, self.N, 2)
+            means2d.grad = self.v_rec[..., 0:2]
+        out = RasterizationOutput(
+            rgbs=self.render[..., :3], alphas=self.alphas, tile_width=self.tile_w, tile_height=self.tile_h,
+            tiles_per_gauss=self.tiles, isect_offsets=self.offsets[:-1].view(self.C, self.tile_h, self.tile_w),
+            width=self.W, height=self.H, tile_size=TILE, n_cameras=self.C, camera_ids=None, gaussian_ids=None,
+            radii=self.radii, means2d=means2d, depths=self.depths, conics=self.conics, opacities=self.rec[..., 5],
+            n_touched=self.n_touched)
+        if self.depth_index >= 0:
+            out.depthmaps = self.render[..., self.depth_index]
+        out.betas = self.render[..., self.betas_index]
+        out._render, out._depth_index, out._betas_index, out._vis_count = self.render, (
+            self.depth_index if self.depth_index >= 0 else None), self.betas_index, self.vis_count
+        out._plan = self
+        return out
+
+    # ---- launches ----------------------------------------------------------------------------------------------------
+    def _project(self, st: int):
+        m = self.map
+        check(lib.gsx_project_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
+                                  self.H, self.eps2d, self.near, self.far, 0.0, self.flags, _p(self.radii),
+                                  _p(self.means2d), _p(self.depths), _p(self.conics), None, _p(self.tiles), self.tile_w,
+                                  self.tile_h, _p(m[3]), _p(m[4]), _p(m[5]), _p(self.rec), _p(self.vis_count),
+                                  _p(self.v_rec), st), "gsx_project_fwd")
+
+    def forward(self, st: int):
+        if self.capacity == 0:
+            raise RuntimeError("RenderPlan.probe() first (tile-list capacity)")
+        self._project(st)
+        check(lib.gsx_isect_bin_sort(_p(self.means2d), _p(self.radii), _p(self.depths), self.N, self.C, self.tile_w,
+                                     self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status), None,
+                                     _p(self.flat), _p(self.tile_order), _p(self.isect_ws), self.isect_ws.numel(), st),
+              "gsx_isect_bin_sort")
+        if self.n_touched is not None:
+            check(lib.gsx_zero_words(_p(self.n_touched), self.n_touched.numel(), st), "gsx_zero_words")
+        check(lib.gsx_raster_fwd(_p(self.rec), self.CH, _p(self.backgrounds), _p(self.offsets), _p(self.flat),
+                                 self.capacity, 1, self.C, self.W, self.H, self.tile_w, self.tile_h, self.vis_min_T,
+                                 _p(self.render), _p(self.alphas), _p(self.last_ids), _p(self.n_touched),
+                                 _p(self.tile_order), st), "gsx_raster_fwd")
+
+    def backward(self, st: int):
+        """from ``self.v_render`` (filled by the loss launch) to the pose partials in ``self.pose_ws`` and, for 'full', the
+        six map gradients (overwritten, summed over cameras inside)"""
+        assert self.grads != 'none'
+        check(lib.gsx_raster_bwd(_p(self.rec), self.CH, _p(self.backgrounds), _p(self.offsets), _p(self.flat),
+                                 self.capacity, 1, self.C, self.W, self.H, self.tile_w, self.tile_h, _p(self.alphas),
+                                 _p(self.last_ids), _p(self.v_render), None, _p(self.v_rec), None, _p(self.tile_order),
+                                 1 if self.geom_only else 0, st), "gsx_raster_bwd")
+        m = self.map
+        vr = self.v_rec.data_ptr()
+        if self.grads == 'pose':
+            outs = (None,) * 3 + (None,) + (None,) * 3
+        else:
+            v = self.v_map
+            outs = (_p(v[0]), _p(v[1]), _p(v[2]), None, _p(v[3]), _p(v[4]), _p(v[5]))
+        check(lib.gsx_project_bwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
+                                  self.H, self.eps2d, self.near, self.far, self.flags | _VIEW_PARTIALS, _p(self.radii),
+                                  vr, 12, None, vr + 8, 12, None, _p(m[3]), _p(m[4]), _p(m[5]), vr, *outs,
+                                  _p(self.pose_ws), self.pose_ws.numel(), st), "gsx_project_bwd")
+
+
+class _PoseSlots:
+    """PoseZhou parameters of up to 16 cameras in three persistent arrays (rows = poses), with the host pointer tables
+    the pose launches take (gslam/primitives.py:40-92)."""
+
+    def __init__(self, n: int, dev, learnable: Sequence[bool]):
+        self.n = n
+        self.Rt = torch.eye(4, device=dev).repeat(n, 1, 1).contiguous()
+        self.dR = torch.zeros(n, 6, device=dev)
+        self.dt = torch.zeros(n, 3, device=dev)
+        self.v_dR = torch.zeros(n, 6, device=dev)
+        self.v_dt = torch.zeros(n, 3, device=dev)
+        self.learnable = [bool(x) for x in learnable]
+        self._flags = (C.c_int * n)(*[1 if x else 0 for x in self.learnable])
+        rows = lambda t: _arr([t[i].data_ptr() for i in range(n)])
+        self._Rt, self._dR, self._dt, self._vdR, self._vdt = rows(self.Rt), rows(self.dR), rows(self.dt), rows(self.v_dR), rows(self.v_dt)
+
+    def forward(self, viewmats: torch.Tensor, st: int):
+        check(lib.gsx_pose_zhou_fwd(self.n, self._Rt, self._dR, self._dt, self._flags, viewmats.data_ptr(), st),
+              "gsx_pose_zhou_fwd")
+
+    def backward_partials(self, r: RenderPlan, st: int):
+        if not any(self.learnable):
+            return
+        check(lib.gsx_pose_zhou_bwd_partials(self.n, self._Rt, self._dR, self._dt, self._flags, _p(r.pose_ws),
+                                             r.pose_blocks, None, self._vdR, self._vdt, st),
+              "gsx_pose_zhou_bwd_partials")
+
+    @torch.no_grad()
+    def load(self, poses):
+        for i, p in enumerate(poses):
+            self.Rt[i].copy_(p.Rt)
+            if self.learnable[i]:
+                self.dR[i].copy_(p.dR)
+                self.dt[i].copy_(p.dt)
+            else:
+                self.dR[i].zero_()
+                self.dt[i].zero_()
+
+    @torch.no_grad()
+    def store(self, poses):
+        for i, p in enumerate(poses):
+            if self.learnable[i]:
+                p.dR.copy_(self.dR[i])
+                p.dt.copy_(self.dt[i])
+
+
+def _photometric_loss(r: RenderPlan, gt: torch.Tensor, exposure: torch.Tensor, mode: int, w_photo: float, map_ws, st: int,
+                      use_alphas: bool):
+    """csrc/loss.hip map_loss_kernel: per-pixel value partials (left in ``map_ws``) and d loss / d render -> r.v_render"""
+    denom = r.C * r.H * r.W * (3 if mode == 1 else 1)
+    check(lib.gsx_map_loss(_p(r.render), _p(r.alphas) if use_alphas else None, _p(gt), _p(exposure), r.C, r.H, r.W, r.CH,
+                           r.depth_index, r.betas_index, mode, w_photo / denom, 0.0, 0.4, None, None, _p(r.v_render),
+                           None, _p(map_ws), map_ws.numel(), st), "gsx_map_loss")
+    return denom
+
+
+class TrackClosure:
+    """One evaluation of the tracking closure (gslam/frontend.py:621-649) on a persistent slot - pose (Rt, dR, dt),
+    exposure [2], target image - against a frozen map: C = 1 render without the depth channel (the reference renders it
+    but reads it only under use_gt_depths, frontend.py:134-137), active-nerf loss with the exposure affine (:113-138,
+    :632-636), backward to the 9 pose scalars + 2 exposure scalars.
+
+    tail = 'fused': ONE launch takes the projection backward's pose partials through the PoseZhou backward, finishes the
+    loss, advances the device optimiser (10 Adam steps + strong-Wolfe L-BFGS, csrc/track_opt.h) and writes the next
+    evaluation point and its view matrix.  'split': the same with separate launches (PoseZhou forward, partials ->
+    PoseZhou backward, loss finish, optimiser advance).  'host': stops at the gradients (``g_dt, g_dR, g_exposure``,
+    ``loss``) for an optimiser on the host."""
+
+    def __init__(self, splats, camera, tail: str = 'fused'):
+        assert tail in ('fused', 'split', 'host')
+        self.tail = tail
+        self.camera = camera
+        self.r = RenderPlan(splats, 1, camera.width, camera.height, render_depth=False, grads='pose',
+                            Ks=camera.intrinsics)
+        dev = self.r.dev
+        self.dev = dev
+        self.slots = _PoseSlots(1, dev, [True])
+        self.exposure = torch.zeros(2, device=dev)
+        self.g_exposure = torch.zeros(2, device=dev)
+        self.img = torch.zeros(camera.height, camera.width, 3, device=dev)
+        self.out2 = torch.zeros(2, device=dev)
+        self.state = torch.zeros(int(lib.gsx_track_opt_state_bytes()), dtype=torch.uint8, device=dev)
+        self.report = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.map_ws = torch.empty(int(lib.gsx_map_loss_workspace_bytes(1, self.r.H, self.r.W)), dtype=torch.uint8,
+                                  device=dev)
+        self.n_rows = (self.r.H * self.r.W + 255) // 256
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graph = HipGraph()
+
+    # convenient views of the slot
+    @property
+    def Rt(self): return self.slots.Rt[0]
+    @property
+    def dR(self): return self.slots.dR[0]
+    @property
+    def dt(self): return self.slots.dt[0]
+    @property
+    def g_dR(self): return self.slots.v_dR[0]
+    @property
+    def g_dt(self): return self.slots.v_dt[0]
+    @property
+    def loss(self): return self.out2[0:1]
+
+    @torch.no_grad()
+    def load(self, Rt: torch.Tensor, img: torch.Tensor, exposure: torch.Tensor):
+        self.slots.Rt[0].copy_(Rt)
+        self.slots.dR.zero_()
+        self.slots.dt.zero_()
+        self.img.copy_(img)
+        self.exposure.copy_(exposure.reshape(2))
+        self.r.viewmats[0].copy_(Rt)                    # dR = dt = 0: the first evaluation's view matrix
+
+    def enqueue(self, st: int):
+        r = self.r
+        if self.tail != 'fused':
+            self.slots.forward(r.viewmats, st)
+        r.forward(st)
+        denom = _photometric_loss(r, self.img, self.exposure, 2, 1.0, self.map_ws, st, use_alphas=False)
+        r.backward(st)
+        if self.tail == 'fused':
+            check(lib.gsx_track_opt_tail(_p(self.state), _p(r.pose_ws), r.pose_blocks, _p(self.slots.Rt), _p(self.slots.dt),
+                                         _p(self.slots.dR), _p(self.exposure), None, None, _p(r.viewmats), _p(self.map_ws),
+                                         self.n_rows, 1.0 / denom, st), "gsx_track_opt_tail")
+            return
+        self.slots.backward_partials(r, st)
+        pm = 1.0 / denom
+        c0 = (C.c_float * 5)(pm, pm, 0.0, 0.0, 0.0)
+        check(lib.gsx_loss_finish(_p(self.map_ws), 1, r.H, r.W, None, 0, None, 0, c0, c0, 0.0, 0.0, None,
+                                  _p(self.g_exposure), _p(self.out2), st), "gsx_loss_finish")
+        if self.tail == 'split':
+            ps = [self.dt, self.dR, self.exposure]
+            gs = [self.g_dt, self.g_dR, self.g_exposure]
+            check(lib.gsx_track_opt_advance(_p(self.state), 3, _arr([t.data_ptr() for t in ps]),
+                                            _arr([t.data_ptr() for t in gs]), (C.c_int * 3)(3, 6, 2), _p(self.out2), st),
+                  "gsx_track_opt_advance")
+
+    def init_optimizer(self, n_adam: int, lr: float, history: int, max_eval: int, st: Optional[int] = None):
+        """torch.optim.LBFGS defaults of the reference call (frontend.py:613-619): max_iter 20, tolerance_grad 1e-7,
+        tolerance_change 1e-9"""
+        check(lib.gsx_track_opt_init(_p(self.state), 11, n_adam, lr, lr, history, 20, max_eval, 1e-7, 1e-9,
+                                     current_stream_ptr(self.dev) if st is None else st), "gsx_track_opt_init")
+
+    def read_report(self, st: Optional[int] = None) -> torch.Tensor:
+        check(lib.gsx_track_opt_report(_p(self.state), _p(self.report), current_stream_ptr(self.dev) if st is None else st),
+              "gsx_track_opt_report")
+        return self.report
+
+    def prepare(self):
+        """capacity probe + two eager evaluations + capture.  The slot must hold a frame (load()); the optimiser state is
+        whatever it was - callers re-initialise it before the replays that count."""
+        saved = [t.clone() for t in (self.slots.dR, self.slots.dt, self.exposure, self.r.viewmats)]
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        st = self.stream.cuda_stream
+        for _ in range(4):
+            self.r.probe(st)
+            self.init_optimizer(10, 0.0, 5, 25, st)          # the warm-up evaluation's step is undone below
+            self.enqueue(st)
+            self.stream.synchronize()
+            if self.r.check_capacity():
+                break
+        else:
+            raise RuntimeError("tile-list capacity keeps overflowing during warm-up")
+        self.graph.capture(self.stream, self.enqueue)
+        self.r.stale = False
+        self.stream.synchronize()
+        with torch.no_grad():
+            for t, s in zip((self.slots.dR, self.slots.dt, self.exposure, self.r.viewmats), saved):
+                t.copy_(s)
+        torch.cuda.current_stream(self.dev).wait_stream(self.stream)
+
+
+class WindowClosure:
+    """One evaluation of the closure of ``Backend.optimize_poses_lbfgs`` (gslam/backend.py:465-504): the C <= 8 window
+    keyframes rendered against the frozen map without the depth channel, photometric term only (:484-492), backward to the
+    pose parameters; the strong-Wolfe L-BFGS state machine (history 10, <= 80 parameters, csrc/window_opt.hip) advanced
+    at its end.  Poses, exposure and images live in slots of the plan; ``load`` / ``store`` move a window in and out."""
+
+    def __init__(self, splats, cameras, learnable: Sequence[bool], active_gs: bool = True):
+        Cn = len(cameras)
+        self.C = Cn
+        Ks = torch.stack([c.intrinsics for c in cameras], dim=0)
+        self.r = RenderPlan(splats, Cn, cameras[0].width, cameras[0].height, render_depth=False, grads='pose')
+        self.r.Ks.copy_(Ks)
+        dev = self.r.dev
+        self.dev = dev
+        self.mode = 0 if active_gs else 1
+        self.slots = _PoseSlots(Cn, dev, learnable)
+        self.exposure = torch.zeros(Cn, 2, device=dev)
+        self.g_exposure = torch.zeros(Cn, 2, device=dev)
+        self.gt = torch.zeros(Cn, self.r.H, self.r.W, 3, device=dev)
+        self.out2 = torch.zeros(2, device=dev)
+        self.state = torch.zeros(int(lib.gsx_window_opt_state_bytes()), dtype=torch.uint8, device=dev)
+        self.report = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.map_ws = torch.empty(int(lib.gsx_map_loss_workspace_bytes(Cn, self.r.H, self.r.W)), dtype=torch.uint8,
+                                  device=dev)
+        # parameter order of the host version: for each learnable pose dt, dR (PoseZhou.parameters())
+        ps, gs, ns = [], [], []
+        for i, l in enumerate(self.slots.learnable):
+            if l:
+                ps += [self.slots.dt[i], self.slots.dR[i]]
+                gs += [self.slots.v_dt[i], self.slots.v_dR[i]]
+                ns += [3, 6]
+        self.n_tensors, self.n_params = len(ps), sum(ns)
+        if self.n_params == 0:
+            raise ValueError("no learnable pose in the window")
+        if self.n_params > 80 or self.n_tensors > 16:
+            raise ValueError("window too large for the device optimiser (80 parameters in 16 tensors)")
+        self._ps, self._gs = _arr([t.data_ptr() for t in ps]), _arr([t.data_ptr() for t in gs])
+        self._ns = (C.c_int * len(ns))(*ns)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graph = HipGraph()
+
+    @torch.no_grad()
+    def load(self, window):
+        self.slots.load([x.pose for x in window])
+        for i, x in enumerate(window):
+            self.gt[i].copy_(x.img)
+            self.exposure[i].copy_(x.exposure_params.detach().reshape(2))
+
+    def store(self, window):
+        self.slots.store([x.pose for x in window])
+
+    def enqueue(self, st: int, advance: bool = True):
+        r = self.r
+        self.slots.forward(r.viewmats, st)
+        r.forward(st)
+        denom = _photometric_loss(r, self.gt, self.exposure, self.mode, 1.0, self.map_ws, st, use_alphas=True)
+        r.backward(st)
+        self.slots.backward_partials(r, st)
+        pm = 1.0 / denom
+        c0 = (C.c_float * 5)(pm, pm, 0.0, 0.0, 0.0)
+        check(lib.gsx_loss_finish(_p(self.map_ws), r.C, r.H, r.W, None, 0, None, 0, c0, c0, 0.0, 0.0, None,
+                                  _p(self.g_exposure), _p(self.out2), st), "gsx_loss_finish")
+        if advance:
+            check(lib.gsx_window_opt_advance(_p(self.state), self.n_tensors, self._ps, self._gs, self._ns, _p(self.out2),
+                                             st), "gsx_window_opt_advance")
+
+    def init_optimizer(self, max_eval: int, st: Optional[int] = None):
+        """torch.optim.LBFGS defaults of the reference call (backend.py:465-470): lr 1, max_iter 20, history 10,
+        tolerance_grad 1e-7, tolerance_change 1e-7"""
+        st = current_stream_ptr(self.dev) if st is None else st
+        check(lib.gsx_window_opt_init(_p(self.state), self.n_params, 0, 0.0, 1.0, 10, 20, int(max_eval), 1e-7, 1e-7, st),
+              "gsx_window_opt_init")
+
+    def read_report(self, st: Optional[int] = None) -> torch.Tensor:
+        check(lib.gsx_window_opt_report(_p(self.state), _p(self.report),
+                                        current_stream_ptr(self.dev) if st is None else st), "gsx_window_opt_report")
+        return self.report
+
+    def prepare(self):
+        saved = [t.clone() for t in (self.slots.dR, self.slots.dt)]
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        st = self.stream.cuda_stream
+        for _ in range(4):
+            self.slots.forward(self.r.viewmats, st)
+            self.r.probe(st)
+            self.init_optimizer(25, st)                      # the warm-up evaluation's step is undone below
+            self.enqueue(st)
+            self.stream.synchronize()
+            if self.r.check_capacity():
+                break
+        else:
+            raise RuntimeError("tile-list capacity keeps overflowing during warm-up")
+        self.graph.capture(self.stream, self.enqueue)
+        self.r.stale = False
+        self.stream.synchronize()
+        with torch.no_grad():
+            for t, s in zip((self.slots.dR, self.slots.dt), saved):
+                t.copy_(s)
+        torch.cuda.current_stream(self.dev).wait_stream(self.stream)
+
+
+GRAD_PARAMS = ('means', 'quats', 'scales', 'opacities', 'colors', 'log_uncertainties')
+
+
+class MappingStep:
+    """One bundle-adjustment iteration of ``Backend.optimize_map`` (gslam/backend.py:260-359) over a FIXED window as a
+    launch plan: PoseZhou forward of the window poses -> render (RGB + depth + beta) -> fused SSIM forward / backward ->
+    loss block (exposure affine, active-nerf photometric + 0.5 log^2 beta, edge-aware depth TV, SSIM gradient folded in;
+    backend.py:273-318) -> rasteriser + projection backward to all six map arrays and the pose partials -> PoseZhou
+    backward -> isotropic term added into the scale gradient -> [all-reduce] -> six splat Adams + pose Adam + opacity
+    decay in one launch (backend.py:554-602, :356-359).
+
+    Every gradient lives in ONE flat fp32 bucket ``[N*15 map | N visible-camera counts | Cw*3 pose dt | Cw*6 pose dR |
+    2 loss values]`` (Cw = cameras of the whole window).  Multi-GPU: the window's cameras are dealt
+    round-robin over ranks, each rank renders its own against its replica of the map, and a single all-reduce(sum) of that
+    bucket carries the map gradients, the visibility counts, the pose gradients (each rank fills the rows of its own
+    cameras, the others are zero) and the loss terms; every rank then applies the identical update to the map AND to
+    all window poses, so replicas never diverge and no pose broadcast is needed.  Per-camera means are scaled by
+    C_local / C_window, the TV sum is not, the isotropic term is applied after the reduction from the window-wide
+    visibility (identical on all ranks).  The step is two graphs around the one collective; with one rank, one graph.
+
+    ``optimizers``: mapping.MapOptimizers built with capturable=True.  Exposure parameters of keyframes are constants
+    here (the backend freezes them when it adds a keyframe, gslam_amd/backend.py add_keyframe)."""
+
+    def __init__(self, splats, optimizers, window, conf, regularize: bool = True, shard=None,
+                 need_n_touched: bool = False, decay_opacity: bool = True):
+        self.splats, self.optimizers, self.conf = splats, optimizers, conf
+        self.window = list(window)
+        self.regularize = bool(regularize)
+        self.rank = 0 if shard is None else shard.rank
+        self.world = 1 if shard is None else shard.world_size
+        self.group = None if shard is None else shard.group
+        Cw = len(self.window)
+        if Cw == 0 or Cw > 16:
+            raise ValueError("window of 1..16 keyframes")
+        self.Cw = Cw
+        self.mine = [i for i in range(Cw) if i % self.world == self.rank]
+        if any(f.exposure_params is not None and f.exposure_params.requires_grad for f in self.window):
+            raise NotImplementedError("trainable keyframe exposure is not part of the launch plan")
+        params = [getattr(splats, n) for n in GRAD_PARAMS]
+        N = int(params[0].shape[0])
+        dev = params[0].device
+        self.dev, self.N = dev, N
+        # ---- the bucket (gslam_amd.dist.StepBucket: map gradients | counts | pose rows | loss slots) -------------------
+        from .dist import StepBucket
+        self.bucket = StepBucket([p.shape for p in params], Cw, dev, group=self.group)
+        self.flat = self.bucket.flat
+        self.grad_views = dict(zip(GRAD_PARAMS, self.bucket.views))
+        self.counts, self.g_dt, self.g_dR = self.bucket.counts, self.bucket.g_dt, self.bucket.g_dR
+        self.out2, self.vis_i32 = self.bucket.out2, self.bucket.vis_i32
+        # ---- poses -----------------------------------------------------------------------------------------------------
+        self.learnable = [bool(getattr(f.pose, "is_learnable", True) and f.pose.dR.requires_grad) for f in self.window]
+        for f in self.window:
+            optimizers.add_pose(f.pose)
+            for t in (f.pose.Rt, f.pose.dR, f.pose.dt):
+                if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                    raise RuntimeError("poses must be contiguous float32 on the GPU")
+        Cl = len(self.mine)
+        self.r: Optional[RenderPlan] = None
+        cam0 = self.window[0].camera
+        self.H, self.W = int(cam0.height), int(cam0.width)
+        if Cl > 0:
+            self.r = RenderPlan(splats, Cl, self.W, self.H, render_depth=True, grads='full', grad_out=self.grad_views,
+                                need_n_touched=need_n_touched)
+            self.r.Ks.copy_(torch.stack([self.window[i].camera.intrinsics for i in self.mine], dim=0))
+            r = self.r
+            self.gt = torch.empty(Cl, self.H, self.W, 3, device=dev)
+            self.exposure = torch.zeros(Cl, 2, device=dev)
+            self.g_exposure = torch.zeros(Cl, 2, device=dev)
+            self.refresh_inputs()
+            self._flags = (C.c_int * Cl)(*[1 if self.learnable[i] else 0 for i in self.mine])
+            self._Rt = _arr([self.window[i].pose.Rt.data_ptr() for i in self.mine])
+            self._dR = _arr([self.window[i].pose.dR.data_ptr() for i in self.mine])
+            self._dt = _arr([self.window[i].pose.dt.data_ptr() for i in self.mine])
+            self._vdR = _arr([self.g_dR[i].data_ptr() for i in self.mine])
+            self._vdt = _arr([self.g_dt[i].data_ptr() for i in self.mine])
+            H, W = self.H, self.W
+            self.dm = torch.empty(3, Cl, 3, H, W, device=dev)
+            self.ssim_grad = torch.empty(Cl, 3, H, W, device=dev)
+            self.ssim_ws = torch.empty(int(lib.gsx_ssim_workspace_bytes(Cl, 3, H, W)), dtype=torch.uint8, device=dev)
+            self.n_ssim = int(lib.gsx_ssim_partials(Cl, 3, H, W))
+            self.map_ws = torch.empty(int(lib.gsx_map_loss_workspace_bytes(Cl, H, W)), dtype=torch.uint8, device=dev)
+            self._one = torch.ones(1, device=dev)
+            self._s_r = (C.c_int64 * 4)(H * W * r.CH, 1, W * r.CH, r.CH)
+            self._s_g = (C.c_int64 * 4)(H * W * 3, 1, W * 3, 3)
+        self.iso_ws = torch.empty(int(lib.gsx_isotropic_workspace_bytes(N)), dtype=torch.uint8, device=dev)
+        # ---- the update: six splat tensors + (dt, dR) of every learnable window pose, identical on every rank ------------
+        grad_of = {id(getattr(splats, n)): self.grad_views[n] for n in GRAD_PARAMS}
+        for i, f in enumerate(self.window):
+            if self.learnable[i]:
+                grad_of[id(f.pose.dt)] = self.g_dt[i]
+                grad_of[id(f.pose.dR)] = self.g_dR[i]
+        vis = self.vis_i32 if self.world > 1 else (self.r.vis_count if self.r is not None else self.vis_i32)
+        self._vis = vis
+        from .optim import AdamPack
+        decay = (splats.opacities, vis, 1, float(conf.opacity_decay)) if decay_opacity else None
+        self.adam = AdamPack([optimizers.splat_opt, optimizers.pose_opt], grad_of, decay)
+        pose_grads = {k: v for k, v in grad_of.items() if k not in {id(getattr(splats, n)) for n in GRAD_PARAMS}}
+        self.adam_poses = AdamPack([optimizers.pose_opt], pose_grads) if pose_grads else None
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graph, self.graph2 = HipGraph(), HipGraph()
+        self.steps = 0
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def refresh_inputs(self):
+        """copies the window's images and exposure parameters into the plan's buffers (they are constants of a window)"""
+        for j, i in enumerate(self.mine):
+            f = self.window[i]
+            self.gt[j].copy_(f.img)
+            if f.exposure_params is not None:
+                self.exposure[j].copy_(f.exposure_params.detach().reshape(2))
+
+    def matches(self, splats, window) -> bool:
+        return (self.r is None or self.r.matches(splats)) and len(window) == self.Cw and \
+            all(a is b for a, b in zip(window, self.window)) and int(splats.means.shape[0]) == self.N
+
+    def enqueue_render_backward(self, st: int):
+        """render + loss + backward of this rank's cameras: fills the bucket (map gradients, counts source, pose rows)"""
+        conf = self.conf
+        if self.world > 1:
+            # rows of other ranks' cameras and the loss slots hold last iteration's sums: clear them (one small launch)
+            tail = self.bucket.tail
+            check(lib.gsx_zero_words(_p(tail), tail.numel(), st), "gsx_zero_words")
+        r = self.r
+        if r is None:
+            return
+        Cl, H, W = r.C, r.H, r.W
+        shard = Cl / float(self.Cw)
+        multi = self.world > 1
+        w_photo, w_ssim = shard * (1.0 - conf.ssim_weight), shard * conf.ssim_weight
+        w_iso = 0.0 if multi else conf.isotropic_regularization_weight
+        w_tv = conf.depth_regularization_weight if self.regularize else 0.0
+        mode = 0 if conf.active_gs else 1
+        check(lib.gsx_pose_zhou_fwd(Cl, self._Rt, self._dR, self._dt, self._flags, _p(r.viewmats), st),
+              "gsx_pose_zhou_fwd")
+        r.forward(st)
+        n_ssim = 0
+        numel_ssim = Cl * 3 * (H - 10) * (W - 10)
+        ssim_grad = None
+        if w_ssim != 0.0:
+            n_ssim = self.n_ssim
+            check(lib.gsx_ssim_fwd(_p(r.render), _p(self.gt), Cl, 3, H, W, self._s_r, self._s_g, 5, None,
+                                   _p(self.dm[0]), _p(self.dm[1]), _p(self.dm[2]), _p(self.ssim_ws),
+                                   self.ssim_ws.numel(), st), "gsx_ssim_fwd")
+            check(lib.gsx_ssim_bwd(_p(r.render), _p(self.gt), Cl, 3, H, W, self._s_r, self._s_g, 5, _p(self.dm[0]),
+                                   _p(self.dm[1]), _p(self.dm[2]), _p(self._one), -w_ssim / numel_ssim,
+                                   _p(self.ssim_grad), st), "gsx_ssim_bwd")
+            ssim_grad = self.ssim_grad
+        denom = Cl * H * W * (3 if mode == 1 else 1)
+        check(lib.gsx_map_loss(_p(r.render), _p(r.alphas), _p(self.gt), _p(self.exposure), Cl, H, W, r.CH, r.depth_index,
+                               r.betas_index, mode, w_photo / denom, w_tv, 0.4, _p(ssim_grad), None, _p(r.v_render),
+                               None, _p(self.map_ws), self.map_ws.numel(), st), "gsx_map_loss")
+        r.backward(st)
+        if any(self.learnable[i] for i in self.mine):
+            check(lib.gsx_pose_zhou_bwd_partials(Cl, self._Rt, self._dR, self._dt, self._flags, _p(r.pose_ws),
+                                                 r.pose_blocks, None, self._vdR, self._vdt, st),
+                  "gsx_pose_zhou_bwd_partials")
+        iso_ws, n_iso = None, 0
+        if w_iso != 0.0:
+            iso_ws, n_iso = self.iso_ws, self.N
+            check(lib.gsx_isotropic_loss_acc(_p(r.map[2]), _p(r.vis_count), self.N, w_iso, None,
+                                             _p(self.grad_views['scales']), _p(iso_ws), iso_ws.numel(), st),
+                  "gsx_isotropic_loss_acc")
+        pm = 1.0 / denom
+        c0 = (C.c_float * 5)(w_photo * pm, w_photo * pm, w_tv, -w_ssim / numel_ssim if n_ssim else 0.0,
+                             w_iso if iso_ws is not None else 0.0)
+        c1 = (C.c_float * 5)(shard * pm, shard * pm, 0.0, 0.0, 0.0)
+        check(lib.gsx_loss_finish(_p(self.map_ws), Cl, H, W, _p(self.ssim_ws) if n_ssim else None, n_ssim, _p(iso_ws),
+                                  n_iso, c0, c1, w_ssim if n_ssim else 0.0, 0.0, None, _p(self.g_exposure),
+                                  _p(self.out2), st), "gsx_loss_finish")
+
+    def reduce(self):
+        """the ONE data-path collective of an iteration (eager, on torch's current stream, between the two graphs)"""
+        if self.world > 1:
+            self.bucket.reduce(None if self.r is None else self.r.vis_count)
+
+    def enqueue_update(self, st: int):
+        """isotropic term from the window-wide visibility (multi-rank) + Adam + opacity decay"""
+        conf = self.conf
+        w = conf.isotropic_regularization_weight
+        if self.world > 1 and w != 0.0:
+            check(lib.gsx_isotropic_loss_acc(_p(self.splats.scales.detach()), _p(self.vis_i32), self.N, w, None,
+                                             _p(self.grad_views['scales']), _p(self.iso_ws), self.iso_ws.numel(), st),
+                  "gsx_isotropic_loss_acc")
+        self.adam.launch(st)
+
+    def _enqueue_all(self, st: int):
+        self.enqueue_render_backward(st)
+        self.enqueue_update(st)
+
+    def prepare(self):
+        """capacity probe, ONE eager render + loss + backward (no update: the map and the optimiser state stay as they
+        are) and the capture of the step"""
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        st = self.stream.cuda_stream
+        if self.r is not None:
+            for _ in range(4):
+                check(lib.gsx_pose_zhou_fwd(self.r.C, self._Rt, self._dR, self._dt, self._flags, _p(self.r.viewmats), st),
+                      "gsx_pose_zhou_fwd")
+                self.r.probe(st)
+                self.enqueue_render_backward(st)
+                self.stream.synchronize()
+                if self.r.check_capacity():
+                    break
+            else:
+                raise RuntimeError("tile-list capacity keeps overflowing during warm-up")
+        if self.world == 1:
+            self.graph.capture(self.stream, self._enqueue_all)
+        else:
+            self.graph.capture(self.stream, self.enqueue_render_backward)
+            self.graph2.capture(self.stream, self.enqueue_update)
+        if self.r is not None:
+            self.r.stale = False
+        self.stream.synchronize()
+        torch.cuda.current_stream(self.dev).wait_stream(self.stream)
+
+    def step(self, graphed: bool = True):
+        """one iteration on torch's current stream; returns (total, photometric) as views of the bucket's loss slots -
+        device values, valid once the stream has run (multi-rank: window-wide sums after the reduction)"""
+        if graphed and (not self.graph.captured or (self.r is not None and self.r.stale)):
+            self.prepare()
+        st = current_stream_ptr(self.dev)
+        if self.world == 1:
+            if graphed:
+                self.graph.launch(st)
+            else:
+                if self.r is not None and self.r.capacity == 0:
+                    check(lib.gsx_pose_zhou_fwd(self.r.C, self._Rt, self._dR, self._dt, self._flags, _p(self.r.viewmats),
+                                                st), "gsx_pose_zhou_fwd")
+                    self.r.probe()
+                self._enqueue_all(st)
+        else:
+            if graphed:
+                self.graph.launch(st)
+            else:
+                if self.r is not None and self.r.capacity == 0:
+                    check(lib.gsx_pose_zhou_fwd(self.r.C, self._Rt, self._dR, self._dt, self._flags, _p(self.r.viewmats),
+                                                st), "gsx_pose_zhou_fwd")
+                    self.r.probe()
+                self.enqueue_render_backward(st)
+            self.reduce()
+            if graphed:
+                self.graph2.launch(st)
+            else:
+                self.enqueue_update(st)
+        self.adam.note_steps(1)
+        self.steps += 1
+        return self.out2[0], self.out2[1]
+
+    def render_backward(self):
+        """render + loss + backward (+ the collective) WITHOUT the update, eagerly on torch's current stream: the
+        iteration whose gradients feed densification (backend.py:329-337); ``step_poses()`` then applies what the
+        reference's optimiser step still applies on that iteration (the re-packed map tensors have no gradient)"""
+        st = current_stream_ptr(self.dev)
+        if self.r is not None and self.r.capacity == 0:
+            check(lib.gsx_pose_zhou_fwd(self.r.C, self._Rt, self._dR, self._dt, self._flags, _p(self.r.viewmats), st),
+                  "gsx_pose_zhou_fwd")
+            self.r.probe()
+        self.enqueue_render_backward(st)
+        self.reduce()
+        return self.out2[0], self.out2[1]
+
+    def step_poses(self):
+        if self.adam_poses is not None:
+            self.adam_poses.launch(current_stream_ptr(self.dev))
+            self.adam_poses.note_steps(1)
+
+    def decay_opacities(self):
+        """backend.py:356-359 as its own launch (for callers that decide about it after reading the loss)"""
+        vis = self._vis
+        check(lib.gsx_opacity_decay(_p(self.splats.opacities.detach()), _p(vis), self.N, 1,
+                                    float(self.conf.opacity_decay), current_stream_ptr(self.dev)), "gsx_opacity_decay")
+
+    def capacity_ok(self) -> bool:
+        return True if self.r is None else self.r.check_capacity()
+
+    def as_output(self):
+        """RasterizationOutput over this rank's cameras (None for a rank without cameras)"""
+        if self.r is None:
+            return None
+        out = self.r.as_output()
+        out._window_cams = self.Cw
+        return out
+
+    def depthmaps(self):
+        """[C_local,H,W] accumulated depth of the last render (what backend.py:361-362 stores as est_depths)"""
+        return None if self.r is None else self.r.render[..., self.r.depth_index]

@@ -6,16 +6,14 @@ build must not copy: the ``ED`` / ``RGB+ED`` post-processing (KeyError 'depthaps
 implemented as the documented intent (depth / alpha), the >32-channel chunk loop (wrong variable at :323) and the
 ``covars`` path (:129-134 vs :147) are rejected explicitly.
 
-Sync-free by construction: the reference's ``isect_tiles`` reads the intersection count M back to the host in the
-middle of every render.  Here the tile-binned sort keeps every size on the device and writes into capacity-sized
-buffers; ``isect_ids`` / ``flatten_ids`` are trimmed lazily (first access) and capacity overflow is detected from
-an asynchronous copy of the device status word (``validate()`` forces the check).
+Sizes: by default M is read back once per render, like the reference's ``isect_tiles`` (exact arrays).  With
+``capacity=IsectCapacity(...)`` the render is sync-free: the tile-binned sort keeps every size on the device and writes
+into capacity-sized buffers; ``isect_ids`` / ``flatten_ids`` are trimmed lazily (first access) and overflow is read from
+the sticky device status word (``IsectCapacity.validate()``).
 """
 from __future__ import annotations
 
 import math
-import os
-import warnings
 from typing import Optional
 
 import torch
@@ -53,7 +51,7 @@ class RasterizationOutput:
             M = int(M_dev.item())                      # the one read-back, only if somebody asks for the arrays
             if M > flat.shape[0]:
                 raise RuntimeError(f"isect capacity overflow: {M} intersections > capacity {flat.shape[0]}; "
-                                   "call gslam_amd.rasterization.validate() and re-render")
+                                   "call IsectCapacity.validate() and re-render")
             self._flatten_ids = flat[:M]
             self._isect_ids = ops.rebuild_isect_ids(self, M)
             self._lazy = None
@@ -83,126 +81,71 @@ class RasterizationOutput:
         return "RasterizationOutput(" + ", ".join(f"{f}=..." for f in self._FIELDS) + ")"
 
 
-class _IsectPool:
-    """Per-device capacity manager for the sync-free tile-binned sort."""
+class IsectCapacity:
+    """Caller-owned capacity of the tile lists for SYNC-FREE eager renders (``rasterization(..., capacity=cap)``).
+
+    The reference reads the intersection count M back to the host inside ``isect_tiles`` on every render; by default this
+    module does the same (exact sizes, one read-back).  A caller that renders the same shape over and over - a loop under
+    HIP-graph capture, a benchmark - passes one of these instead: the first render probes M once (synchronously), later
+    renders write into buffers of 1.5x that size without any read-back, and ``validate()`` tells - with one blocking read
+    of the sticky device status word - whether any render since the last call overflowed (the capacity has then been
+    grown; the caller re-renders).  One object per problem shape (N, C, W, H) and stream of launches; no global state.
+    The optimisation loops do not come through here: their launch plans (gslam_amd.plan) own their capacity."""
     GROW = 1.5
 
-    def __init__(self, dev):
-        self.dev = dev
+    def __init__(self, device):
+        self.dev = torch.device(device)
         self.capacity = 0
-        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._pinned = torch.zeros(2, dtype=torch.int64).pin_memory()
-        self._staging = torch.zeros(2, dtype=torch.int64, device=dev)
-        self._event: Optional[torch.cuda.Event] = None
-        self.overflowed = False
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.M_dev: Optional[Tensor] = None
         self.last_M = 0
-        self._graph_M = None
-        self.signature = None       # (N, C, W, H) of the renders the capacity was sized for
 
     def ensure(self, estimate: int):
         want = int(estimate * self.GROW) + 4096
         if want > self.capacity:
             self.capacity = want
 
-    def poll(self, block: bool = False) -> bool:
-        """Consumes the asynchronous (M, status) copy of the previous render if it has arrived.  Returns False when
-        that render overflowed its capacity (capacity is grown for the next one)."""
+    def validate(self) -> bool:
         ok = True
-        if self._event is not None and (block or self._event.query()):
-            if block:
-                self._event.synchronize()
-            M, st = int(self._pinned[0]), int(self._pinned[1])
-            self._event = None
-            self.last_M = M
+        if self.M_dev is not None:
+            st, m = int(self.status.item()), int(self.M_dev.item())
+            self.last_M = m
             if st & 1:
                 ok = False
-                self.overflowed = True
                 # M can be an under-estimate when the overflow was in the pre-sort's instance records (csrc/isect_bin.hip
                 # 3c): grow geometrically from the current capacity as well
-                self.capacity = int(max(M, self.capacity) * self.GROW) + 4096
+                self.capacity = int(max(m, self.capacity) * self.GROW) + 4096
                 self.status.zero_()
             else:
-                self.ensure(M)
+                self.ensure(m)
         return ok
 
-    def note_captured(self, M_dev: Tensor):
-        """a render captured into a HIP graph cannot post its own async read-back; remember where its M lives so that
-        validate() can read it after replays"""
-        self._graph_M = M_dev
 
-    def post(self, M_dev: Tensor):
-        self._staging[0:1].copy_(M_dev)
-        self._staging[1:2].copy_(self.status)
-        self._pinned.copy_(self._staging, non_blocking=True)
-        self._event = torch.cuda.Event()
-        self._event.record()
-
-
-_POOLS: dict = {}
-_BG_CACHE: dict = {}
+_BG_CACHE: "dict" = {}
 
 
 def _packed_backgrounds(backgrounds: Optional[Tensor], C: int, with_depth: bool, with_beta: bool) -> Optional[Tensor]:
     """[C,3] -> [C,CH]: + 0 for depth + e^1 for beta (rasterization.py:236-239,251-255).  Cached while the caller
-    keeps passing the same (unmodified) tensor, which is what map.py does every render."""
+    keeps passing the same (unmodified) tensor, which is what map.py does every render; a small FIFO."""
     if backgrounds is None:
         return None
     if not (with_depth or with_beta):
         return backgrounds
-    key = (backgrounds.data_ptr(), backgrounds._version, C, with_depth, with_beta, backgrounds.requires_grad)
+    key = (backgrounds.data_ptr(), backgrounds._version, C, with_depth, with_beta)
     hit = _BG_CACHE.get(key)
-    if hit is not None and not backgrounds.requires_grad:
-        return hit
+    if hit is not None and not backgrounds.requires_grad and hit[0] is backgrounds:
+        return hit[1]
     parts = [backgrounds]
     if with_depth:
         parts.append(torch.zeros(C, 1, device=backgrounds.device, dtype=backgrounds.dtype))
     if with_beta:
         parts.append(torch.full((C, 1), math.e, device=backgrounds.device, dtype=backgrounds.dtype))
     bg = torch.cat(parts, dim=-1)
-    if not backgrounds.requires_grad and len(_BG_CACHE) < 512:
-        # entries are never evicted: a captured HIP graph may have a cached tensor's address baked in (they are tiny)
-        _BG_CACHE[key] = bg
-        _BG_CACHE[("keepalive",) + key] = backgrounds      # pin the id / data_ptr while cached
+    if not backgrounds.requires_grad:
+        while len(_BG_CACHE) >= 16:
+            _BG_CACHE.pop(next(iter(_BG_CACHE)))
+        _BG_CACHE[key] = (backgrounds, bg)          # holding the source pins its address while the entry lives
     return bg
-
-
-def _pool(dev, sig=None) -> _IsectPool:
-    """one capacity manager per (device, problem shape (N, C, W, H)): a tracker (C = 1) and a bundle adjuster (C = 8) of
-    one process - possibly on two threads / streams - do not re-probe or overflow each other's buffers"""
-    key = (torch.device(dev).index, sig)
-    p = _POOLS.get(key)
-    if p is None:
-        if len(_POOLS) >= 64:                          # maps that keep changing size: forget the oldest shapes
-            for k in list(_POOLS.keys())[:32]:
-                if _POOLS[k]._graph_M is None:
-                    del _POOLS[k]
-        p = _IsectPool(dev)
-        p.signature = sig
-        _POOLS[key] = p
-    return p
-
-
-def validate(device=None, signature=None) -> bool:
-    """Blocks until the last render's intersection count has arrived and returns True iff no sync-free render since
-    the previous call overflowed its buffers.  On False the caller should re-run the affected iteration (the capacity
-    has already been grown).  ``signature`` = (N, C, W, H) restricts the check to the renders of that shape."""
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    bad = False
-    for (di, sig_), p in list(_POOLS.items()):
-        if di != dev.index or (signature is not None and sig_ != tuple(signature)):
-            continue
-        p.poll(block=True)
-        if p._graph_M is not None:                  # renders replayed from a HIP graph: status is sticky on the device
-            st = int(p.status.item())
-            p.last_M = int(p._graph_M.item())
-            if st & 1:
-                p.overflowed = True
-                p.capacity = int(max(p.last_M, p.capacity) * p.GROW) + 4096
-                p.status.zero_()
-                p._graph_M = None                   # the captured graph is stale (capacity baked in): re-capture
-        bad = bad or p.overflowed
-        p.overflowed = False
-    return not bad
 
 
 def rasterization(
@@ -233,13 +176,16 @@ def rasterization(
     visibility_min_T: float = 0.5,
     mask: Optional[Tensor] = None,
     need_n_touched: bool = True,
+    capacity: Optional[IsectCapacity] = None,
 ) -> RasterizationOutput:
     """gslam ``rasterization`` (gslam/rasterization.py:44-360).  One fused projection+activation+packing kernel,
     tile-binned depth sort, one tiled rasterisation kernel; autograd reaches every pre-activation input and
     ``viewmats``.  The only caller in the reference passes packed=False (map.py:99).
 
     ``need_n_touched`` (extension, default True = reference behaviour): False skips the per-Gaussian touched-pixel
-    counts, which only visibility pruning reads (backend.py:370-375); ``n_touched`` is then None."""
+    counts, which only visibility pruning reads (backend.py:370-375); ``n_touched`` is then None.
+    ``capacity`` (extension): an ``IsectCapacity`` makes the render sync-free (see there); default None sizes the tile
+    lists exactly from one read-back of M, like the reference's ``isect_tiles``."""
     N = means.shape[0]
     C = viewmats.shape[0]
     assert means.shape == (N, 3), means.shape
@@ -298,26 +244,21 @@ def rasterization(
 
     lazy = None
     tile_order = None
-    if os.environ.get("GSX_SYNC_ISECT", "0") == "1":
-        # reference-shaped path: M is read back inside isect_tiles (one host sync per render)
+    if capacity is None:
+        # reference-shaped: M is read back inside isect_tiles (one host sync per render, exact sizes)
         _, isect_ids, flatten_ids = ops.isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height,
                                                     packed=False, n_cameras=C, tiles_per_gauss=tiles_per_gauss)
         isect_offsets = ops.isect_offset_encode(isect_ids, C, tile_width, tile_height)
         raster_offsets, has_end = isect_offsets, False
     else:
-        sig = (N, C, int(width), int(height))
-        pool = _pool(dev, sig)
+        pool = capacity
         capturing = torch.cuda.is_current_stream_capturing()
-        if not capturing:
-            pool.poll()
         if pool.capacity == 0:
-            # a new problem shape (first render, map grown / pruned, other resolution or window size): size the buffers
-            # with ONE synchronous probe; between probes M only drifts with the poses and is tracked asynchronously
+            # first render of this shape: size the buffers with ONE synchronous probe of the projection's upper bound
             if capturing:
                 raise RuntimeError("render this (N, C, W, H) once eagerly before capturing a HIP graph "
                                    "(intersection capacity probe)")
             pool.ensure(int(tiles_per_gauss.sum().item()))
-            pool.signature = sig
         cap = pool.capacity
         flat_buf = torch.empty(cap, dtype=torch.int32, device=dev)
         # heaviest-first launch order for the rasteriser: pays off while the tile lists are short (100 k Gaussians:
@@ -328,10 +269,7 @@ def rasterization(
         with torch.no_grad():
             off1, M_dev, _ = ops.isect_bin_sort(means2d.detach(), radii, depths.detach(), tile_width, tile_height, cap,
                                                 None, flat_buf, status=pool.status, tile_order=tile_order)
-        if not capturing:
-            pool.post(M_dev)
-        else:
-            pool.note_captured(M_dev)
+        pool.M_dev = M_dev
         isect_offsets = off1[:-1].view(C, tile_height, tile_width)
         raster_offsets, has_end, flatten_ids, isect_ids = off1, True, flat_buf, None
         lazy = (pool, M_dev, flat_buf, True)

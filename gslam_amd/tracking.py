@@ -6,8 +6,6 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional
 
-import os
-
 import torch
 
 from .map import GaussianSplattingData
@@ -117,128 +115,79 @@ def warp_track(new_frame: Frame, ref_frame: Frame, ref_img: torch.Tensor, ref_de
 
 
 class GraphedTracker:
-    """The tracking closure (C = 1 render forward + active-nerf loss + backward to the pose delta and the exposure
-    parameters, gslam/frontend.py:621-649) captured once into a HIP graph over a persistent "slot" and replayed for
-    every closure of every frame: ~12 kernel launches become one graph launch.
+    """``igs_track_lbfgs`` (gslam/frontend.py:604-662) on a launch plan: the tracking closure - C = 1 render forward,
+    active-nerf loss, backward to the pose delta and the exposure parameters (:621-649) - is a fixed chain of libgsx
+    launches over a persistent slot (gslam_amd.plan.TrackClosure), recorded once into a HIP graph and replayed for every
+    closure of every frame.  No autograd graph and no allocation inside the closure.
 
     ``device_optimizer=True`` (default) also moves the optimiser of frontend.py:613-658 - 10 Adam steps, then one
-    strong-Wolfe L-BFGS step - onto the device (csrc/track_opt.h): the state machine is advanced by one single-wavefront
-    kernel at the end of the captured closure, so a tracked frame is ``n_adam + max_eval + 1`` graph launches and ONE
-    read-back at the end instead of one ``loss.item()`` per closure (frontend.py:648).  With ``False`` the optimiser
-    logic stays on the host exactly as in the reference (torch.optim.Adam / torch.optim.LBFGS)."""
+    strong-Wolfe L-BFGS step - onto the device (csrc/track_opt.h): the state machine is advanced at the end of the captured
+    closure, so a tracked frame is ``n_adam + max_eval + 1`` graph launches and ONE read-back at the end instead of one
+    ``loss.item()`` per closure (frontend.py:648).  With ``False`` the optimiser logic stays on the host exactly as in the
+    reference (torch.optim.Adam / torch.optim.LBFGS) and only the closure is a graph.
+
+    ``tail``: 'fused' (default with the device optimiser: pose backward, loss finish, optimiser step and next view matrix
+    in one launch) or 'split' (the same as separate launches; kept as an independent implementation for the tests)."""
 
     def __init__(self, splats: GaussianSplattingData, camera, conf: Optional[TrackingConfig] = None,
-                 device_optimizer: bool = True, max_eval: int = 25):
-        from .losses import tracking_loss_and_grads
+                 device_optimizer: bool = True, max_eval: int = 25, tail: Optional[str] = None):
+        from .plan import TrackClosure
         from .primitives import PoseZhou
-        from .rasterization import validate
         self.conf = conf or TrackingConfig()
         self.splats, self.camera = splats, camera
-        dev = splats.means.device
-        H, W = camera.height, camera.width
+        self.device_optimizer = bool(device_optimizer)
+        self.max_eval = int(max_eval)
+        if tail is None:
+            tail = 'fused' if device_optimizer else 'host'
+        if not device_optimizer:
+            tail = 'host'
+        self.fused_tail = tail == 'fused'
+        self.plan = TrackClosure(splats, camera, tail=tail)
+        c = self.plan
+        dev = c.dev
+        # the slot seen as the reference's objects: a PoseZhou whose Rt / dR / dt ARE the plan's buffers, the exposure pair
         self.pose = PoseZhou(torch.eye(4, device=dev)).to(dev)
-        self.exposure = torch.zeros(2, device=dev, requires_grad=True)
-        self.img = torch.zeros(H, W, 3, device=dev)
+        self.pose.Rt = c.Rt
+        self.pose.dt = torch.nn.Parameter(c.dt)
+        self.pose.dR = torch.nn.Parameter(c.dR)
+        self.exposure = c.exposure.requires_grad_(True)
+        self.img = c.img
         self.params = [self.pose.dt, self.pose.dR, self.exposure]
-        self._loss_fn = tracking_loss_and_grads
-        self.graph = None
-        self.loss = None
-        self._validate = validate
-        self.device_optimizer = device_optimizer
-        self.max_eval = max_eval
-        self._state = self._report = None
-        self.fused_tail = bool(device_optimizer) and os.environ.get("GSX_TRACK_TAIL", "fused") != "split"
-        if device_optimizer:
-            from ._lib import lib
-            self._state = torch.zeros(int(lib.gsx_track_opt_state_bytes()), dtype=torch.uint8, device=dev)
-            self._report = torch.zeros(8, dtype=torch.float32, device=dev)
-            # the view matrix the fused closure renders with: written by the closure's own tail for the next evaluation
-            self._viewmat = torch.zeros(1, 4, 4, device=dev, requires_grad=True)
-            self._viewmat._gsx_partials_only = True
+        self._grads = [c.g_dt, c.g_dR, c.g_exposure]
+        self._state, self._report = c.state, c.report
+        self.loss = c.loss
+        self._retrying = False
 
-    def _closure_body(self, advance: bool = False):
-        if advance and self.fused_tail:
-            return self._closure_fused()
-        for p in self.params:
-            p.grad = None               # AccumulateGrad then adopts the fresh gradient tensor (no accumulate kernel)
-        # the reference renders the depth channel in its tracking closure too (frontend.py:627-631) but only reads it
-        # under use_gt_depths (frontend.py:134-137), which this tracker does not implement: four channels instead of five
-        out = self.splats([self.camera], [self.pose], render_depth=False, need_n_touched=False)  # n_touched: never read
-        # value and analytic gradient in one pass (csrc/loss.hip); the backward is seeded at the render tensor
-        out2, v_render, v_exposure = self._loss_fn(out, self.img, self.exposure)
-        torch.autograd.backward([out._render], [v_render])
-        self.exposure.grad = v_exposure
-        loss = out2[0:1]
-        if advance:
-            import ctypes as C
-            from ._lib import check, lib, stream_ptr
-            n = len(self.params)
-            check(lib.gsx_track_opt_advance(
-                self._state.data_ptr(), n, (C.c_void_p * n)(*[p.data_ptr() for p in self.params]),
-                (C.c_void_p * n)(*[p.grad.data_ptr() for p in self.params]),
-                (C.c_int * n)(*[p.numel() for p in self.params]), loss.data_ptr(),
-                stream_ptr(loss.device)), "gsx_track_opt_advance")
-        return loss
+    @property
+    def graph(self):
+        return self.plan.graph if self.plan.graph.captured else None
 
-    def _closure_fused(self):
-        """the captured closure of the device optimiser: renders with the persistent view matrix, and ONE launch takes
-        the projection backward's pose partials through the PoseZhou backward, the optimiser step and the PoseZhou
-        forward of the new parameters (csrc/track_opt_impl.inc: track_opt_tail_kernel) - no autograd node and no
-        launch of its own for the pose on either side of the render"""
-        from ._lib import check, lib, stream_ptr
-        from .ops import workspace
-        out = self.splats._render([self.camera], self._viewmat, 'RGB', 0.5, need_n_touched=False)
-        (loss_ws, n_rows, coef), v_render, _ = self._loss_fn(out, self.img, self.exposure, finish=False)
-        torch.autograd.backward([out._render], [v_render])      # ends with the pose partials in the workspace
-        N = int(self.splats.means.shape[0])
-        dev = v_render.device
-        ws = workspace(lib.gsx_project_bwd_workspace_bytes(N, 1), dev, "proj_bwd")
-        check(lib.gsx_track_opt_tail(self._state.data_ptr(), ws.data_ptr(), int(lib.gsx_project_bwd_blocks(N)),
-                                     self.pose.Rt.data_ptr(), self.pose.dt.data_ptr(), self.pose.dR.data_ptr(),
-                                     self.exposure.data_ptr(), None, None, self._viewmat.data_ptr(),
-                                     loss_ws.data_ptr(), n_rows, coef, stream_ptr(dev)), "gsx_track_opt_tail")
-        return None
+    def matches(self, splats) -> bool:
+        return self.plan.r.matches(splats)
 
     def load(self, frame: Frame, prev_exposure: Optional[torch.Tensor] = None):
-        with torch.no_grad():
-            self.pose.Rt.copy_(frame.pose())
-            self.pose.dR.zero_()
-            self.pose.dt.zero_()
-            self.img.copy_(frame.img)
-            self.exposure.copy_(frame.exposure_params if prev_exposure is None else prev_exposure)
-            if self.device_optimizer:
-                self._viewmat.copy_(self.pose.Rt[None])               # dR = dt = 0: the first evaluation's view matrix
+        exposure = frame.exposure_params if prev_exposure is None else prev_exposure
+        self.plan.load(frame.pose().detach(), frame.img, exposure.detach())
 
     def capture(self):
+        """probe the tile-list capacity for the loaded frame, warm up and record the closure (the slot is left as loaded)"""
         from ._sync import capture_lock
         with capture_lock:
-            self._capture()
-
-    def _capture(self):
-        # warm-up and capture run on the SAME side stream: autograd pins each leaf's AccumulateGrad node to the stream
-        # it was first used on, and a capture on another stream would push the accumulation out of the graph
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        sig = (int(self.splats.means.shape[0]), 1, int(self.camera.width), int(self.camera.height))
-        with torch.cuda.stream(side):
-            for attempt in range(4):                    # a warm-up render that overflowed has grown the capacity
-                for _ in range(2):
-                    self._closure_body()
-                if self._validate(signature=sig):
-                    break
-            else:
-                raise RuntimeError("intersection capacity keeps changing during warm-up")
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: a backend thread of the same process may be allocating / synchronising on its own stream
-        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
-            self.loss = self._closure_body(advance=self.device_optimizer)
+            self.plan.prepare()
 
     def closure(self):
-        if self.graph is None:
-            return self._closure_body()
-        self.graph.replay()
+        """one evaluation at the slot's current parameters: loss [1] on the device; with the host optimiser the
+        gradients are attached to ``self.params``"""
+        if self.plan.graph.captured:
+            self.plan.graph.replay()
+        else:
+            if self.plan.r.capacity == 0:
+                self.plan.r.probe()
+            from .plan import current_stream_ptr
+            self.plan.enqueue(current_stream_ptr(self.plan.dev))
+        if not self.device_optimizer:
+            for p, g in zip(self.params, self._grads):
+                p.grad = g
         return self.loss
 
     def _write_back(self, frame: Frame):
@@ -253,34 +202,26 @@ class GraphedTracker:
               sync: bool = True):
         """igs_track_lbfgs on the slot; writes the optimised pose / exposure back into ``frame``.  Returns
         (last_loss, n_closures); with the device optimiser and ``sync=False`` both are left on the device (the
-        8-float report tensor of gsx_track_opt_report is returned instead) and the call does not block."""
+        8-float report tensor of gsx_track_opt_report is returned instead) and the call does not block - the caller
+        then polls ``capacity_ok()`` now and then."""
         conf = self.conf
         self.load(frame, prev_exposure)
-        if self.graph is None:
+        if not self.plan.graph.captured or self.plan.r.stale:
             self.capture()
             self.load(frame, prev_exposure)
         if self.device_optimizer:
-            from ._lib import check, lib, stream_ptr
-            dev = self.img.device
-            me = self.max_eval if max_eval is None else max_eval
-            n_par = sum(p.numel() for p in self.params)
-            # torch.optim.LBFGS defaults of the reference call (frontend.py:613-619): max_iter 20, tolerance_grad 1e-7
-            check(lib.gsx_track_opt_init(self._state.data_ptr(), n_par, conf.n_adam_warmup, conf.pose_optim_lr,
-                                         conf.pose_optim_lr, conf.lbfgs_history, 20, me, 1e-7, 1e-9, stream_ptr(dev)),
-                  "gsx_track_opt_init")
-            for _ in range(conf.n_adam_warmup + me + 1):   # a line search may overshoot max_eval by one evaluation
-                self.graph.replay()
-            check(lib.gsx_track_opt_report(self._state.data_ptr(), self._report.data_ptr(), stream_ptr(dev)),
-                  "gsx_track_opt_report")
+            me = self.max_eval if max_eval is None else int(max_eval)
+            self.plan.init_optimizer(conf.n_adam_warmup, conf.pose_optim_lr, conf.lbfgs_history, me)
+            # a line search may overshoot max_eval by one evaluation
+            self.plan.graph.launch(count=conf.n_adam_warmup + me + 1)
+            rep = self.plan.read_report()
             if not sync:
                 self._write_back(frame)
-                return self._report
-            rep = self._report.cpu()
+                return rep
+            rep = rep.cpu()
             # the map under the captured closure changes between frames (BA updates, in-place SYNC): if its tile lists
             # outgrew the capacity baked into the graph, re-capture with the grown buffers and track this frame again
-            sig = (int(self.splats.means.shape[0]), 1, int(self.camera.width), int(self.camera.height))
-            if not self._validate(signature=sig) and not getattr(self, "_retrying", False):
-                self.graph = None
+            if not self.plan.r.check_capacity() and not self._retrying:
                 self._retrying = True
                 try:
                     return self.track(frame, prev_exposure, max_eval, sync)
@@ -306,5 +247,15 @@ class GraphedTracker:
         lbfgs = torch.optim.LBFGS(self.params, history_size=conf.lbfgs_history, line_search_fn='strong_wolfe',
                                   tolerance_change=1e-9, lr=conf.pose_optim_lr, **kw)
         lbfgs.step(closure)
+        if not self.plan.r.check_capacity() and not self._retrying:
+            self._retrying = True
+            try:
+                return self.track(frame, prev_exposure, max_eval, sync)
+            finally:
+                self._retrying = False
         self._write_back(frame)
         return last, n_evals
+
+    def capacity_ok(self) -> bool:
+        """blocking check of the sticky overflow status (for callers of ``track(sync=False)``)"""
+        return self.plan.r.check_capacity()

@@ -317,6 +317,27 @@ int gsx_gather_rows(int n_tensors, const void *const *src, void *const *dst, con
 int gsx_concat_rows(int n_tensors, const void *const *a, int64_t n_a, const void *const *b, int64_t n_b,
                     void *const *dst, const int *row_words, void *stream);
 
+/* ---- streams and HIP graphs (csrc/runtime.hip).  A closure of the tracking / mapping optimisers is a fixed chain of the
+ * launches above over caller-owned persistent buffers; it is recorded once by capturing the stream it is issued on and
+ * replayed with one call - what replaces the reference's per-iteration Python loops (gslam/frontend.py:621-658,
+ * gslam/backend.py:260-359,465-504).  Nothing may be allocated, freed or synchronised on the capturing thread between
+ * gsx_graph_begin and gsx_graph_end.  capture mode: 0 global, 1 thread-local, 2 relaxed (hipStreamCaptureMode). */
+int gsx_stream_create(void **stream_out);                    /* non-blocking stream */
+int gsx_stream_destroy(void *stream);
+int gsx_stream_synchronize(void *stream);
+int gsx_stream_wait_stream(void *stream, void *other);       /* device-side: `stream` waits for what `other` holds now */
+int gsx_graph_begin(void *stream, int mode);
+int gsx_graph_end(void *stream, void **exec_out, int64_t *n_nodes_out /*nullable*/);
+int gsx_graph_abort(void *stream);                           /* leave capture mode after a failed launch; no graph */
+int gsx_graph_launch(void *exec, void *stream);
+int gsx_graph_launch_n(void *exec, int count, void *stream); /* count launches back to back */
+int gsx_graph_destroy(void *exec);
+/* pinned, device-mapped host memory (zeroed): kernels write status words the host polls without a stream sync */
+int gsx_host_alloc(void **host_out, void **dev_out, int64_t bytes);
+int gsx_host_free(void *host);
+/* n_words 4-byte words at ptr := 0, by a kernel (a captured hipMemsetAsync node misbehaved on replay, ROCm 7.2) */
+int gsx_zero_words(void *ptr, int64_t n_words, void *stream);
+
 /* ---- self tests of device primitives (wave64 reductions); returns 0 if all pass.  scratch: >= 64 KiB device ----- */
 int gsx_selftest(void *scratch, int64_t scratch_bytes, void *stream);
 

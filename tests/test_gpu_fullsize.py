@@ -192,24 +192,23 @@ def test_raster_properties_full_size(dev, n, c, W, H, ch):
 
 def test_full_pipeline_500k_sync_free_equals_reference_shaped(dev):
     """config 3: fused gslam rasterization at 500 k; sync-free path == reference-shaped path (M read back)"""
-    from gslam_amd.rasterization import rasterization, validate
+    from gslam_amd.rasterization import IsectCapacity, rasterization
     from gslam_amd.synthetic import make_cameras, make_scene
     n, W, H = 500_000, 640, 480
     sc = {k: v.to(dev) for k, v in make_scene(n, 0).items()}
     viewmats, Ks = make_cameras(1, W, H)
     viewmats, Ks = viewmats.to(dev), Ks.to(dev)
 
-    def run():
+    def run(capacity):
         return rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], viewmats, Ks, W, H,
                              packed=False, render_mode="RGB+D", log_uncertainties=sc["log_uncertainties"],
-                             backgrounds=torch.zeros(1, 3, device=dev))
-    a = run()
-    assert validate(dev)
-    os.environ["GSX_SYNC_ISECT"] = "1"
-    try:
-        b = run()
-    finally:
-        os.environ["GSX_SYNC_ISECT"] = "0"
+                             backgrounds=torch.zeros(1, 3, device=dev), capacity=capacity)
+    cap = IsectCapacity(dev)
+    a = run(cap)
+    a2 = run(cap)                                   # second render of the shape: no probe, no read-back
+    assert cap.validate() and cap.last_M == int(a.tiles_per_gauss.sum())
+    assert torch.equal(a.rgbs, a2.rgbs)
+    b = run(None)                                   # default: exact sizes from one read-back of M, like the reference
     assert torch.equal(a.flatten_ids, b.flatten_ids) and torch.equal(a.isect_ids, b.isect_ids)
     assert torch.equal(a.isect_offsets, b.isect_offsets) and torch.equal(a.radii, b.radii)
     assert torch.equal(a.rgbs, b.rgbs) and torch.equal(a.n_touched, b.n_touched)

@@ -1,0 +1,207 @@
+"""Launch plans (gslam_amd/plan.py) against the autograd-shaped operators they replace in the optimisation loops: same
+C-ABI launches, so the numbers must agree to float noise (atomics in the rasteriser backward).  Also the regression test
+for the round-1 crash: the window pose refiner run in the context the SLAM loop runs it in (eager BA on the default
+stream first, then the refiner, then a prune that re-packs the map, then the refiner again).  Run with -m gpu."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _world(dev, n=20000, W=320, H=240, seed=0):
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.primitives import Camera, Frame, PoseZhou
+    from gslam_amd.synthetic import make_intrinsics, make_scene, make_viewmat
+    K = make_intrinsics(W, H).to(dev)
+    cam = Camera(K, H, W)
+    sc = make_scene(n, seed)
+    sc["scales"] = sc["scales"] + 0.4
+    m = GaussianSplattingData.from_dict(sc, dev)
+
+    def frame(i, start, index=None):
+        V = make_viewmat(i).to(dev)
+        with torch.no_grad():
+            img = m([cam], [PoseZhou(V, is_learnable=False).to(dev)], render_depth=False).rgbs[0].clamp(0, 1)
+        V0 = make_viewmat(start).to(dev)
+        return Frame(img=img.contiguous(), timestamp=0.0, camera=cam, pose=PoseZhou(V0).to(dev), gt_pose=V,
+                     index=i if index is None else index, exposure_params=torch.zeros(2, device=dev))
+    return m, cam, frame
+
+
+def test_hip_graph_runtime_roundtrip(dev):
+    """csrc/runtime.hip: capture a chain of libgsx launches on an own stream, instantiate, replay on another stream"""
+    import ctypes as C
+    from gslam_amd._lib import check, lib
+    from gslam_amd.plan import HipGraph
+    buf = torch.ones(1000, dtype=torch.int32, device=dev)
+    ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+    s = torch.cuda.Stream()
+
+    def chain(st):
+        check(lib.gsx_zero_words(buf.data_ptr(), 500, st), "zero")
+        check(lib.gsx_counters_add(1, (C.c_void_p * 1)(ctr.data_ptr()), 3, st), "add")
+    g = HipGraph()
+    torch.cuda.synchronize()
+    g.capture(s, chain)
+    torch.cuda.synchronize()
+    assert g.captured and g.nodes == 2
+    assert int(buf.sum()) == 1000 and int(ctr) == 0                       # capturing did not execute anything
+    g.launch(count=4)
+    torch.cuda.synchronize()
+    assert int(buf[:500].sum()) == 0 and int(buf[500:].sum()) == 500 and int(ctr) == 12
+    g.destroy()
+    assert not g.captured
+    # pinned, device-mapped host words
+    h, d = C.c_void_p(), C.c_void_p()
+    check(lib.gsx_host_alloc(C.byref(h), C.byref(d), 64), "host_alloc")
+    assert h.value and d.value
+    check(lib.gsx_host_free(h), "host_free")
+
+
+def test_track_closure_matches_autograd_operators(dev):
+    """TrackClosure (host tail) == splats(...) + tracking loss + backward through the autograd operators"""
+    from gslam_amd.losses import fused_tracking_loss
+    from gslam_amd.plan import TrackClosure, current_stream_ptr
+    from gslam_amd.primitives import PoseZhou
+    m, cam, frame = _world(dev)
+    mf = m.no_grad_clone()
+    f = frame(2, 1)
+    exposure = torch.tensor([0.05, -0.02], device=dev)
+    # autograd-shaped
+    pose = PoseZhou(f.pose.Rt.clone()).to(dev)
+    with torch.no_grad():
+        pose.dR.copy_(torch.tensor([0.01, -0.02, 0.005, 0.0, 0.01, -0.01], device=dev))
+        pose.dt.copy_(torch.tensor([0.02, -0.01, 0.015], device=dev))
+    ex = exposure.clone().requires_grad_(True)
+    out = mf([cam], [pose], render_depth=False, need_n_touched=False)
+    loss = fused_tracking_loss(out, f.img, ex)
+    loss.backward()
+    # plan
+    c = TrackClosure(mf, cam, tail='host')
+    c.load(f.pose.Rt, f.img, exposure)
+    with torch.no_grad():
+        c.dR.copy_(pose.dR)
+        c.dt.copy_(pose.dt)
+    c.r.probe()
+    c.enqueue(current_stream_ptr(dev))
+    torch.cuda.synchronize()
+    assert c.r.check_capacity()
+    assert torch.equal(c.r.radii, out.radii) and torch.equal(c.r.render, out._render)
+    assert abs(float(c.loss) - float(loss)) < 1e-6 * abs(float(loss))
+    for a, b in ((c.g_dR, pose.dR.grad), (c.g_dt, pose.dt.grad), (c.g_exposure, ex.grad)):
+        assert (a - b).abs().max() < 2e-4 * b.abs().max() + 1e-9, (a, b)
+    # captured and replayed: same numbers, idempotent
+    c.prepare()
+    vals = []
+    for _ in range(3):
+        c.graph.replay()
+        torch.cuda.synchronize()
+        vals.append((float(c.loss), c.g_dR.clone(), c.g_dt.clone()))
+    assert c.r.check_capacity()
+    for v, gr, gt in vals:
+        assert abs(v - float(loss)) < 1e-6 * abs(float(loss))
+        assert (gr - pose.dR.grad).abs().max() < 2e-4 * pose.dR.grad.abs().max() + 1e-9
+
+
+def test_mapping_step_plan_matches_autograd_step(dev):
+    """MappingStep (eager launches and graph replay) == BundleAdjuster.step on the autograd operators: loss values, every
+    map gradient, the pose gradients, and the parameters after the update"""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.mapping import BundleAdjuster
+    from gslam_amd.primitives import Camera, Frame, PoseZhou
+    from gslam_amd.synthetic import make_cameras, make_scene
+    n, W, H = 6000, 320, 240
+    sc = make_scene(n, 11)
+    sc["scales"] = sc["scales"] + 0.5
+    viewmats, Ks = make_cameras(3, W, H)
+    gt = torch.rand(3, H, W, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+
+    def build(capturable):
+        splats = GaussianSplattingData.from_dict(sc, dev)
+        window = [Frame(img=gt[i].contiguous(), timestamp=0.0, camera=Camera(Ks[i].to(dev), H, W),
+                        pose=PoseZhou(viewmats[i].to(dev), is_learnable=(i != 0)).to(dev), gt_pose=viewmats[i].to(dev),
+                        index=i, exposure_params=torch.tensor([0.03 * i, -0.01 * i], device=dev)) for i in range(3)]
+        return splats, window, BundleAdjuster(splats, capturable=capturable)
+
+    sa, wa, ba = build(False)
+    ta, pa = ba.render_backward(wa)
+    grads_a = {k: getattr(sa, k).grad.clone() for k in ("means", "quats", "scales", "opacities", "colors",
+                                                         "log_uncertainties")}
+    pose_a = [(f.pose.dR.grad.clone(), f.pose.dt.grad.clone()) for f in wa[1:]]
+    ba.update()
+    sb, wb, bb = build(True)
+    plan = bb.plan(wb)
+    assert plan.learnable == [False, True, True] and plan.mine == [0, 1, 2]
+    tb, pb = plan.render_backward()
+    torch.cuda.synchronize()
+    assert plan.capacity_ok()
+    assert abs(float(ta) - float(tb)) < 1e-5 * abs(float(ta)) and abs(float(pa) - float(pb)) < 1e-5 * abs(float(pa))
+    for k, ga in grads_a.items():
+        gb = plan.grad_views[k]
+        assert (ga - gb).abs().max() < 2e-4 * ga.abs().max() + 1e-10, k
+    for (gr, gtv), i in zip(pose_a, (1, 2)):
+        assert (plan.g_dR[i] - gr).abs().max() < 1e-3 * gr.abs().max() + 1e-9
+        assert (plan.g_dt[i] - gtv).abs().max() < 1e-3 * gtv.abs().max() + 1e-9
+    out = plan.as_output()
+    assert out.means2d.grad.shape == (3, n, 2) and out.depthmaps.shape == (3, H, W) and out.radii.shape == (3, n)
+    assert torch.equal(out.radii, ba.last_outputs.radii)
+    # the update: one graph replay from the same start (the eager render_backward above did not touch the parameters)
+    plan.step()
+    torch.cuda.synchronize()
+    assert plan.graph.captured and plan.capacity_ok()
+    for k in grads_a:
+        a, b = getattr(sa, k), getattr(sb, k)
+        assert (a - b).abs().mean() < 2e-5, (k, float((a - b).abs().mean()))
+    assert (wa[1].pose.dR - wb[1].pose.dR).abs().max() < 1e-3
+    assert torch.equal(wb[0].pose.dR, torch.zeros_like(wb[0].pose.dR))            # the fixed pose did not move
+
+
+def test_refiner_after_eager_ba_and_prune(dev):
+    """Regression for the round-1 SIGSEGV (GraphedPoseRefiner.capture inside Backend.idle_step): eager autograd BA over the
+    keyframes' own poses on the default stream, then the refiner on the same keyframes, then a prune that re-packs the
+    map (new tensors, new N), then the refiner again on a slid window.  The refiner owns its pose slots and its stream
+    and records plain launches, so neither the autograd history of the poses nor the re-pack can reach its capture."""
+    from gslam_amd.mapping import BundleAdjuster, GraphedPoseRefiner
+    from gslam_amd.pruning import prune_using_mask
+    m, cam, frame = _world(dev, n=15000)
+    window = [frame(0, 0, index=0), frame(2, 1), frame(4, 3), frame(6, 5)]
+    for p in window[0].pose.parameters():
+        p.requires_grad_(False)
+    ba = BundleAdjuster(m, capturable=True)
+    for _ in range(3):                                     # leaves AccumulateGrad history on the window's pose leaves
+        ba.step(window)
+    assert ba.last_outputs is not None                      # the autograd graph of the last step is still referenced
+    ref = GraphedPoseRefiner(m, window)
+    before = [float((f.pose()[:3, 3] - f.gt_pose[:3, 3]).norm()) for f in window]
+    loss1, n1 = ref.run(window)
+    torch.cuda.synchronize()
+    assert 2 <= n1 <= 26 and loss1 == loss1
+    g1 = ref.graph
+    loss1b, _ = ref.run(window)                             # same window again: same graph
+    assert ref.graph is g1
+    # prune a third of the map: new parameter tensors -> the old refiner no longer matches, a new one is built
+    keep = torch.rand(m.means.shape[0], device=dev) > 0.33
+    assert prune_using_mask(m, ba.optimizers, keep) > 0
+    ba.map_changed()
+    assert not ref.matches(m, window)
+    window2 = window[1:] + [frame(8, 7)]                    # slid window: no fixed frame any more
+    ref2 = GraphedPoseRefiner(m, window2)
+    loss2, n2 = ref2.run(window2)
+    torch.cuda.synchronize()
+    assert 2 <= n2 <= 26 and loss2 == loss2
+    # the same refiner serves another window of the same shape without re-capturing
+    window3 = window2[1:] + [frame(10, 9)]
+    g2 = ref2.graph
+    assert ref2.matches(m, window3)
+    ref2.run(window3)
+    assert ref2.graph is g2
+    ba.step(window2)                                         # and eager BA still works afterwards
+    torch.cuda.synchronize()
+    after = [float((f.pose()[:3, 3] - f.gt_pose[:3, 3]).norm()) for f in window]
+    assert after[0] == before[0]                             # frame 0 fixed (backend.py:459-462)

@@ -152,27 +152,47 @@ def _worker(rank, world, port, q):
     r, w = gdist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
 
-    class Splats:                                   # stands in for GaussianSplattingData on the CPU
-        pass
-    n = 50
-    sp = Splats()
-    gen = torch.Generator().manual_seed(0)
-    for name, shape in zip(gdist.GRAD_PARAMS, [(n, 3), (n, 4), (n, 3), (n,), (n, 3), (n,)]):
-        setattr(sp, name, torch.randn(shape, generator=gen).requires_grad_(True))
+    n, cw = 50, 5                                   # 5 keyframes over 2 ranks -> 3 + 2
+    shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 3), (n,)]
     shard = gdist.KeyframeShard()
-    window = list(range(5))                         # 5 keyframes over 2 ranks -> 3 + 2
+    window = list(range(cw))
     mine = shard.select(window)
     assert mine == [i for i in window if i % world == rank]
-    bucket = gdist.GradBucket(sp)
-    bucket.attach_zeroed()
-    # per-camera "loss": mean over the window of a function of the camera index (the C_local/C rule of SURVEY §8e)
-    loss = sum(((getattr(sp, nm) * (c + 1)).sum() for c in mine for nm in gdist.GRAD_PARAMS)) / len(window)
-    loss.backward()
-    assert sp.means.grad.data_ptr() == bucket.views[0].data_ptr()      # autograd accumulated straight into the bucket
-    bucket.all_reduce()
+    bucket = gdist.StepBucket(shapes, cw, "cpu")
+    assert bucket.flat.numel() == n * 15 + n + cw * 9 + 2 and bucket.world_size == world
+    assert [tuple(v.shape) for v in bucket.views] == shapes
+    # what a rank's launch plan writes: map gradients of its cameras (per-camera mean rule C_local / C of SURVEY 8e folded
+    # into the weights), its cameras' pose rows, its share of the loss; rows of other ranks' cameras stay zero
+    for v in bucket.views:
+        v.fill_(sum(c + 1 for c in mine) / cw)
+    for c in mine:
+        bucket.g_dt[c] = float(c + 1)
+        bucket.g_dR[c] = float(10 * (c + 1))
+    bucket.out2[0] = float(len(mine))
+    bucket.out2[1] = 0.5 * len(mine)
+    local_vis = torch.full((n,), len(mine), dtype=torch.int32)
+    bucket.reduce(local_vis)
+    expect = sum(c + 1 for c in window) / cw
+    ok = all(torch.allclose(v, torch.full_like(v, expect)) for v in bucket.views)
+    ok = ok and torch.equal(bucket.vis_i32, torch.full((n,), cw, dtype=torch.int32))
+    ok = ok and torch.equal(bucket.g_dt[:, 0], torch.arange(1, cw + 1, dtype=torch.float32))
+    ok = ok and torch.equal(bucket.g_dR[:, 5], 10.0 * torch.arange(1, cw + 1, dtype=torch.float32))
+    ok = ok and float(bucket.out2[0]) == cw and float(bucket.out2[1]) == 0.5 * cw
+    # a window shorter than the world: the rank without cameras contributes zeros and still joins the collective
+    b2 = gdist.StepBucket(shapes, 1, "cpu")
+    if rank == 0:
+        for v in b2.views:
+            v.fill_(2.0)
+        b2.g_dt[0] = 3.0
+        b2.reduce(torch.ones(n, dtype=torch.int32))
+    else:
+        for v in b2.views:
+            v.fill_(123.0)                           # stale values of an earlier window must not leak into the sum
+        b2.tail.zero_()                              # (the plan's first launch of an iteration clears the tail)
+        b2.reduce(None)
+    ok = ok and all(torch.equal(v, torch.full_like(v, 2.0)) for v in b2.views)
+    ok = ok and torch.equal(b2.vis_i32, torch.ones(n, dtype=torch.int32)) and float(b2.g_dt[0, 0]) == 3.0
     vis = shard.all_reduce_sum(torch.tensor([len(mine)], dtype=torch.int32))
-    expect = sum(c + 1 for c in window) / len(window)
-    ok = all(torch.allclose(getattr(sp, nm).grad, torch.full_like(getattr(sp, nm), expect)) for nm in gdist.GRAD_PARAMS)
     mx = shard.all_reduce_max(torch.tensor([rank]))
     t = torch.tensor([float(rank)])
     shard.broadcast_([t], src=1)
@@ -194,4 +214,4 @@ def test_keyframe_sharded_ba_collectives_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, ok, vis, mx, t, numel in res:
-        assert ok and vis == 5 and mx == 1 and t == 1.0 and numel == 50 * 16   # 15 gradient columns + the count column
+        assert ok and vis == 5 and mx == 1 and t == 1.0 and numel == 50 * 16 + 5 * 9 + 2
