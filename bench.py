@@ -1,17 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the gslam hot path on MI355X (contract: see the task prompt / DESIGN.md §Measurement).
+"""bench.py — headline benchmark of the gslam hot path on MI355X (contract: the task prompt / DESIGN.md §Measurement).
 
-A "step" is one keyframe bundle-adjustment iteration of the reference's mapping loop (gslam/backend.py:260-359) on
-synthetic TUM-shape input: differentiable render forward (RGB + depth + beta, CH = 5) of the window's keyframes ->
-loss (active-NeRF photometric + 0.2*(1-fused_ssim 'valid') + isotropic + edge-aware depth TV) -> backward through
-K9/K2 -> [all-reduce of the [N,15] gradient bucket when N_gpus > 1] -> fused Adam on the six splat tensors + poses
--> opacity decay.  Nothing is skipped inside the timed region.
+--gpus 1 (default) = BASELINE.json configs[2], the configuration the metric is quoted on: tracking + mapping at 640x480 with
+500 k Gaussians on ONE GPU, synthetic TUM-shape sequence, the reference's iteration counts:
 
-Workload (BASELINE.json configs[1]): 100 k Gaussians, 640x480, one keyframe per GPU (weak scaling: the window has
-n_gpus keyframes, every rank renders one against its replica of the map).  value = keyframe renders fwd+bwd per second
-over the whole job.  Inputs are resident in HBM before the timed region.
+  * a "step" is one tracked frame: 10 Adam closures + one strong-Wolfe L-BFGS step of <= 25 (+1) closures on the pose and
+    exposure (gslam/frontend.py:604-662) = 36 launches of the captured tracking closure (C = 1 render forward, active-nerf
+    loss, backward to the pose; the optimiser is a device state machine, no read-back), plus the frame's output render
+    (frontend.py:228-231, forward only, RGB + depth);
+  * every 5th frame is a keyframe: the backend runs 15 bundle-adjustment iterations over the last 8 keyframes
+    (gslam/backend.py:71-74,260-359: render CH = 5, active-nerf + fused-SSIM + isotropic + depth-TV loss, backward, six
+    splat Adams + pose Adam + opacity decay) on its own HIP stream beside the tracker - as the reference's backend process
+    does beside its frontend process on the same device - and then ships the map to the frontend (SYNC, backend.py:508-519)
+    through the device mailbox of gslam_amd.transport; the tracker picks it up at the next frame boundary.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--gaussians 100000] [--no-cpu-baseline]
+  value = frames / s with everything above inside the timed region (inputs resident in HBM).  Nothing is skipped: the 36
+  closure launches are issued for every frame whether or not the line search converged earlier.
+
+--gpus G > 1 = BASELINE.json configs[3], STRONG scaling of keyframe bundle adjustment: 2 M Gaussians, a fixed window of 8
+keyframes dealt round-robin over the G ranks, one all-reduce of the step bucket (map + pose gradients, visibility counts,
+loss) per iteration over RCCL; value = keyframe renders (forward + backward) per second over the whole job = 8 x BA
+iterations / s.  The 1-GPU value of the SAME workload is measured by the --gpus 1 run as well and reported there as
+``extra.ba_2m_window8`` so that the scaling curve has its 1-GPU point next to the headline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 from __future__ import annotations
@@ -28,48 +40,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+N_ADAM, MAX_EVAL, KF_EVERY, BA_ITERS, WINDOW = 10, 25, 5, 15, 8     # frontend.py:651, torch LBFGS max_eval, backend.py:864,74,71
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)   # the first ~50 steps after an idle GPU run ~6 % slow (clock ramp)
-    ap.add_argument("--gaussians", type=int, default=100_000)
+    ap.add_argument("--steps", type=int, default=None, help="frames (1 GPU; default 100) / BA iterations (G > 1; default 60)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 10")
+    ap.add_argument("--gaussians", type=int, default=None, help="default 500000 (1 GPU) / 2000000 (G > 1)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads of the 1-GPU line")
+    ap.add_argument("--ba-only", action="store_true", help="1 GPU: run the G > 1 workload (configs[3]) on one GPU")
     return ap.parse_args()
 
 
-def make_window(n_frames, W, H, dev, gt_scene, own):
-    """Synthetic keyframes: pose c = 0.05*c m along x + 1 deg*c yaw; gt = render of scene(seed+1)."""
+def make_frames(indices, W, H, dev, gt_scene, learnable=True):
+    """Synthetic frames: pose c = 0.05*c m along x + 1 deg*c yaw; image = render of scene(seed+1)."""
     from gslam_amd.primitives import Camera, Frame, PoseZhou
     from gslam_amd.synthetic import make_intrinsics, make_viewmat
     K = make_intrinsics(W, H).to(dev)
+    cam = Camera(K, H, W)
     frames = []
-    for c in range(n_frames):
+    for c in indices:
         V = make_viewmat(c).to(dev)
-        pose = PoseZhou(V, is_learnable=True).to(dev)
-        img = None
-        if c in own:
-            with torch.no_grad():
-                out = gt_scene([Camera(K, H, W)], [pose], render_depth=False)
-                img = out.rgbs[0].clamp(0, 1).contiguous()
-        frames.append(Frame(img=img, timestamp=c / 30.0, camera=Camera(K, H, W), pose=pose, gt_pose=V, index=c,
-                            exposure_params=torch.zeros(2, device=dev)))
-    return frames
+        with torch.no_grad():
+            img = gt_scene([cam], [PoseZhou(V, is_learnable=False).to(dev)], render_depth=False).rgbs[0].clamp(0, 1)
+        frames.append(Frame(img=img.contiguous(), timestamp=c / 30.0, camera=cam, pose=PoseZhou(V, is_learnable=learnable).to(dev),
+                            gt_pose=V, index=c, exposure_params=torch.zeros(2, device=dev)))
+    return frames, cam
 
 
 class StageTimer:
-    """Times every C-ABI launch with HIP events on the stream the kernels are launched on (torch's current stream)."""
-    STAGES = ("gsx_pose_zhou_fwd", "gsx_project_fwd", "gsx_isect_bin_sort", "gsx_isect_scan", "gsx_isect_emit_sort",
-              "gsx_isect_offset_encode", "gsx_raster_fwd", "gsx_ssim_fwd", "gsx_ssim_bwd", "gsx_map_loss",
-              "gsx_raster_bwd", "gsx_project_bwd", "gsx_pose_zhou_bwd", "gsx_isotropic_loss", "gsx_isotropic_loss_acc",
-              "gsx_loss_finish", "gsx_counters_add", "gsx_adam_multi", "gsx_adam_multi_steps",
-              "gsx_adam_multi_steps_decay", "gsx_opacity_decay")
+    """Times every C-ABI launch with HIP events on the stream the kernels are launched on (torch's current stream: the
+    instrumented passes issue their plans' launches there)."""
+    STAGES = ("gsx_pose_zhou_fwd", "gsx_project_fwd", "gsx_isect_bin_sort", "gsx_raster_fwd", "gsx_ssim_fwd",
+              "gsx_ssim_bwd", "gsx_map_loss", "gsx_raster_bwd", "gsx_project_bwd", "gsx_pose_zhou_bwd_partials",
+              "gsx_isotropic_loss_acc", "gsx_loss_finish", "gsx_counters_add", "gsx_adam_multi_steps",
+              "gsx_adam_multi_steps_decay", "gsx_track_opt_tail")
 
     def __init__(self):
         self.events = {s: [] for s in self.STAGES}
@@ -101,34 +112,282 @@ class StageTimer:
     def mean_us(self, skip=0):
         out = {}
         for s, ev in self.events.items():
-            ts = [a.elapsed_time(b) * 1e3 for a, b in ev]
-            per_step = ts[skip:]
-            if per_step:
-                out[s] = sum(per_step) / len(per_step)
+            ts = [a.elapsed_time(b) * 1e3 for a, b in ev][skip:]
+            if ts:
+                out[s] = sum(ts) / len(ts)
         return out
 
 
-def algorithmic_bytes(N, C, M, P, CH):
+def algorithmic_bytes(N, C, M, P, CH, T):
     """SURVEY.md §8(d) per-launch algorithmic bytes (every array touched once)."""
     return {
         "gsx_project_fwd": C * N * (40 + 28),
-        "gsx_isect_emit_sort": M * 12 + M * 24,
-        "gsx_isect_bin_sort": C * N * 16 * 2 + M * 8 + M * 8 + M * 4,
-        "gsx_map_loss": P * (20 + 4 + 12 + 12 + 20),
-        "gsx_isect_offset_encode": M * 8,
+        "gsx_isect_bin_sort": C * N * 16 + C * N * 4 + M * 12 + M * 24 + M * 8 + T * 4,
+        "gsx_map_loss": P * (4 * CH + 4 + 12 + 4 * CH),
         "gsx_raster_fwd": M * (28 + 4 * CH) + P * (4 * CH + 8) + C * N * 4,
         "gsx_raster_bwd": P * (4 * CH + 12) + M * (28 + 4 * CH) + C * N * (24 + 4 * CH),
         "gsx_project_bwd": C * N * (40 + 28 + 24) + N * 40 + C * 64,
         "gsx_ssim_fwd": 72 * P,
         "gsx_ssim_bwd": 72 * P,
-        "gsx_adam_multi": 420 * N,
         "gsx_adam_multi_steps": 420 * N,
         "gsx_adam_multi_steps_decay": 420 * N + 4 * N,
     }
 
 
-def cpu_baseline(N, W, H, budget_s=25.0):
-    """CPU port (the oracle, scalar C, 1 core) of the same step on the same synthetic inputs; bounded sample."""
+def render_bytes(N, C, M, P, CH, T):
+    """B_fwd + B_bwd of one render forward + backward, SURVEY.md §8(d)"""
+    b_fwd = C * N * 92 + M * (72 + 4 * CH) + P * (4 * CH + 8) + 4 * T
+    b_bwd = C * N * (116 + 4 * CH) + N * 40 + M * (28 + 4 * CH) + P * (4 * CH + 12)
+    return b_fwd, b_bwd
+
+
+def traffic_for(kernel_hint, N):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic_r02.json), or None"""
+    for name in ("traffic_r02.json",):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                tj = json.load(open(path))
+                if tj.get("workload_gaussians") == N and tj.get("stage") == kernel_hint:
+                    return tj.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+    return None
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# 1 GPU: tracking + mapping (configs[2])
+# ------------------------------------------------------------------------------------------------------------------------
+def run_headline(args, dev):
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.mapping import BundleAdjuster, MapConfig
+    from gslam_amd.plan import HipGraph, RenderPlan, current_stream_ptr
+    from gslam_amd.synthetic import make_scene
+    from gslam_amd.tracking import GraphedTracker, TrackingConfig
+    from gslam_amd.transport import MapMailbox, receive
+
+    N = args.gaussians or 500_000
+    W, H = args.width, args.height
+    steps = args.steps or 100
+    warmup = 10 if args.warmup is None else args.warmup
+    gt_scene = GaussianSplattingData.from_dict(make_scene(N, 1), dev)
+    backend_map = GaussianSplattingData.from_dict(make_scene(N, 0), dev)
+    n_frames = warmup + steps
+    frames, cam = make_frames(range(WINDOW + n_frames), W, H, dev, gt_scene)
+    del gt_scene
+    keyframes = frames[:WINDOW]                             # pre-seeded window: BA runs at its full size from the start
+    mailbox = MapMailbox()
+    frontend_map, _ = receive(None, mailbox.publish(backend_map))      # what SYNC ships (backend.py:508-519)
+    conf = TrackingConfig()
+    tracker = GraphedTracker(frontend_map, cam, conf, device_optimizer=True, max_eval=MAX_EVAL)
+    ba = BundleAdjuster(backend_map, MapConfig(), capturable=True)
+    plan = ba.plan(keyframes)
+    # the frame's output render (frontend.py:228-231): forward only, RGB + depth
+    out_render = RenderPlan(frontend_map, 1, W, H, render_depth=True, grads='none', Ks=cam.intrinsics)
+    out_graph = HipGraph()
+    out_stream = torch.cuda.Stream()
+
+    # ---- warm-up of the machinery (allocations, capacity probes, captures) -------------------------------------------------
+    tracker.track(frames[WINDOW])
+    plan.prepare()
+    out_render.viewmats.copy_(frames[WINDOW].pose().detach()[None])
+    out_render.probe()
+    out_stream.wait_stream(torch.cuda.current_stream())
+    out_graph.capture(out_stream, out_render.forward)
+    torch.cuda.synchronize()
+
+    map_stream, track_stream = torch.cuda.Stream(), torch.cuda.Stream()
+    closures_per_frame = N_ADAM + MAX_EVAL + 1
+
+    def run(first, count):
+        track_stream.wait_stream(torch.cuda.current_stream())
+        map_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(track_stream):
+            return _run(first, count)
+
+    def _run(first, count):
+        pending = None
+        n_ba = n_sync = 0
+        for i in range(first, first + count):
+            f = frames[WINDOW + i]
+            if pending is not None and pending[1].query():          # a SYNC has arrived: one-launch copy, graph survives
+                receive(frontend_map, pending[0])
+                pending = None
+                n_sync += 1
+            tracker.track(f, sync=False)                             # 36 graph launches + report, no read-back
+            out_render.viewmats.copy_(tracker.plan.r.viewmats)       # the tracked pose (left there by the closure's tail)
+            out_graph.launch()
+            if (i + 1) % KF_EVERY == 0:
+                # the backend's map is its own copy; its BA round only waits for the previous one and overlaps the
+                # tracking of the following frames
+                with torch.cuda.stream(map_stream):
+                    for _ in range(BA_ITERS):
+                        plan.step()
+                        n_ba += 1
+                    payload = mailbox.publish(backend_map)
+                pending = (payload, payload._mail_event)
+        torch.cuda.current_stream().wait_stream(map_stream)
+        return n_ba, n_sync
+
+    for attempt in range(3):
+        run(0, warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_ba, n_sync = run(warmup, steps)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        # sync-free renders: a truncated tile list would be skipped work, so an overflowing run is discarded
+        ok = tracker.capacity_ok() and plan.capacity_ok() and out_render.check_capacity()
+        if ok:
+            break
+        print(f"bench.py: tile-list capacity overflow on attempt {attempt}, re-capturing and re-running", file=sys.stderr)
+        tracker.track(frames[WINDOW])
+        plan.prepare()
+        if out_render.stale:
+            out_graph.capture(out_stream, out_render.forward)
+            out_render.stale = False
+        torch.cuda.synchronize()
+    else:
+        raise RuntimeError("tile lists kept overflowing")
+
+    line = {
+        "metric": "tracking+mapping fps @640x480 / 500k Gaussians", "value": round(steps / elapsed, 3), "unit": "frames/s",
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[2]: synthetic TUM-shape 640x480 sequence, 500k Gaussians, full frontend "
+                        "tracking + backend mapping on 1 GPU",
+            "gaussians": N, "width": W, "height": H,
+            "tracking_closures_per_frame": closures_per_frame, "adam_closures": N_ADAM, "lbfgs_max_eval": MAX_EVAL,
+            "output_renders_per_frame": 1, "keyframe_every": KF_EVERY, "ba_iterations_per_keyframe": BA_ITERS,
+            "ba_window": WINDOW, "ba_iterations_timed": n_ba, "map_syncs_timed": n_sync,
+            "parallelism": "1 GPU: tracking stream + mapping stream",
+            "launch": "hip-graph replay (csrc/runtime.hip): tracking closure, BA step, output render",
+        },
+    }
+
+    # ---- tracking alone / mapping alone (serial, for the breakdown) ---------------------------------------------------------
+    f = frames[WINDOW + 1]
+    tracker.track(f, sync=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        tracker.track(f, sync=False)
+    torch.cuda.synchronize()
+    closure_us = (time.perf_counter() - t0) / (5 * closures_per_frame) * 1e6
+    t0 = time.perf_counter()
+    for _ in range(BA_ITERS):
+        plan.step()
+    torch.cuda.synchronize()
+    ba_iter_us = (time.perf_counter() - t0) / BA_ITERS * 1e6
+    M1 = int(tracker.plan.r.M_dev.item())
+    M8 = int(plan.r.M_dev.item())
+    P, T = H * W, tracker.plan.r.T
+    bf, bb = render_bytes(N, 1, M1, P, 4, T)
+    line["closure"] = {"us": round(closure_us, 1), "n_isects": M1, "algorithmic_bytes": int(bf + bb),
+                       "achieved_gbs": round((bf + bb) / closure_us * 1e-3, 1),
+                       "frac_of_hbm_peak": round((bf + bb) / closure_us * 1e-3 / HBM_PEAK_GBS, 4)}
+    bf8, bb8 = render_bytes(N, WINDOW, M8, WINDOW * P, 5, WINDOW * T)
+    ba_bytes = bf8 + bb8 + 2 * 72 * WINDOW * P + 424 * N
+    line["ba_iteration"] = {"us": round(ba_iter_us, 1), "n_isects": M8, "algorithmic_bytes": int(ba_bytes),
+                            "achieved_gbs": round(ba_bytes / ba_iter_us * 1e-3, 1),
+                            "frac_of_hbm_peak": round(ba_bytes / ba_iter_us * 1e-3 / HBM_PEAK_GBS, 4)}
+
+    # ---- per-stage timing of the tracking closure: HIP events on the launch stream, GPU kept busy by a queue of closures ------
+    if not args.no_stage_timing:
+        c = tracker.plan
+        c.load(f.pose().detach(), f.img, f.exposure_params)
+        c.init_optimizer(N_ADAM, conf.pose_optim_lr, conf.lbfgs_history, MAX_EVAL)
+        st = current_stream_ptr(dev)
+        with StageTimer() as timer:
+            for _ in range(30):
+                c.enqueue(st)
+        stages = timer.mean_us(skip=8)
+        algo = algorithmic_bytes(N, 1, M1, P, 4, T)
+        dom = max((s for s in stages if s in algo), key=lambda s: stages[s])
+        achieved = algo[dom] / (stages[dom] * 1e-6) / 1e9
+        line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for(dom, N),
+                            "algorithmic_bytes": int(algo[dom]), "avg_launch_us": round(stages[dom], 2), "n_isects": M1,
+                            "whole_closure_frac": line["closure"]["frac_of_hbm_peak"]}
+        line["stage_us"] = {k: round(v, 2) for k, v in stages.items()}
+        tracker.capacity_ok()
+    return line, (N, W, H)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# keyframe bundle adjustment (configs[3] strong scaling; configs[1] as an extra)
+# ------------------------------------------------------------------------------------------------------------------------
+def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=False):
+    import torch.distributed as td
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.mapping import BundleAdjuster, MapConfig
+    from gslam_amd.synthetic import make_scene
+    splats = GaussianSplattingData.from_dict(make_scene(N, 0), dev)
+    gt_scene = GaussianSplattingData.from_dict(make_scene(N, 1), dev)
+    window, _cam = make_frames(range(window_size), W, H, dev, gt_scene)
+    del gt_scene
+    torch.cuda.empty_cache()
+    ba = BundleAdjuster(splats, MapConfig(), capturable=True)
+    plan = ba.plan(window)
+    plan.prepare()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for attempt in range(3):
+        for _ in range(warmup):
+            plan.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            plan.step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ok = 1 if plan.capacity_ok() else 0
+        if world > 1:
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            td.all_reduce(flag, op=td.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            break
+        print(f"bench.py[rank {rank}]: tile-list overflow on attempt {attempt}, re-running", file=sys.stderr)
+    else:
+        raise RuntimeError("tile lists kept overflowing")
+    # the collective alone, same bucket
+    reduce_us = None
+    if world > 1:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            plan.reduce()
+        barrier()
+        reduce_us = (time.perf_counter() - t0) / 10 * 1e6
+        t = torch.tensor([elapsed, reduce_us], device=dev, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed, reduce_us = float(t[0]), float(t[1])
+    res = {"elapsed": elapsed, "ms_per_iter": elapsed / steps * 1e3, "keyframes_per_s": window_size * steps / elapsed,
+           "reduce_us": reduce_us, "bucket_bytes": int(plan.flat.numel() * 4),
+           "n_isects_local": int(plan.r.M_dev.item()) if plan.r is not None else 0, "local_cameras": len(plan.mine)}
+    if stage_timing and rank == 0 and plan.r is not None:
+        from gslam_amd.plan import current_stream_ptr
+        st = current_stream_ptr(dev)
+        with StageTimer() as timer:
+            for _ in range(12):
+                plan.enqueue_render_backward(st)
+                plan.enqueue_update(st)
+        res["stage_us"] = {k: round(v, 2) for k, v in timer.mean_us(skip=4).items()}
+        res["M"] = int(plan.r.M_dev.item())
+    return res
+
+
+def cpu_baseline_tracking(N, W, H, budget_s=25.0):
+    """The oracle (oracle/gsx_oracle.c, scalar C, one host core) on the same work: tracking closures (C = 1 render forward
+    + backward to the pose at 500 k) and one camera of a BA iteration, bounded to ~25 s; frames/s extrapolated with the
+    iteration counts of the headline."""
     import numpy as np
     from oracle.oracle import Oracle
     from gslam_amd.synthetic import make_cameras, make_scene
@@ -142,29 +401,29 @@ def cpu_baseline(N, W, H, budget_s=25.0):
     while True:
         t0 = time.perf_counter()
         out = o.gslam_rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], viewmats, Ks,
-                                    W, H, render_mode="RGB+D", log_uncertainties=sc["log_uncertainties"],
+                                    W, H, render_mode="RGB", log_uncertainties=sc["log_uncertainties"],
                                     backgrounds=np.zeros((1, 3), np.float32))
-        rgb = np.ascontiguousarray(out["rgbs"].transpose(0, 3, 1, 2))
-        _, g_ssim = o.fused_ssim(rgb, np.ascontiguousarray(gt.transpose(0, 3, 1, 2)), "valid")
         v_render = np.zeros_like(out["render"])
-        v_render[..., :3] = (out["rgbs"] - gt) * 1e-3 - 0.2 * g_ssim.transpose(0, 2, 3, 1)
+        v_render[..., :3] = (out["rgbs"] - gt) * 1e-3
         v_render[..., 3:] = 1e-6
         vm, vc, vcol, vop, _ = o.raster_bwd(out["means2d"], out["conics"], out["colors_packed"], out["opacities"],
                                             out["backgrounds_packed"], W, H, 16, out["isect_offsets"],
                                             out["flatten_ids"], out["alphas"], out["last_ids"], v_render,
                                             np.zeros_like(out["alphas"]))
         scales = np.exp(sc["scales"])
-        g = o.project_bwd(sc["means"], sc["quats"], scales, viewmats, Ks, W, H, out["radii"], vm, vcol[..., 3], vc)
-        for p, gr in ((sc["means"], g[0]), (sc["quats"], g[1]), (sc["scales"], g[2] * scales)):
-            o.adam(p, gr, np.zeros_like(p), np.zeros_like(p), 1e-3, 1)
+        o.project_bwd(sc["means"], sc["quats"], scales, viewmats, Ks, W, H, out["radii"], vm,
+                      np.zeros_like(out["depths"]), vc)
         times.append(time.perf_counter() - t0)
         if time.perf_counter() - t_start + times[-1] > budget_s or len(times) >= 5:
             break
     times.sort()
-    med = times[len(times) // 2]
-    return {"value": 1.0 / med, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{len(times)} full steps (fwd+bwd+SSIM+Adam) of the same {N}-Gaussian {W}x{H} C=1 workload, "
-                      f"median {med:.2f} s/step, oracle/gsx_oracle.c scalar C on 1 host core"}
+    t_c = times[len(times) // 2]
+    # a BA camera costs at least a tracking closure (one more channel, SSIM, Adam on top): lower bound on the CPU time
+    per_frame = (N_ADAM + MAX_EVAL + 1) * t_c + t_c + (BA_ITERS * WINDOW / KF_EVERY) * t_c
+    return {"value": round(1.0 / per_frame, 5), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{len(times)} tracking closures (render fwd + bwd to the pose, {N} Gaussians, {W}x{H}, C=1) timed on 1 "
+                      f"host core with oracle/gsx_oracle.c, median {t_c:.2f} s/closure; frames/s = 1 / ((36 + 1 + "
+                      f"{BA_ITERS}*{WINDOW}/{KF_EVERY}) closures x that), a BA camera counted as one closure (lower bound)"}
 
 
 def main():
@@ -172,140 +431,79 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
     # rehearsal knobs (1-GPU box): GSX_FORCE_DEVICE=0 puts every rank on cuda:0, GSX_DIST_BACKEND=gloo avoids RCCL's
     # duplicate-GPU check.  The driver's multi-GPU runs use neither: one rank per GPU over RCCL/xGMI.
     dev_index = int(os.environ.get("GSX_FORCE_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-
     from gslam_amd import dist as gdist
     import torch.distributed as td
     gdist.init_from_env(backend=os.environ.get("GSX_DIST_BACKEND"), device=dev)
 
-    from gslam_amd.map import GaussianSplattingData
-    from gslam_amd.mapping import BundleAdjuster, MapConfig
-    from gslam_amd.synthetic import make_scene
-
-    N, W, H = args.gaussians, args.width, args.height
-    splats = GaussianSplattingData.from_dict(make_scene(N, 0), dev)
-    gt_scene = GaussianSplattingData.from_dict(make_scene(N, 1), dev)
-    own = {c for c in range(world) if c % world == rank}
-    window = make_window(world, W, H, dev, gt_scene, own)
-    del gt_scene
-    use_graph = not args.no_graph
-    ba = BundleAdjuster(splats, MapConfig(), capturable=use_graph)
-    step_fn = lambda: ba.step(window)
-    if use_graph:
-        from gslam_amd.mapping import GraphedBundleAdjuster
-        gba, ok = None, 1
-        try:
-            gba = GraphedBundleAdjuster(ba, window)
-        except Exception as e:  # e.g. a runtime that cannot capture next to a live RCCL communicator
-            ok = 0
-            print(f"bench.py[rank {rank}]: HIP-graph capture failed ({e!r}); running eagerly", file=sys.stderr)
-        if world > 1:           # all ranks must take the same path
-            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-            td.all_reduce(flag, op=td.ReduceOp.MIN)
-            ok = int(flag.item())
-        if ok:
-            step_fn = gba.step
-        else:
-            use_graph = False
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            td.barrier()
-        torch.cuda.synchronize()
-
-    from gslam_amd.rasterization import validate
-    for attempt in range(3):
-        for _ in range(args.warmup):
-            step_fn()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step_fn()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        # the render is sync-free (no M read-back inside a step); check afterwards that no step overflowed its
-        # intersection buffers - a truncated step would be skipped work, so such a measurement is discarded
-        if validate(dev):
-            break
-        print(f"bench.py: intersection capacity overflow on attempt {attempt}, re-running", file=sys.stderr)
-        if use_graph:
-            gba = GraphedBundleAdjuster(ba, window)
-            step_fn = gba.step
-        else:
-            step_fn = lambda: ba.step(window)
-    else:
-        raise RuntimeError("intersection buffers kept overflowing")
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.steps / elapsed
-
-    roofline, stages = None, None
-    if not args.no_stage_timing:
-        # every rank runs the instrumented steps (they contain the collectives); only rank 0 keeps the timers
-        if rank == 0:
-            with StageTimer() as st:
-                for _ in range(10):
-                    ba.step(window)
-            stages = st.mean_us(skip=0)
-        else:
-            for _ in range(10):
-                ba.step(window)
-    if rank == 0 and stages is not None:
-        out = ba.last_outputs
-        M = int(out.flatten_ids.shape[0])
-        P = H * W
-        algo = algorithmic_bytes(N, 1, M, P, 5)
-        dom = max((s for s in stages if s in algo), key=lambda s: stages[s])
-        achieved = algo[dom] / (stages[dom] * 1e-6) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):
+    if world == 1 and not args.ba_only:
+        line, (N, W, H) = run_headline(args, dev)
+        if not args.no_extras:
+            extra = {}
+            r = run_ba(dev, 0, 1, 2_000_000, W, H, WINDOW, 30, 5)
+            extra["ba_2m_window8"] = {"workload": "BASELINE.json configs[3] on 1 GPU: 2M Gaussians, 8-keyframe BA window",
+                                      "keyframes_per_s": round(r["keyframes_per_s"], 2),
+                                      "ms_per_ba_iteration": round(r["ms_per_iter"], 4), "n_isects": r["n_isects_local"]}
+            torch.cuda.empty_cache()
+            r = run_ba(dev, 0, 1, 100_000, W, H, 1, 200, 20)
+            extra["ba_100k_window1"] = {"workload": "BASELINE.json configs[1]: 100k Gaussians, 1 keyframe, full BA step",
+                                        "keyframes_per_s": round(r["keyframes_per_s"], 2),
+                                        "ms_per_ba_iteration": round(r["ms_per_iter"], 4), "n_isects": r["n_isects_local"]}
+            line["extra"] = extra
+        if not args.no_cpu_baseline:
             try:
-                tj = json.load(open(tpath))
-                if tj.get("workload_gaussians") == N and tj.get("kernel") == dom:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes": int(algo[dom]), "avg_launch_us": round(stages[dom], 2), "n_isects": M}
-
-    if rank == 0:
-        line = {
-            "metric": "keyframe BA render fwd+bwd fps @640x480 / N Gaussians (tracking+mapping hot path)",
-            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: 100k Gaussians, 640x480, render fwd+bwd (RGB+D+beta, CH=5) "
-                                   "+ fused-SSIM + full mapping loss + fused Adam; 1 keyframe per GPU",
-                       "gaussians": N, "width": W, "height": H, "keyframes_per_gpu": 1, "window": world,
-                       "parallelism": f"keyframe-sharded BA x{world}, 1 all-reduce of the [N,15] grad bucket",
-                       "launch": ("eager" if not use_graph else "hip-graph replay of the whole step" if world == 1 else
-                                  "hip-graph replay (render+loss+backward | Adam) around one eager all-reduce")},
-        }
-        if roofline is not None:
-            line["roofline"] = roofline
-            line["stage_us"] = {k: round(v, 2) for k, v in stages.items()}
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(N, W, H)
+                line["cpu_baseline"] = cpu_baseline_tracking(N, W, H)
             except Exception as e:  # the baseline is informational; never lose the GPU number over it
                 line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port",
                                         "sample": f"failed: {e!r}"}
+        print(json.dumps(line), flush=True)
+        return
+
+    # ---- keyframe-BA strong scaling (configs[3]) -----------------------------------------------------------------------------
+    N = args.gaussians or 2_000_000
+    W, H = args.width, args.height
+    steps = args.steps or 60
+    warmup = 10 if args.warmup is None else args.warmup
+    r = run_ba(dev, rank, world, N, W, H, WINDOW, steps, warmup, stage_timing=not args.no_stage_timing)
+    if rank == 0:
+        line = {
+            "metric": "keyframe-BA throughput: keyframe renders fwd+bwd per second @640x480 / 2M Gaussians, 8-keyframe window",
+            "value": round(r["keyframes_per_s"], 3), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(r["ms_per_iter"], 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[3]: 2M Gaussians, 640x480, keyframe bundle adjustment over a fixed 8-keyframe "
+                            "window sharded across the GPUs (step = one BA iteration: render fwd+bwd CH=5 + full mapping loss + "
+                            "fused Adam)",
+                "gaussians": N, "width": W, "height": H, "window": WINDOW, "cameras_on_rank0": r["local_cameras"],
+                "parallelism": f"keyframe-sharded BA x{world}: one all-reduce(sum) of a {r['bucket_bytes'] / 1e6:.1f} MB fp32 bucket "
+                               "(map + pose gradients, visibility counts, loss) per iteration over RCCL",
+                "launch": "hip-graph replay (render+loss+backward | isotropic+Adam) around one eager all-reduce"
+                          if world > 1 else "hip-graph replay of the whole step",
+            },
+            "all_reduce_us": None if r["reduce_us"] is None else round(r["reduce_us"], 1),
+            "all_reduce_algbw_gbs": None if not r["reduce_us"] else round(r["bucket_bytes"] / r["reduce_us"] * 1e-3, 1),
+            "rccl": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "RCCL_MSCCL_ENABLE") if os.environ.get(k)},
+        }
+        if "stage_us" in r:
+            Cl = r["local_cameras"]
+            algo = algorithmic_bytes(N, Cl, r["M"], Cl * H * W, 5, Cl * 1200)
+            stages = r["stage_us"]
+            dom = max((s for s in stages if s in algo), key=lambda s: stages[s])
+            achieved = algo[dom] / (stages[dom] * 1e-6) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                                "algorithmic_bytes": int(algo[dom]), "avg_launch_us": round(stages[dom], 2),
+                                "n_isects": r["M"]}
+            line["stage_us"] = stages
         print(json.dumps(line), flush=True)
     if world > 1:
         td.barrier()

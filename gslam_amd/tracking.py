@@ -192,7 +192,8 @@ class GraphedTracker:
 
     def _write_back(self, frame: Frame):
         with torch.no_grad():
-            new_pose = self.pose().detach().clone()
+            # fused tail: the closure's last launch left the view matrix of the final parameters in the plan
+            new_pose = self.plan.r.viewmats[0] if self.fused_tail else self.pose().detach().clone()
             frame.pose.Rt.copy_(new_pose)
             frame.pose.dR.zero_()
             frame.pose.dt.zero_()

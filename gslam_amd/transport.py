@@ -12,8 +12,10 @@ its shape, but the map inside it is a *view*:
   again in one launch, into the consumer's own persistent map when the number of Gaussians is unchanged - the addresses
   the tracker's HIP graph has captured stay valid - and only re-allocates when the map was densified or pruned.
 
-A slot is overwritten two publishes later; the consumer has copied out long before (it takes the payload as soon as it
-polls its queue, and the backend publishes once per keyframe)."""
+A slot is reused two publishes later.  Two guards make that safe when the consumer lags: ``publish`` makes the producer's
+stream wait for the event the consumer recorded after its last copy out of that slot (no overwrite under a running copy),
+and every payload carries the generation of its slot - ``receive`` drops a payload whose slot has been re-published in the
+meantime (``stale``: the newer map is already in the consumer's queue) instead of reading a torn or re-sized map."""
 from __future__ import annotations
 
 import ctypes as C
@@ -53,6 +55,8 @@ class MapMailbox:
 
     def __init__(self):
         self._slots: List[Optional[List[torch.Tensor]]] = [None, None]
+        self._generation = [0, 0]
+        self._consumed: List[Optional[torch.cuda.Event]] = [None, None]    # recorded by receive() after its copy
         self._next = 0
         self.publishes = 0
 
@@ -70,8 +74,14 @@ class MapMailbox:
     @torch.no_grad()
     def publish(self, splats: GaussianSplattingData) -> GaussianSplattingData:
         n = int(splats.means.shape[0])
-        slot = self._ensure(self._next, splats)
+        i = self._next
         self._next ^= 1
+        done = self._consumed[i]
+        if done is not None:                                  # back-pressure: a consumer copy out of this slot may be in flight
+            torch.cuda.current_stream().wait_event(done)
+            self._consumed[i] = None
+        slot = self._ensure(i, splats)
+        self._generation[i] += 1
         copy_rows(slot, [getattr(splats, p).detach().contiguous() for p in _PARAMS], n)
         view = GaussianSplattingData(*[s[:n] for s in slot])
         for p in _PARAMS:
@@ -79,6 +89,7 @@ class MapMailbox:
         ev = torch.cuda.Event()
         ev.record()                                           # on the producer's current stream
         view._mail_event = ev
+        view._mail_slot = (self, i, self._generation[i])
         self.publishes += 1
         return view
 
@@ -87,17 +98,28 @@ class MapMailbox:
 def receive(dst: Optional[GaussianSplattingData], payload: GaussianSplattingData):
     """-> (map to use, replaced).  ``replaced`` is False when ``dst`` was updated in place (same N: captured graphs
     over its tensors stay valid); otherwise a new no-grad map was allocated."""
+    slot = getattr(payload, "_mail_slot", None)
+    if slot is not None and slot[0]._generation[slot[1]] != slot[2]:
+        return dst, False                                     # stale: its slot was re-published; the newer payload follows
     ev = getattr(payload, "_mail_event", None)
     if ev is not None:
         torch.cuda.current_stream().wait_event(ev)
     n = int(payload.means.shape[0])
     same = dst is not None and int(dst.means.shape[0]) == n and dst.means.device == payload.means.device and all(
         getattr(dst, p).shape == getattr(payload, p).shape and getattr(dst, p).is_contiguous() for p in _PARAMS)
+    def consumed():
+        if slot is not None:
+            done = torch.cuda.Event()
+            done.record()
+            slot[0]._consumed[slot[1]] = done
+
     if same:
         copy_rows([getattr(dst, p).data for p in _PARAMS], [getattr(payload, p).data for p in _PARAMS], n)
+        consumed()
         return dst, False
     out = GaussianSplattingData(*[torch.empty_like(getattr(payload, p).data) for p in _PARAMS])
     for p in _PARAMS:
         getattr(out, p).requires_grad_(False)
     copy_rows([getattr(out, p).data for p in _PARAMS], [getattr(payload, p).data for p in _PARAMS], n)
+    consumed()
     return out, True
