@@ -31,8 +31,7 @@ PROTOTYPES = {
     "gsx_isect_count": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "gsx_scan_workspace_bytes": (i64, [i64]),
     "gsx_isect_scan": (i32, [vp, i64, vp, vp, i64, vp]),
-    "gsx_isect_sort_workspace_bytes": (i64, [i64]),
-    "gsx_isect_emit_sort": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i64, i32, vp, vp, vp, i64, vp]),
+    "gsx_isect_emit": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i64, vp, vp, vp]),
     "gsx_isect_offset_encode": (i32, [vp, i64, i64, i32, i32, vp, vp]),
     "gsx_isect_bin_workspace_bytes": (i64, [i64, i32, i32, i64]),
     "gsx_isect_bin_workspace_bytes_n": (i64, [i64, i64, i32, i32, i64]),
@@ -97,6 +96,11 @@ PROTOTYPES = {
     "gsx_host_alloc": (i32, [C.POINTER(vp), C.POINTER(vp), i64]),
     "gsx_host_free": (i32, [vp]),
     "gsx_zero_words": (i32, [vp, i64, vp]),
+    "gsx_front_workspace_bytes": (i64, [i64, i64, i32, i32, i64]),
+    "gsx_front_rows": (i64, [i64, i64, i32, i32]),
+    "gsx_front_pose_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, i64, vp, i64, vp, vp]),
+    "gsx_front_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                            vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp]),
 }
 
 

@@ -3,15 +3,14 @@
 //   key = cam << (32 + tile_n_bits) | tile << 32 | float_bits(depth),  value = flatten id (c*N+g),
 //   stable order (ties keep emission order = ascending flatten id, tiles row-major inside the bbox).
 //
-// v1 of the sort: device-wide LSD radix sort over the live key bits via rocPRIM (temporary yardstick);
-// the tile-binned LDS sort that replaces it is tracked in DESIGN.md.
+// This file holds the gsplat-shaped pieces that are NOT the sort: the per-Gaussian tile count (K3), the int64 inclusive
+// scan of those counts and the unsorted emission of (key, flatten id) pairs in gsplat's order (isect_tiles(sort=False)),
+// and the offset encode of sorted keys (K7).  The sort itself is the tile-binned one of isect_bin.hip; the library links
+// no sort / scan library (the device-wide radix sort the first version borrowed from rocPRIM is gone - the parity tests
+// use torch.sort on the unsorted emission as their independent yardstick).
 #include "gsx_common.h"
 
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace {
 
@@ -98,9 +97,77 @@ int bit_length(uint32_t v) {
     return n;
 }
 
-struct I32ToI64 {
-    __device__ __host__ int64_t operator()(int32_t v) const { return (int64_t)v; }
-};
+// ---- int32 -> int64 inclusive scan in three launches: 2048-element blocks (local scan + block total), one workgroup over the
+// block totals, the block bases added back ------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_blocks_kernel(const int32_t *__restrict__ in, int64_t n,
+                                                                   int64_t *__restrict__ out,
+                                                                   int64_t *__restrict__ block_sums) {
+    __shared__ long long s_w[SCAN_THREADS / 64];
+    const int t = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)t * SCAN_ITEMS;
+    long long v[SCAN_ITEMS];
+    long long sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? (long long)in[base + k] : 0;
+        sum += v[k];
+    }
+    long long incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long u = __shfl_up(incl, off, 64);
+        if ((t & 63) >= off) incl += u;
+    }
+    if ((t & 63) == 63) s_w[t >> 6] = incl;
+    __syncthreads();
+    long long run = incl - sum, total = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+        if (w < (t >> 6)) run += s_w[w];
+        total += s_w[w];
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        run += v[k];
+        if (base + k < n) out[base + k] = run;
+    }
+    if (t == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void scan_totals_kernel(int64_t *__restrict__ block_sums, int64_t nb) {
+    __shared__ long long s_scan[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (nb + 1023) / 1024;
+    const int64_t lo = min(nb, (int64_t)t * per), hi = min(nb, lo + per);
+    long long sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += block_sums[i];
+    s_scan[t] = sum;
+    for (int off = 1; off < 1024; off <<= 1) {
+        __syncthreads();
+        const long long add = (t >= off) ? s_scan[t - off] : 0;
+        __syncthreads();
+        s_scan[t] += add;
+    }
+    __syncthreads();
+    long long run = s_scan[t] - sum;                       // exclusive base of this thread's chunk
+    for (int64_t i = lo; i < hi; ++i) {
+        const long long c = block_sums[i];
+        block_sums[i] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(int64_t *__restrict__ out, int64_t n,
+                                                                const int64_t *__restrict__ block_bases) {
+    const long long add = block_bases[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = base + (int64_t)k * SCAN_THREADS;
+        if (i < n) out[i] += add;
+    }
+}
 
 }  // namespace
 
@@ -115,82 +182,45 @@ extern "C" int gsx_isect_count(const float *means2d, const int32_t *radii, int64
 }
 
 extern "C" int64_t gsx_scan_workspace_bytes(int64_t CN) {
-    size_t bytes = 0;
-    auto in = rocprim::make_transform_iterator((const int32_t *)nullptr, I32ToI64());
-    if (rocprim::inclusive_scan(nullptr, bytes, in, (int64_t *)nullptr, (size_t)(CN > 0 ? CN : 1),
-                                rocprim::plus<int64_t>()) != hipSuccess)
-        return -1;
-    return gsx_align256((int64_t)bytes) + 256;
+    const int64_t nb = (CN > 0 ? CN : 1 + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+    return gsx_align256(nb * 8) + 256;
 }
 
 extern "C" int gsx_isect_scan(const int32_t *tiles_per_gauss, int64_t CN, int64_t *cum_tiles, void *workspace,
                               int64_t workspace_bytes, void *stream) {
     GSX_CHECK_ARG(tiles_per_gauss && cum_tiles && CN >= 0);
     if (CN == 0) return GSX_OK;
-    size_t bytes = (size_t)workspace_bytes;
-    auto in = rocprim::make_transform_iterator(tiles_per_gauss, I32ToI64());
-    size_t need = 0;
-    (void)rocprim::inclusive_scan(nullptr, need, in, cum_tiles, (size_t)CN, rocprim::plus<int64_t>());
-    if (!workspace || bytes < need) {
-        gsx_set_error("gsx_isect_scan: workspace too small (%zu < %zu)", bytes, need);
+    const int64_t nb = (CN + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (!workspace || workspace_bytes < nb * 8) {
+        gsx_set_error("gsx_isect_scan: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)(nb * 8));
         return GSX_E_WORKSPACE;
     }
-    hipError_t e = rocprim::inclusive_scan(workspace, bytes, in, cum_tiles, (size_t)CN, rocprim::plus<int64_t>(),
-                                           (hipStream_t)stream);
-    if (e != hipSuccess) {
-        gsx_set_error("gsx_isect_scan: %s", hipGetErrorString(e));
-        return GSX_E_LAUNCH;
+    GSX_CHECK_ARG(nb < ((int64_t)1 << 31));
+    hipStream_t st = (hipStream_t)stream;
+    int64_t *sums = (int64_t *)workspace;
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, tiles_per_gauss, CN, cum_tiles,
+                       sums);
+    GSX_CHECK_LAUNCH();
+    if (nb > 1) {
+        hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, sums, nb);
+        GSX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, cum_tiles, CN, sums);
+        GSX_CHECK_LAUNCH();
     }
     return GSX_OK;
 }
 
-extern "C" int64_t gsx_isect_sort_workspace_bytes(int64_t M) {
-    if (M <= 0) return 256;
-    size_t bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-                                  (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)M, 0, 64) != hipSuccess)
-        return -1;
-    // unsorted keys + values live in the workspace next to rocPRIM's temporary storage
-    return gsx_align256((int64_t)bytes) + gsx_align256(M * 8) + gsx_align256(M * 4) + 256;
-}
-
-extern "C" int gsx_isect_emit_sort(const float *means2d, const int32_t *radii, const float *depths,
-                                   const int64_t *cum_tiles, int64_t N, int64_t C, int tile_w, int tile_h, int64_t M,
-                                   int sort, int64_t *isect_ids, int32_t *flatten_ids, void *workspace,
-                                   int64_t workspace_bytes, void *stream) {
+extern "C" int gsx_isect_emit(const float *means2d, const int32_t *radii, const float *depths, const int64_t *cum_tiles,
+                              int64_t N, int64_t C, int tile_w, int tile_h, int64_t M, int64_t *isect_ids,
+                              int32_t *flatten_ids, void *stream) {
     GSX_CHECK_ARG(means2d && radii && depths && cum_tiles && N >= 0 && C >= 1 && tile_w > 0 && tile_h > 0 && M >= 0);
     if (M == 0 || N == 0) return GSX_OK;
     GSX_CHECK_ARG(isect_ids && flatten_ids);
-    hipStream_t st = (hipStream_t)stream;
     const int64_t CN = C * N;
     const int tile_n_bits = bit_length((uint32_t)(tile_w * tile_h));
-    const int cam_n_bits = bit_length((uint32_t)C);
-    const unsigned blocks = (unsigned)((CN + 255) / 256);
-    if (!sort) {
-        hipLaunchKernelGGL(isect_emit_kernel, dim3(blocks), dim3(256), 0, st, means2d, radii, depths, cum_tiles, N,
-                           CN, tile_w, tile_h, tile_n_bits, isect_ids, flatten_ids);
-        GSX_CHECK_LAUNCH();
-        return GSX_OK;
-    }
-    if (!workspace || workspace_bytes < gsx_isect_sort_workspace_bytes(M)) {
-        gsx_set_error("gsx_isect_emit_sort: workspace too small");
-        return GSX_E_WORKSPACE;
-    }
-    char *ws = (char *)workspace;
-    int64_t *keys_in = (int64_t *)ws;
-    int32_t *vals_in = (int32_t *)(ws + gsx_align256(M * 8));
-    void *tmp = ws + gsx_align256(M * 8) + gsx_align256(M * 4);
-    size_t tmp_bytes = (size_t)(workspace_bytes - gsx_align256(M * 8) - gsx_align256(M * 4));
-    hipLaunchKernelGGL(isect_emit_kernel, dim3(blocks), dim3(256), 0, st, means2d, radii, depths, cum_tiles, N, CN,
-                       tile_w, tile_h, tile_n_bits, keys_in, vals_in);
+    hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)((CN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, means2d,
+                       radii, depths, cum_tiles, N, CN, tile_w, tile_h, tile_n_bits, isect_ids, flatten_ids);
     GSX_CHECK_LAUNCH();
-    const unsigned end_bit = (unsigned)(32 + tile_n_bits + cam_n_bits);
-    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint64_t *)keys_in, (uint64_t *)isect_ids,
-                                             (const int32_t *)vals_in, flatten_ids, (size_t)M, 0u, end_bit, st);
-    if (e != hipSuccess) {
-        gsx_set_error("gsx_isect_emit_sort: radix sort: %s", hipGetErrorString(e));
-        return GSX_E_LAUNCH;
-    }
     return GSX_OK;
 }
 

@@ -1125,3 +1125,537 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
     }
     return GSX_OK;
 }
+
+// =====================================================================================================================
+// Fused front of a render for the launch plans (gslam_amd/plan.py): K1 + K3..K7 in FOUR launches instead of seven.
+//
+//   1. front_project_kernel  : the projection of project.hip (same arithmetic: project_core.h) for a chunk of 1024 x items
+//                              Gaussians per workgroup, all cameras; while the rectangle of a visible instance is in
+//                              registers it is counted into the workgroup's per-tile histogram (LDS) - the workgroup's row
+//                              of the count matrix - and appended to the workgroup's segment of 16-byte instance records
+//                              (packed rectangle, depth bits, flatten id).  Culled rows write radii = 0 / tiles = 0 only
+//                              when the caller says nobody reads them (GSX_PROJ_SKIP_CULLED: two thirds of a 500 k map
+//                              are outside a 640x480 frustum; 128 B of zero stores each)
+//   2. column_scan_kernel    : as before (each row's base inside every tile, per-tile totals)
+//   3. front_place_kernel    : every workgroup scans the T per-tile totals in LDS itself (the one-workgroup tile_scan launch
+//                              is gone; workgroup 0 publishes offsets / M / status for the kernels behind), then places the
+//                              instance records of ITS row that touch ITS stripe of tile rows through LDS cursors.  The
+//                              stripe index is blockIdx % 8: workgroups that share an XCD (round-robin dispatch, a speed
+//                              assumption only) write the same contiguous eighth of the entry buffer, so the 8-byte
+//                              scattered stores of one 128-byte line meet in one L2 instead of going out as partial
+//                              lines from eight of them
+//   4. tile_sort_count_kernel: as before
+// Results are those of gsx_project_fwd + gsx_isect_bin_sort (the tile sort fixes the order inside a tile).
+// =====================================================================================================================
+#include "project_core.h"
+
+namespace {
+
+using namespace gsx_proj;
+
+constexpr int FRONT_THREADS = 1024;
+constexpr int FPLACE_THREADS = 256;
+constexpr int FRONT_STRIPES = 8;
+
+struct FrontArgs {
+    const float *means, *quats, *scales, *viewmats, *Ks, *logit_opac, *logit_colors, *log_unc;
+    int64_t N;
+    int C, W, H, flags, tile_w, tile_h, items, R;
+    float eps2d, near_p, far_p;
+    int32_t *radii, *tiles, *vis_count;
+    float *means2d, *depths, *conics, *rec, *v_rec;
+    int32_t *cnt;        // [C][R][n_tiles]
+    int32_t *n_inst;     // [C][R]
+    PreRec *recs;        // [C][R][1024 * items]
+};
+
+// Conservative screen-space cull of one Gaussian for one camera from its mean and its largest scale alone (no covariance
+// algebra): true only if the full projection is CERTAIN to cull it - same near / far comparison on the same expression, and
+// a bounding box test with an upper bound of the radius: trace(J Sc J^T) <= |J|_F^2 |R|_F^2 s_max^2 with
+// |J|_F^2 <= rz^2 (fx^2 (1 + lx^2) + fy^2 (1 + ly^2)) (lx, ly: the frustum clamp of tx / z, ty / z), v1 <= trace + 2 eps + 0.1,
+// radius <= 3 sqrt(v1) + 1; one per cent and one pixel of slack on top cover the float rounding of this estimate.
+__device__ __forceinline__ bool surely_culled(const float mean[3], float smax2, const Cam &cam, float RF, float KJ,
+                                              int W, int H, float eps2d, float near_p, float far_p) {
+    const float *R = cam.R;
+    const float x = ((R[0] * mean[0] + R[1] * mean[1]) + R[2] * mean[2]) + cam.t[0];
+    const float y = ((R[3] * mean[0] + R[4] * mean[1]) + R[5] * mean[2]) + cam.t[1];
+    const float z = ((R[6] * mean[0] + R[7] * mean[1]) + R[8] * mean[2]) + cam.t[2];
+    if (z < near_p || z > far_p) return true;            // exactly project_core's test
+    const float rz = 1.0f / z;
+    const float pmx = (cam.fx * x) * rz + cam.cx, pmy = (cam.fy * y) * rz + cam.cy;
+    const float v1b = 1.01f * (rz * rz) * KJ * RF * smax2 + 2.0f * eps2d + 0.2f;
+    const float rb = 3.0f * sqrtf(v1b) + 2.0f;
+    return (pmx + rb <= 0.0f) || (pmx - rb >= (float)W) || (pmy + rb <= 0.0f) || (pmy - rb >= (float)H);
+}
+
+__global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs a) {
+    extern __shared__ int s_front[];                        // [C * n_tiles] counts, [C] instance counters, survivors
+    const int n_tiles = a.tile_w * a.tile_h;
+    const int C = a.C;
+    int *s_cnt = s_front, *s_ninst = s_front + C * n_tiles;
+    int *s_nsurv = s_ninst + C;
+    unsigned short *s_list = reinterpret_cast<unsigned short *>(s_nsurv + 1);     // [1024 * items] local indices
+    for (int i = threadIdx.x; i < C * n_tiles + C + 1; i += FRONT_THREADS) s_front[i] = 0;
+    __syncthreads();
+    const int seg_cap = FRONT_THREADS * a.items;
+    const int lane = threadIdx.x & 63;
+    const bool skip_culled = (a.flags & GSX_PROJ_SKIP_CULLED) != 0;
+    const int64_t g0 = (int64_t)blockIdx.x * seg_cap;
+    // ---- phase 1: cheap conservative cull; the survivors' local indices are compacted into LDS ------------------------------
+    for (int it = 0; it < a.items; ++it) {
+        const int loc = it * FRONT_THREADS + threadIdx.x;
+        const int64_t g = g0 + loc;
+        const bool active = g < a.N;
+        bool survive = false;
+        if (active) {
+            const float mean[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
+            float sm = fmaxf(a.scales[3 * g], fmaxf(a.scales[3 * g + 1], a.scales[3 * g + 2]));
+            if (a.flags & GSX_PROJ_LOG_SCALES) sm = expf(sm);
+            const float smax2 = sm * sm;
+            for (int c = 0; c < C; ++c) {
+                Cam cam;
+                load_cam(a.viewmats, a.Ks, c, cam);
+                const float *R = cam.R;
+                const float RF = ((R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) + (R[3] * R[3] + R[4] * R[4] + R[5] * R[5])) +
+                                 (R[6] * R[6] + R[7] * R[7] + R[8] * R[8]);
+                const float tanx = 0.5f * (float)a.W / cam.fx, tany = 0.5f * (float)a.H / cam.fy;
+                const float lx = fmaxf(((float)a.W - cam.cx) / cam.fx, cam.cx / cam.fx) + GSX_FOV_SLACK * tanx;
+                const float ly = fmaxf(((float)a.H - cam.cy) / cam.fy, cam.cy / cam.fy) + GSX_FOV_SLACK * tany;
+                const float KJ = cam.fx * cam.fx * (1.0f + lx * lx) + cam.fy * cam.fy * (1.0f + ly * ly);
+                const bool out = surely_culled(mean, smax2, cam, RF, KJ, a.W, a.H, a.eps2d, a.near_p, a.far_p);
+                if (!out) survive = true;
+                else if (!skip_culled) survive = true;      // rows of culled instances are wanted as zeros: full path writes them
+                else {
+                    const int64_t idx = (int64_t)c * a.N + g;
+                    a.radii[idx] = 0;
+                    a.tiles[idx] = 0;
+                }
+            }
+            if (!survive && a.vis_count) a.vis_count[g] = 0;
+        }
+        const unsigned long long m = __ballot(survive);
+        if (m != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(s_nsurv, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (survive) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)loc;
+        }
+    }
+    __syncthreads();
+    const int n_surv = *s_nsurv;
+    // ---- phase 2: the projection proper, dense over the survivors (whole wavefronts of real work) ---------------------------
+    for (int s0 = 0; s0 < n_surv; s0 += FRONT_THREADS) {
+        const int si = s0 + threadIdx.x;
+        const bool active = si < n_surv;
+        const int64_t g = g0 + (active ? (int)s_list[si] : 0);
+        float mean[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, s[3] = {1.f, 1.f, 1.f};
+        float opac = 0.f, col[3] = {0.f, 0.f, 0.f}, beta = 0.f;
+        if (active) {
+            mean[0] = a.means[3 * g]; mean[1] = a.means[3 * g + 1]; mean[2] = a.means[3 * g + 2];
+            q[0] = a.quats[4 * g]; q[1] = a.quats[4 * g + 1]; q[2] = a.quats[4 * g + 2]; q[3] = a.quats[4 * g + 3];
+            s[0] = a.scales[3 * g]; s[1] = a.scales[3 * g + 1]; s[2] = a.scales[3 * g + 2];
+            if (a.flags & GSX_PROJ_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
+            opac = gsx_sigmoid(a.logit_opac[g]);
+            col[0] = gsx_sigmoid(a.logit_colors[3 * g]);
+            col[1] = gsx_sigmoid(a.logit_colors[3 * g + 1]);
+            col[2] = gsx_sigmoid(a.logit_colors[3 * g + 2]);
+            if (a.flags & GSX_PROJ_BETAS) beta = fmaxf(expf(a.log_unc[g]), GSX_BETA_MIN);
+        }
+        QuatRot qr;
+        quat_to_rotmat(q, qr);
+        float M[9];
+        Sym3 S;
+        covar_from_rot_scale(qr.R, s, M, S);
+        int n_vis = 0;
+        for (int c = 0; c < C; ++c) {
+            Cam cam;
+            load_cam(a.viewmats, a.Ks, c, cam);
+            const int64_t idx = (int64_t)c * a.N + g;
+            Proj p;
+            int32_t radius_i = 0;
+            float mx = 0.f, my = 0.f, depth = 0.f, con0 = 0.f, con1 = 0.f, con2 = 0.f;
+            if (active && project_core(mean, S, cam, a.W, a.H, a.eps2d, a.near_p, a.far_p, p)) {
+                const float pmx = (cam.fx * p.pc[0]) * p.rz + cam.cx, pmy = (cam.fy * p.pc[1]) * p.rz + cam.cy;
+                const float b00 = p.c00 + a.eps2d, b11 = p.c11 + a.eps2d;
+                const float b = 0.5f * (b00 + b11);
+                const float v1 = b + sqrtf(fmaxf(GSX_RADIUS_FLOOR, b * b - p.det));
+                const float radius = ceilf(GSX_RADIUS_SIGMA * sqrtf(v1));
+                const bool keep = !(radius <= 0.0f) &&
+                                  !(pmx + radius <= 0.0f || pmx - radius >= (float)a.W || pmy + radius <= 0.0f ||
+                                    pmy - radius >= (float)a.H);
+                if (keep) {
+                    radius_i = (int32_t)radius;
+                    mx = pmx; my = pmy; depth = p.pc[2];
+                    con0 = p.conic[0]; con1 = p.conic[1]; con2 = p.conic[2];
+                }
+            }
+            const bool vis = radius_i > 0;
+            Rect r = {0, 0, 0, 0};
+            if (vis) r = tile_rect(mx, my, radius_i, a.tile_w, a.tile_h);
+            const bool has = (r.x1 > r.x0) && (r.y1 > r.y0);
+            if (active) {
+                a.radii[idx] = radius_i;
+                a.tiles[idx] = has ? (r.y1 - r.y0) * (r.x1 - r.x0) : 0;
+                n_vis += vis ? 1 : 0;
+                if (vis || !skip_culled) {
+                    if (a.means2d) { a.means2d[2 * idx] = mx; a.means2d[2 * idx + 1] = my; }
+                    if (a.depths) a.depths[idx] = depth;
+                    if (a.conics) { a.conics[3 * idx] = con0; a.conics[3 * idx + 1] = con1; a.conics[3 * idx + 2] = con2; }
+                    float ch[6] = {col[0], col[1], col[2], 0.f, 0.f, 0.f};
+                    int n = 3;
+                    if (a.flags & GSX_PROJ_RENDER_DEPTH) ch[n++] = depth;
+                    if (a.flags & GSX_PROJ_BETAS) ch[n++] = beta;
+                    float4 *o = reinterpret_cast<float4 *>(a.rec + idx * 12);
+                    o[0] = make_float4(mx, my, con0, con1);
+                    o[1] = make_float4(con2, opac, vis ? ch[0] : 0.f, vis ? ch[1] : 0.f);
+                    o[2] = make_float4(vis ? ch[2] : 0.f, vis ? ch[3] : 0.f, vis ? ch[4] : 0.f, 0.f);
+                    if (a.v_rec) {
+                        float4 *z = reinterpret_cast<float4 *>(a.v_rec + idx * 12);
+                        z[0] = z[1] = z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+            // instance record: position = wavefront's reservation in the workgroup's segment + rank inside the wavefront
+            const unsigned long long m = __ballot(has);
+            if (m != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ninst[c], __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (has) {
+                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    PreRec pr;
+                    pr.xs = (uint32_t)r.x0 | ((uint32_t)r.x1 << 16);
+                    pr.ys_c = (uint32_t)r.y0 | ((uint32_t)r.y1 << 12) | ((uint32_t)c << 24);
+                    pr.depth = __float_as_uint(depth);
+                    pr.id = (uint32_t)idx;
+                    a.recs[((int64_t)c * a.R + blockIdx.x) * seg_cap + pos] = pr;
+                }
+            }
+            walk_rects(r, a.tile_w, 0u, 0u, [&](int tile, unsigned int, unsigned int) { atomicAdd(&s_cnt[tile], 1); },
+                       c * n_tiles);
+        }
+        if (active && a.vis_count) a.vis_count[g] = n_vis;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * n_tiles; i += FRONT_THREADS) {
+        const int c = i / n_tiles, tl = i - c * n_tiles;
+        a.cnt[((int64_t)c * a.R + blockIdx.x) * n_tiles + tl] = s_cnt[i];
+    }
+    if (threadIdx.x < C) a.n_inst[threadIdx.x * a.R + blockIdx.x] = s_ninst[threadIdx.x];
+}
+
+// workgroup b: row = b / stripes (a chunk of the projection), stripe = b % stripes (tile rows [stripe * rps, +rps) of every
+// camera).  counts: per-tile totals (prescanned = 0) or the finished offsets (prescanned = 1, tile_scan_kernel ran).
+__global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
+    const PreRec *__restrict__ recs, const int32_t *__restrict__ n_inst, int R, int seg_cap, int C, int tile_w,
+    int tile_h, int stripes, int rps, int64_t M_cap, const int32_t *__restrict__ counts, int prescanned,
+    const int32_t *__restrict__ cnt, int32_t *__restrict__ offsets_out, int64_t *__restrict__ M_dev,
+    int32_t *__restrict__ status, unsigned long long *__restrict__ entries) {
+    extern __shared__ int s_cur[];                          // [T]: exclusive offsets, then this stripe's write cursors
+    __shared__ long long s_wsum[FPLACE_THREADS / 64];
+    const int n_tiles = tile_w * tile_h, T = C * n_tiles;
+    const int stripe = blockIdx.x % stripes, row = blockIdx.x / stripes;
+    const int t = threadIdx.x;
+    const int ys0 = stripe * rps, ys1 = min(tile_h, ys0 + rps);
+    const int span = max(0, (ys1 - ys0) * tile_w);
+    // Everything this workgroup needs from global memory that does not depend on the scan is requested first - the first
+    // trip of camera 0's instance records, its row's bases for the stripe, the instance count - so that the kernel is one
+    // memory round trip plus the scan deep, not four (a workgroup places only a few hundred entries: latency is all there is).
+    const PreRec *seg0 = recs + (int64_t)row * seg_cap;
+    PreRec pre0 = {0u, 0u, 0u, 0u};
+    if (t < seg_cap) pre0 = seg0[t];
+    const int n0 = n_inst[row];
+    int base0 = 0;
+    if (t < span) base0 = cnt[(int64_t)row * n_tiles + ys0 * tile_w + t];
+    if (prescanned) {
+        for (int i = t; i < T; i += FPLACE_THREADS) s_cur[i] = counts[i];
+    } else {
+        // exclusive scan of the T totals: contiguous chunk per thread, wavefront scan of the chunk sums, 4 wavefront sums
+        const int per = (T + FPLACE_THREADS - 1) / FPLACE_THREADS;
+        const int lo = min(T, t * per), hi = min(T, lo + per);
+        long long sum = 0;
+        for (int i = lo; i < hi; ++i) sum += max(counts[i], 0);
+        long long incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long u = __shfl_up(incl, off, 64);
+            if ((t & 63) >= off) incl += u;
+        }
+        if ((t & 63) == 63) s_wsum[t >> 6] = incl;
+        __syncthreads();
+        long long run = incl - sum, total = 0;
+        for (int w = 0; w < FPLACE_THREADS / 64; ++w) {
+            const long long ws = s_wsum[w];
+            if (w < (t >> 6)) run += ws;
+            total += ws;
+        }
+        const bool pub = blockIdx.x == 0;
+        for (int i = lo; i < hi; ++i) {
+            const int cval = counts[i];
+            if (cval < 0 && pub) atomicOr(status, 2);
+            const int32_t o = (int32_t)min(run, (long long)0x7fffffff);
+            s_cur[i] = o;
+            if (pub) offsets_out[i] = o;
+            run += max(cval, 0);
+        }
+        if (pub && t == 0) {
+            offsets_out[T] = (int32_t)min(total, (long long)0x7fffffff);
+            M_dev[0] = total;
+            if (total > M_cap || total > 0x7fffffffLL) atomicOr(status, 1);
+        }
+    }
+    __syncthreads();
+    if (span <= 0) return;
+    for (int c = 0; c < C; ++c) {
+        const int32_t *brow = cnt + ((int64_t)c * R + row) * n_tiles;
+        for (int i = t; i < span; i += FPLACE_THREADS) {
+            const int tl = ys0 * tile_w + i;
+            s_cur[c * n_tiles + tl] += (c == 0 && i == t) ? base0 : brow[tl];
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < C; ++c) {
+        const int n = min(max(c == 0 ? n0 : n_inst[c * R + row], 0), seg_cap);
+        const PreRec *seg = recs + ((int64_t)c * R + row) * seg_cap;
+        for (int i0 = 0; i0 < n; i0 += FPLACE_THREADS) {
+            const int i = i0 + t;
+            Rect r = {0, 0, 0, 0};
+            unsigned int klo = 0u, khi = 0u;
+            if (i < n) {
+                const PreRec pr = (c == 0 && i0 == 0) ? pre0 : seg[i];
+                r.x0 = (int)(pr.xs & 0xffffu); r.x1 = (int)(pr.xs >> 16);
+                r.y0 = max((int)(pr.ys_c & 0xfffu), ys0); r.y1 = min((int)((pr.ys_c >> 12) & 0xfffu), ys1);
+                klo = pr.id; khi = pr.depth;
+                if (r.y1 <= r.y0) r = Rect{0, 0, 0, 0};
+            }
+            place_rects(r, tile_w, klo, khi, s_cur, M_cap, entries, c * n_tiles);
+        }
+    }
+}
+
+// Pose gradient of a pose-only closure over the VISIBLE instances the front left behind (instead of a pass over all N
+// Gaussians that skips the culled two thirds): one thread per instance record recomputes the projection of its Gaussian
+// (project_core) and pushes the record-shaped gradient row [v_xy, v_conic, ..., v_depth] through conic -> cov2d -> J, Sc ->
+// (R, t) exactly as project_bwd_kernel<POSE_ONLY> does; the 12 entries of d loss / d [R | t] are summed per workgroup and
+// left as one partial row per (front row, camera) for the consumer that finishes the pose backward (gsx_track_opt_tail /
+// gsx_pose_zhou_bwd_partials).
+constexpr int FPB_THREADS = 256;
+
+__global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
+    const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
+    const float *__restrict__ viewmats, const float *__restrict__ Ks, int64_t N, int C, int W, int H, float eps2d,
+    float near_p, float far_p, int flags, const float *__restrict__ v_rec, const PreRec *__restrict__ recs,
+    const int32_t *__restrict__ n_inst, int R, int seg_cap, float *__restrict__ partials /*[R][C][12]*/) {
+    __shared__ float s_part[FPB_THREADS / 64][12];
+    const int row = blockIdx.x, c = blockIdx.y;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int n = min(max(n_inst[c * R + row], 0), seg_cap);
+    const PreRec *seg = recs + ((int64_t)c * R + row) * seg_cap;
+    Cam cam;
+    load_cam(viewmats, Ks, c, cam);
+    float acc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = t; i < n; i += FPB_THREADS) {
+        const int64_t idx = (int64_t)seg[i].id;
+        const int64_t g = idx - (int64_t)c * N;
+        if (g < 0 || g >= N) continue;                       // never from a sane front; keeps the gathers in range
+        const float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+        const float q[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
+        float s[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+        if (flags & GSX_PROJ_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
+        const float4 *r4 = reinterpret_cast<const float4 *>(v_rec + idx * 12);
+        const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2];
+        QuatRot qr;
+        quat_to_rotmat(q, qr);
+        float M[9];
+        Sym3 S;
+        covar_from_rot_scale(qr.R, s, M, S);
+        Proj p;
+        if (!project_core(mean, S, cam, W, H, eps2d, near_p, far_p, p)) continue;
+        const float vmx = q0.x, vmy = q0.y;
+        const float vdepth = (flags & GSX_PROJ_RENDER_DEPTH) ? q2.y : 0.f;          // record column 9
+        // 1. conic = inverse(blurred cov2d): GX = -Y G Y
+        const float a = p.conic[0], b = p.conic[1], cc = p.conic[2];
+        const float va = q0.z, vb = 0.5f * q0.w, vc = q1.x;
+        const float P00 = va * a + vb * b, P01 = va * b + vb * cc;
+        const float P10 = vb * a + vc * b, P11 = vb * b + vc * cc;
+        const float G00 = -(a * P00 + b * P10), G01 = -(a * P01 + b * P11), G11 = -(b * P01 + cc * P11);
+        // 3. cov2d = J Sc J^T
+        const float Jm[6] = {p.J00, 0.f, p.J02, 0.f, p.J11, p.J12};
+        const float Gm[4] = {G00, G01, G01, G11};
+        float GJ[6];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) GJ[i2 * 3 + j] = Gm[i2 * 2 + 0] * Jm[j] + Gm[i2 * 2 + 1] * Jm[3 + j];
+        float vSc[9];
+#pragma unroll
+        for (int i2 = 0; i2 < 3; ++i2)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vSc[i2 * 3 + j] = Jm[i2] * GJ[j] + Jm[3 + i2] * GJ[3 + j];
+        float vJ[6];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                vJ[i2 * 3 + j] = 2.0f * (GJ[i2 * 3 + 0] * symget(p.Sc, 0, j) + GJ[i2 * 3 + 1] * symget(p.Sc, 1, j) +
+                                         GJ[i2 * 3 + 2] * symget(p.Sc, 2, j));
+        const float fx = cam.fx, fy = cam.fy;
+        const float x = p.pc[0], y = p.pc[1], rz = p.rz, rz2 = rz * rz, rz3 = rz2 * rz;
+        float vpc[3];
+        vpc[0] = fx * rz * vmx;
+        vpc[1] = fy * rz * vmy;
+        vpc[2] = -(fx * x * vmx + fy * y * vmy) * rz2 + vdepth;
+        const float vJ00 = vJ[0], vJ02 = vJ[2], vJ11 = vJ[4], vJ12 = vJ[5];
+        if (p.x_in) vpc[0] += -fx * rz2 * vJ02; else vpc[2] += -fx * rz3 * vJ02 * p.tx;
+        if (p.y_in) vpc[1] += -fy * rz2 * vJ12; else vpc[2] += -fy * rz3 * vJ12 * p.ty;
+        vpc[2] += -fx * rz2 * vJ00 - fy * rz2 * vJ11 + 2.0f * fx * p.tx * rz3 * vJ02 + 2.0f * fy * p.ty * rz3 * vJ12;
+        // 5. Sc = R S R^T ; pc = R mu + t
+        const float *Rm = cam.R;
+        float A[9];
+#pragma unroll
+        for (int i2 = 0; i2 < 3; ++i2)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                A[i2 * 3 + j] = vSc[i2 * 3 + 0] * Rm[j] + vSc[i2 * 3 + 1] * Rm[3 + j] + vSc[i2 * 3 + 2] * Rm[6 + j];
+#pragma unroll
+        for (int i2 = 0; i2 < 3; ++i2) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                acc[i2 * 4 + j] += 2.0f * (A[i2 * 3 + 0] * symget(S, 0, j) + A[i2 * 3 + 1] * symget(S, 1, j) +
+                                           A[i2 * 3 + 2] * symget(S, 2, j)) +
+                                   vpc[i2] * mean[j];
+            acc[i2 * 4 + 3] += vpc[i2];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const float tot = gsx_wave_sum(acc[k]);
+        if (lane == 0) s_part[wave][k] = tot;
+    }
+    __syncthreads();
+    if (t < 12) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < FPB_THREADS / 64; ++w) sum += s_part[w][t];
+        partials[((int64_t)row * C + c) * 12 + t] = sum;
+    }
+}
+
+struct FrontLayout {
+    int64_t counts_off, ninst_off, entries_off, scratch_off, matrix_off, recs_off, total;
+    int items, R;
+};
+
+FrontLayout front_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap) {
+    FrontLayout L;
+    const int64_t T = C * tile_w * tile_h;
+    int items = 1;
+    while ((N + (int64_t)FRONT_THREADS * items - 1) / ((int64_t)FRONT_THREADS * items) > 256 && items < 8) items *= 2;
+    while ((N + (int64_t)FRONT_THREADS * items - 1) / ((int64_t)FRONT_THREADS * items) > GB_MAX) items *= 2;
+    L.items = items;
+    L.R = (int)((N + (int64_t)FRONT_THREADS * items - 1) / ((int64_t)FRONT_THREADS * items));
+    if (L.R < 1) L.R = 1;
+    L.counts_off = 0;
+    L.ninst_off = gsx_align256((T + 1) * 4);
+    L.entries_off = L.ninst_off + gsx_align256(C * (int64_t)GB_MAX * 4);
+    L.scratch_off = L.entries_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);
+    L.matrix_off = L.scratch_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);
+    L.recs_off = L.matrix_off + gsx_align256(T * (int64_t)GB_MAX * 4);
+    L.total = gsx_align256(L.recs_off + C * (int64_t)L.R * FRONT_THREADS * items * 16 + 256);
+    return L;
+}
+
+}  // namespace
+
+extern "C" int64_t gsx_front_workspace_bytes(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap) {
+    return front_layout(N, C, tile_w, tile_h, M_cap).total;
+}
+
+extern "C" int gsx_front_fwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                             const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                             float far_plane, int flags, const float *logit_opacities, const float *logit_colors,
+                             const float *log_uncertainties, int32_t *radii, float *means2d, float *depths, float *conics,
+                             int32_t *tiles_per_gauss, float *rec, float *v_rec_clear, int32_t *vis_count, int64_t M_cap,
+                             int32_t *offsets, int64_t *M_dev, int32_t *status, int32_t *flatten_ids, int32_t *tile_order,
+                             void *workspace, int64_t workspace_bytes, void *stream) {
+    GSX_CHECK_ARG(N >= 1 && C >= 1 && C <= 255 && W > 0 && H > 0 && C * N < ((int64_t)1 << 31));
+    GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && logit_opacities && logit_colors && radii && tiles_per_gauss && rec);
+    GSX_CHECK_ARG(!(flags & GSX_PROJ_BETAS) || log_uncertainties);
+    GSX_CHECK_ARG(offsets && M_dev && status && flatten_ids && M_cap >= 1 && M_cap < ((int64_t)1 << 31));
+    const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
+    const int64_t n_tiles = (int64_t)tile_w * tile_h, T = C * n_tiles;
+    GSX_CHECK_ARG(tile_w < 65536 && tile_h < 4096);
+    const FrontLayout L = front_layout(N, C, tile_w, tile_h, M_cap);
+    if (!workspace || workspace_bytes < L.total) {
+        gsx_set_error("gsx_front_fwd: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)L.total);
+        return GSX_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    int32_t *counts = (int32_t *)(ws + L.counts_off);
+    FrontArgs a;
+    a.means = means; a.quats = quats; a.scales = scales; a.viewmats = viewmats; a.Ks = Ks;
+    a.logit_opac = logit_opacities; a.logit_colors = logit_colors; a.log_unc = log_uncertainties;
+    a.N = N; a.C = (int)C; a.W = W; a.H = H; a.flags = flags; a.tile_w = tile_w; a.tile_h = tile_h;
+    a.items = L.items; a.R = L.R; a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane;
+    a.radii = radii; a.tiles = tiles_per_gauss; a.vis_count = vis_count; a.means2d = means2d; a.depths = depths;
+    a.conics = conics; a.rec = rec; a.v_rec = v_rec_clear;
+    a.cnt = (int32_t *)(ws + L.matrix_off); a.n_inst = (int32_t *)(ws + L.ninst_off); a.recs = (PreRec *)(ws + L.recs_off);
+    const size_t front_lds = (size_t)((T + C + 1) * 4 + 2 * FRONT_THREADS * L.items);   // histogram + survivor list
+    if (front_lds > 65536 || L.items > 63) {
+        gsx_set_error("gsx_front_fwd: %lld tiles over all cameras / %d Gaussians per thread do not fit the LDS plan",
+                      (long long)T, L.items);
+        return GSX_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(front_project_kernel, dim3((unsigned)L.R), dim3(FRONT_THREADS), front_lds, st, a);
+    GSX_CHECK_LAUNCH();
+    // with a launch order wanted the totals are scanned (and bucketed) by the one-workgroup kernel into `offsets` itself;
+    // otherwise every placement workgroup scans them on its own and workgroup 0 publishes the offsets
+    int32_t *col_out = tile_order ? offsets : counts;
+    hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((n_tiles + 63) / 64), (unsigned)C), dim3(64 * CS_GROUPS), 0, st,
+                       a.cnt, L.R, (int)n_tiles, col_out);
+    GSX_CHECK_LAUNCH();
+    if (tile_order) {
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, (int)T, M_cap, offsets, M_dev, status, tile_order);
+        GSX_CHECK_LAUNCH();
+    }
+    const int stripes = tile_h >= FRONT_STRIPES ? FRONT_STRIPES : 1;
+    const int rps = (tile_h + stripes - 1) / stripes;
+    unsigned long long *entries = (unsigned long long *)(ws + L.entries_off);
+    unsigned long long *scratch = (unsigned long long *)(ws + L.scratch_off);
+    hipLaunchKernelGGL(front_place_kernel, dim3((unsigned)(L.R * stripes)), dim3(FPLACE_THREADS), (size_t)(T * 4), st,
+                       a.recs, a.n_inst, L.R, FRONT_THREADS * L.items, (int)C, tile_w, tile_h, stripes, rps, M_cap,
+                       col_out, tile_order ? 1 : 0, a.cnt, offsets, M_dev, status, entries);
+    GSX_CHECK_LAUNCH();
+    const uint32_t id_max = (uint32_t)(C * N - 1);
+    hipLaunchKernelGGL(tile_sort_count_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, scratch, offsets,
+                       (int)n_tiles, bit_length((uint32_t)n_tiles), M_cap, id_max, (int64_t *)nullptr, flatten_ids);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int64_t gsx_front_rows(int64_t N, int64_t C, int tile_w, int tile_h) {
+    return front_layout(N, C, tile_w, tile_h, 1).R;
+}
+
+extern "C" int gsx_front_pose_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                                  const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                                  float far_plane, int flags, const float *v_rec, int64_t M_cap, const void *workspace,
+                                  int64_t workspace_bytes, float *partials, void *stream) {
+    GSX_CHECK_ARG(N >= 1 && C >= 1 && C <= 255 && W > 0 && H > 0 && M_cap >= 1);
+    GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && v_rec && partials);
+    const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
+    const FrontLayout L = front_layout(N, C, tile_w, tile_h, M_cap);
+    if (!workspace || workspace_bytes < L.total) {
+        gsx_set_error("gsx_front_pose_bwd: not the workspace of gsx_front_fwd (%lld < %lld)", (long long)workspace_bytes,
+                      (long long)L.total);
+        return GSX_E_WORKSPACE;
+    }
+    const char *ws = (const char *)workspace;
+    hipLaunchKernelGGL(front_pose_bwd_kernel, dim3((unsigned)L.R, (unsigned)C), dim3(FPB_THREADS), 0, (hipStream_t)stream,
+                       means, quats, scales, viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, flags, v_rec,
+                       (const PreRec *)(ws + L.recs_off), (const int32_t *)(ws + L.ninst_off), L.R,
+                       FRONT_THREADS * L.items, partials);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}

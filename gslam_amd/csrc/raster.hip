@@ -621,16 +621,18 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
     hipStream_t st = (hipStream_t)stream;
     const int variant = n_touched ? raster_variant(false, T) : 5;   // only the v4 kernels can skip the touched counts
+    const char *pf = getenv("GSX_PAD_F");
+    const size_t pad_f = pf ? (size_t)atoi(pf) * 1024 : 0;
     const bool v1 = (use_v1() || variant == 1) && !offsets_has_end && n_touched;
 #define LAUNCH(ch, rs)                                                                                              \
     do {                                                                                                            \
         if (variant == 5 && !v1) {                                                                                  \
             if (n_touched)                                                                                          \
-                hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, rec,   \
+                hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, true>), dim3((unsigned)T), dim3(256), pad_f, st, rec,   \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
                                    visibility_min_T, render, alphas, last_ids, n_touched, tile_order);                          \
             else                                                                                                    \
-                hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, rec,  \
+                hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, false>), dim3((unsigned)T), dim3(256), pad_f, st, rec,  \
                                    backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
                                    visibility_min_T, render, alphas, last_ids, n_touched, tile_order);                          \
         } else if (variant == 4 && !v1) {                                                                           \
@@ -681,6 +683,8 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     const int64_t T = C * tile_w * tile_h;
     hipStream_t st = (hipStream_t)stream;
     const int variant = raster_variant(true, T);
+    const char *pb = getenv("GSX_PAD_B");
+    const size_t pad_b = pb ? (size_t)atoi(pb) * 1024 : 0;
     const bool v1 = (use_v1() || variant == 1) && !offsets_has_end;
     const char *bb = getenv("GSX_BWD_MODE");
     // Gradient accumulation without LDS atomics (reduce-scatter + cross-row sums in registers, plain stores into
@@ -692,7 +696,9 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     const int bwd_auto = T >= 4096 ? 4 : (M / (T > 0 ? T : 1) > 1000 ? 6 : 5);
     // geometry-only gradients exist in the quadrant kernels; a caller that asks for them gets those kernels
     const bool geom_only = geometry_only != 0 && !v_abs;
-    const int bwd_mode = geom_only ? (M / (T > 0 ? T : 1) > 1000 ? 6 : 5)
+    // geometry-only: batches of 64 (all 1200 workgroups of a camera resident at once: 25 KiB of LDS, 73 VGPRs; with
+    // batches of 128 only 4 workgroups fit a CU and 15 % of the tiles wait for a second round: 86.9 -> 80.9 us at 500 k)
+    const int bwd_mode = geom_only ? ((bb && (bb[0] == '5' || bb[0] == '6')) ? bb[0] - '0' : 5)
                                    : (bb && bb[0] >= '0' && bb[0] <= '6') ? bb[0] - '0' : bwd_auto;
     const char *sb = getenv("GSX_BWD_SCALAR");
     const bool scalar_bwd = sb && sb[0] == '1';
@@ -703,20 +709,20 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
         if (variant >= 4 && !v1 && !v_abs) {                                                                        \
             if (bwd_mode == 5)                                                                                      \
                 if (geom_only)                                                                                      \
-                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, true>), dim3((unsigned)T), dim3(256), 0, st, \
+                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, true>), dim3((unsigned)T), dim3(256), pad_b, st, \
                                        rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
                                        tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
                 else                                                                                                \
-                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, false>), dim3((unsigned)T), dim3(256), 0, st, \
+                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, false>), dim3((unsigned)T), dim3(256), pad_b, st, \
                                        rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
                                        tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
             else if (bwd_mode == 6)                                                                                 \
                 if (geom_only)                                                                                      \
-                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128, true>), dim3((unsigned)T), dim3(256), 0, st, \
+                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128, true>), dim3((unsigned)T), dim3(256), pad_b, st, \
                                        rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
                                        tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
                 else                                                                                                \
-                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128, false>), dim3((unsigned)T), dim3(256), 0, st, \
+                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128, false>), dim3((unsigned)T), dim3(256), pad_b, st, \
                                        rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
                                        tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
             else if (bwd_mode == 3)                                                                                 \

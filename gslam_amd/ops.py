@@ -8,7 +8,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -236,9 +235,10 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
         tiles_per_gauss = torch.empty(Cn, N, dtype=torch.int32, device=dev)
         check(lib.gsx_isect_count(ptr(means2d), ptr(radii), Cn * N, tile_width, tile_height, ptr(tiles_per_gauss), st),
               "gsx_isect_count")
-    if sort and os.environ.get("GSX_SORT_V1", "0") != "1":
-        # v2: tile-binned sort (csrc/isect_bin.hip).  This gsplat-shaped API returns exactly-sized arrays, so M is read
-        # back once here; the fused gslam path (gslam_amd.rasterization) uses the same kernels without any read-back.
+    if sort:
+        # tile-binned sort (csrc/isect_bin.hip).  This gsplat-shaped API returns exactly-sized arrays, so M is read
+        # back once here; the fused gslam path (gslam_amd.rasterization with an IsectCapacity, gslam_amd.plan) uses the
+        # same kernels without any read-back.
         M = int(tiles_per_gauss.sum().item()) if Cn * N > 0 else 0
         isect_ids = torch.empty(M, dtype=torch.int64, device=dev)
         flatten_ids = torch.empty(M, dtype=torch.int32, device=dev)
@@ -248,6 +248,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
             # instead of re-deriving them from the 64-bit keys (175 us for 76 M intersections)
             isect_ids._gsx_offsets = (off[:-1].view(Cn, tile_height, tile_width), isect_ids._version)
         return tiles_per_gauss, isect_ids, flatten_ids
+    # sort=False: gsplat's unsorted emission order (flatten order, tiles row-major): own scan + emit
     cum = torch.empty(Cn * N, dtype=torch.int64, device=dev)
     M = 0
     if Cn * N > 0:
@@ -259,10 +260,8 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     isect_ids = torch.empty(M, dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(M, dtype=torch.int32, device=dev)
     if M > 0:
-        ws = workspace(lib.gsx_isect_sort_workspace_bytes(M), dev, "sort")
-        check(lib.gsx_isect_emit_sort(ptr(means2d), ptr(radii), ptr(depths), ptr(cum), N, Cn, tile_width, tile_height,
-                                      M, 1 if sort else 0, ptr(isect_ids), ptr(flatten_ids), ptr(ws), ws.numel(), st),
-              "gsx_isect_emit_sort")
+        check(lib.gsx_isect_emit(ptr(means2d), ptr(radii), ptr(depths), ptr(cum), N, Cn, tile_width, tile_height, M,
+                                 ptr(isect_ids), ptr(flatten_ids), st), "gsx_isect_emit")
     return tiles_per_gauss, isect_ids, flatten_ids
 
 

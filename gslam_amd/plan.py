@@ -30,6 +30,7 @@ from .ops import PROJ_BETAS, PROJ_LOG_SCALES, PROJ_RENDER_DEPTH
 
 TILE = 16
 _VIEW_PARTIALS = 8      # GSX_PROJ_VIEW_PARTIALS
+_SKIP_CULLED = 16       # GSX_PROJ_SKIP_CULLED
 
 
 def _arr(ptrs: Sequence[Optional[int]]):
@@ -120,7 +121,9 @@ class RenderPlan:
     def __init__(self, splats, n_cams: int, width: int, height: int, *, render_depth: bool, grads: str = 'pose',
                  Ks: Optional[torch.Tensor] = None, capacity: Optional[int] = None, need_n_touched: bool = False,
                  visibility_min_T: float = 0.5, grad_out: Optional[Dict[str, torch.Tensor]] = None,
-                 near_plane: float = 0.01, far_plane: float = 1e10, eps2d: float = 0.3):
+                 near_plane: float = 0.01, far_plane: float = 1e10, eps2d: float = 0.3, front: Optional[bool] = None):
+        """front: use the fused projection + tile-list front (gsx_front_fwd, four launches) instead of gsx_project_fwd +
+        gsx_isect_bin_sort (seven); None = where it is the faster one (measured)"""
         assert grads in ('none', 'pose', 'full')
         self.splats = splats
         self.map = _map_tensors(splats)
@@ -175,6 +178,13 @@ class RenderPlan:
                 if not (g.is_contiguous() and g.shape == t.shape and g.dtype == f32 and g.device == dev):
                     raise RuntimeError(f"grad_out[{name}] must be a contiguous float32 tensor shaped like the parameter")
                 self.v_map.append(g)
+        fits = self.T * 4 + 64 + 16384 <= 65536 and Cn <= 255 and 1 <= N <= 5_000_000
+        self.front = (fits and Cn * N < (1 << 20)) if front is None else (bool(front) and fits)
+        # a pose-only closure never reads the rows of culled instances nor the separate means2d / depths / conics arrays
+        self.lean = grads == 'pose'
+        if self.front and grads == 'pose':
+            # pose gradient over the visible instances the front leaves behind: one partial row per (front row, camera)
+            self.pose_blocks = int(lib.gsx_front_rows(N, Cn, self.tile_w, self.tile_h))
         self.capacity = 0
         self.flat = self.tile_order = self.isect_ws = None
         self.last_M = 0
@@ -189,7 +199,10 @@ class RenderPlan:
         self.flat = torch.empty(cap, dtype=torch.int32, device=dev)
         # heaviest-first launch order pays off while the tile lists are short (see rasterization.rasterization)
         self.tile_order = torch.empty(self.T, dtype=torch.int32, device=dev) if cap < 1000 * self.T else None
-        nbytes = int(lib.gsx_isect_bin_workspace_bytes_n(self.C, self.N, self.tile_w, self.tile_h, cap))
+        if self.front:
+            nbytes = int(lib.gsx_front_workspace_bytes(self.N, self.C, self.tile_w, self.tile_h, cap))
+        else:
+            nbytes = int(lib.gsx_isect_bin_workspace_bytes_n(self.C, self.N, self.tile_w, self.tile_h, cap))
         self.isect_ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
         self.stale = True
 
@@ -254,14 +267,28 @@ class RenderPlan:
                                   self.tile_h, _p(m[3]), _p(m[4]), _p(m[5]), _p(self.rec), _p(self.vis_count),
                                   _p(self.v_rec), st), "gsx_project_fwd")
 
+    def _front(self, st: int):
+        m = self.map
+        lean = self.lean
+        check(lib.gsx_front_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
+                                self.H, self.eps2d, self.near, self.far, self.flags | (_SKIP_CULLED if lean else 0),
+                                _p(m[3]), _p(m[4]), _p(m[5]), _p(self.radii), None if lean else _p(self.means2d),
+                                None if lean else _p(self.depths), None if lean else _p(self.conics), _p(self.tiles),
+                                _p(self.rec), _p(self.v_rec), _p(self.vis_count), self.capacity, _p(self.offsets),
+                                _p(self.M_dev), _p(self.status), _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
+                                self.isect_ws.numel(), st), "gsx_front_fwd")
+
     def forward(self, st: int):
         if self.capacity == 0:
             raise RuntimeError("RenderPlan.probe() first (tile-list capacity)")
-        self._project(st)
-        check(lib.gsx_isect_bin_sort(_p(self.means2d), _p(self.radii), _p(self.depths), self.N, self.C, self.tile_w,
-                                     self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status), None,
-                                     _p(self.flat), _p(self.tile_order), _p(self.isect_ws), self.isect_ws.numel(), st),
-              "gsx_isect_bin_sort")
+        if self.front:
+            self._front(st)
+        else:
+            self._project(st)
+            check(lib.gsx_isect_bin_sort(_p(self.means2d), _p(self.radii), _p(self.depths), self.N, self.C, self.tile_w,
+                                         self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status),
+                                         None, _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
+                                         self.isect_ws.numel(), st), "gsx_isect_bin_sort")
         if self.n_touched is not None:
             check(lib.gsx_zero_words(_p(self.n_touched), self.n_touched.numel(), st), "gsx_zero_words")
         check(lib.gsx_raster_fwd(_p(self.rec), self.CH, _p(self.backgrounds), _p(self.offsets), _p(self.flat),
@@ -279,6 +306,12 @@ class RenderPlan:
                                  1 if self.geom_only else 0, st), "gsx_raster_bwd")
         m = self.map
         vr = self.v_rec.data_ptr()
+        if self.grads == 'pose' and self.front:
+            check(lib.gsx_front_pose_bwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C,
+                                         self.W, self.H, self.eps2d, self.near, self.far, self.flags, vr, self.capacity,
+                                         _p(self.isect_ws), self.isect_ws.numel(), _p(self.pose_ws), st),
+                  "gsx_front_pose_bwd")
+            return
         if self.grads == 'pose':
             outs = (None,) * 3 + (None,) + (None,) * 3
         else:

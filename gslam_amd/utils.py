@@ -28,26 +28,28 @@ def edge_aware_tv(depth: torch.Tensor, rgb: torch.Tensor, mask: Optional[torch.T
 
 
 class StopOnPlateau:
-    """Stop optimisation if the loss doesn't decrease appreciably for a bit (gslam/utils.py:164-186, verbatim
-    state machine including its quirks: the counter counts DEcreases below min_loss)."""
+    """Early-stop rule of the mapping loop (same interface and same decisions as gslam/utils.py:164-186, pinned by the
+    reference-generated trace in tests/golden/utils.npz).  Restated: the first loss only seeds the comparison value and
+    never stops.  A loss above ``min_loss`` is ignored altogether - it neither stops, nor counts, nor becomes the
+    comparison value.  A loss at or below ``min_loss`` that improves on the comparison value adds one to a streak and
+    stops once the streak reaches ``patience``; one that does not improve resets the streak.  Either way it becomes the
+    new comparison value (unless it just stopped)."""
 
     def __init__(self, patience, min_loss):
         self.patience = patience
-        self.counter = 0
         self.min_loss = min_loss
-        self.last_loss = None
+        self.counter = 0            # current streak of improving losses below min_loss
+        self.last_loss = None       # comparison value
 
     def stop(self, loss):
-        if self.last_loss is None:
+        seeded = self.last_loss is not None
+        if not seeded:
             self.last_loss = loss
+        if not seeded or loss > self.min_loss:
             return False
-        if loss > self.min_loss:
-            return False
-        elif self.last_loss > loss:
-            self.counter += 1
-            if self.counter >= self.patience:
-                return True
-        else:
-            self.counter = 0
+        improved = loss < self.last_loss
+        self.counter = self.counter + 1 if improved else 0
+        if improved and self.counter >= self.patience:
+            return True
         self.last_loss = loss
         return False

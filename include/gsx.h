@@ -48,6 +48,8 @@ extern "C" {
 #define GSX_PROJ_VIEW_PARTIALS 8  /* gsx_project_bwd only: leave the per-workgroup pose-gradient partials
                                      ([gsx_project_bwd_blocks(N)][C][12] floats at the start of the workspace) for a fused
                                      consumer (gsx_track_opt_tail) and skip the finishing launch; v_viewmats is ignored */
+#define GSX_PROJ_SKIP_CULLED 16   /* gsx_front_fwd only: rows of culled (camera, Gaussian) pairs get radii = 0 and
+                                     tiles_per_gauss = 0 and nothing else (nobody reads them in a pose-only closure) */
 #define GSX_PROJ_BETAS 4          /* gslam record: append beta=clamp(exp(log_unc),0.01) (rasterization.py:149,249-256) */
 
 int gsx_version(void);
@@ -108,15 +110,14 @@ int gsx_pack_records(const float *means2d, const float *conics, const float *opa
  */
 int gsx_isect_count(const float *means2d, const int32_t *radii, int64_t CN, int tile_w, int tile_h,
                     int32_t *tiles_per_gauss, void *stream);
-/* inclusive scan of tiles_per_gauss -> cum_tiles int64 [CN]; M = cum_tiles[CN-1] */
+/* inclusive scan of tiles_per_gauss -> cum_tiles int64 [CN]; M = cum_tiles[CN-1] (own three-launch scan, no library) */
 int64_t gsx_scan_workspace_bytes(int64_t CN);
 int gsx_isect_scan(const int32_t *tiles_per_gauss, int64_t CN, int64_t *cum_tiles, void *workspace,
                    int64_t workspace_bytes, void *stream);
-/* emit + sort; writes sorted isect_ids [M] and flatten_ids [M] */
-int64_t gsx_isect_sort_workspace_bytes(int64_t M);
-int gsx_isect_emit_sort(const float *means2d, const int32_t *radii, const float *depths, const int64_t *cum_tiles,
-                        int64_t N, int64_t C, int tile_w, int tile_h, int64_t M, int sort, int64_t *isect_ids,
-                        int32_t *flatten_ids, void *workspace, int64_t workspace_bytes, void *stream);
+/* unsorted emission in gsplat's order (isect_tiles(sort=False)): for every visible (camera, Gaussian) in flatten order, its
+ * tiles row-major, isect_ids[k] = key, flatten_ids[k] = flatten id, k from cum_tiles.  The sort is gsx_isect_bin_sort. */
+int gsx_isect_emit(const float *means2d, const int32_t *radii, const float *depths, const int64_t *cum_tiles, int64_t N,
+                   int64_t C, int tile_w, int tile_h, int64_t M, int64_t *isect_ids, int32_t *flatten_ids, void *stream);
 int gsx_isect_offset_encode(const int64_t *isect_ids, int64_t M, int64_t C, int tile_w, int tile_h,
                             int32_t *offsets /*[C,tile_h,tile_w]*/, void *stream);
 
@@ -134,6 +135,33 @@ int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, const float *
                        int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev, int32_t *status,
                        int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_order, void *workspace,
                        int64_t workspace_bytes, void *stream);
+
+/* ---- K1 + K3..K7 fused for the launch plans (csrc/isect_bin.hip, "fused front"): the gslam front-end projection of
+ * gsx_project_fwd (flags: GSX_PROJ_LOG_SCALES implied by the caller's data, RENDER_DEPTH, BETAS, SKIP_CULLED; radius_clip 0)
+ * and the sync-free tile lists of gsx_isect_bin_sort, in four launches: the projection counts every visible instance into
+ * its workgroup's row of the count matrix and leaves a 16-byte instance record, the placement scans the per-tile totals
+ * itself.  Same outputs, bit for bit: radii, tiles_per_gauss, rec [C,N,12], vis_count, offsets [T+1], M_dev, status,
+ * flatten_ids [M_cap], tile_order (nullable).  means2d / depths / conics are nullable (the rasteriser reads the record).
+ * v_rec_clear nullable.  Limits: C <= 255, C * tile_w * tile_h * 4 + 64 bytes of LDS <= 64 KiB. */
+int64_t gsx_front_workspace_bytes(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap);
+int gsx_front_fwd(const float *means, const float *quats, const float *scales, const float *viewmats, const float *Ks,
+                  int64_t N, int64_t C, int W, int H, float eps2d, float near_plane, float far_plane, int flags,
+                  const float *logit_opacities, const float *logit_colors, const float *log_uncertainties,
+                  int32_t *radii, float *means2d, float *depths, float *conics, int32_t *tiles_per_gauss, float *rec,
+                  float *v_rec_clear, int32_t *vis_count, int64_t M_cap, int32_t *offsets, int64_t *M_dev,
+                  int32_t *status, int32_t *flatten_ids, int32_t *tile_order, void *workspace, int64_t workspace_bytes,
+                  void *stream);
+
+/* Pose gradient of a pose-only closure from the instance records gsx_front_fwd left in its workspace (same N, C, W, H,
+ * M_cap): the pose part of gsx_project_bwd(v_means = NULL, flags | GSX_PROJ_VIEW_PARTIALS) over the visible instances
+ * only.  v_rec [C,N,12]: the gradient records of gsx_raster_bwd (xy, conic and - with RENDER_DEPTH - depth columns read).
+ * partials [gsx_front_rows(...)][C][12]: one partial row of d loss / d [R | t] per (front row, camera), to be summed by
+ * gsx_track_opt_tail / gsx_pose_zhou_bwd_partials (n_blocks = gsx_front_rows). */
+int64_t gsx_front_rows(int64_t N, int64_t C, int tile_w, int tile_h);
+int gsx_front_pose_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                       const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                       float far_plane, int flags, const float *v_rec, int64_t M_cap, const void *workspace,
+                       int64_t workspace_bytes, float *partials, void *stream);
 
 /* ---- K8: gsplat(fork) rasterize_to_pixels fwd (gslam/rasterization.py:325-339; fork: + n_touched) ----------------
  * rec: splat records [C*N, gsx_record_stride(CH)].  render [C,H,W,CH], alphas [C,H,W], last_ids [C,H,W] (global

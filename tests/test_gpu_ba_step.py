@@ -142,9 +142,10 @@ def test_binning_variants_give_identical_tile_lists(dev, monkeypatch, presort):
     tw, th = math.ceil(W / 16), math.ceil(H / 16)
     radii, m2d, dep, _, _ = ops.fully_fused_projection(sc["means"], None, sc["quats"], torch.exp(sc["scales"]) * 2.0,
                                                        viewmats.to(dev), Ks.to(dev), W, H)
-    monkeypatch.setenv("GSX_SORT_V1", "1")
-    _, ids1, flat1 = ops.isect_tiles(m2d, radii, dep, 16, tw, th, n_cameras=C)        # device-wide radix sort
-    monkeypatch.setenv("GSX_SORT_V1", "0")
+    # yardstick: gsplat's unsorted emission (own scan + emit) put in order by a device-wide stable sort of the 64-bit keys
+    _, ids_u, flat_u = ops.isect_tiles(m2d, radii, dep, 16, tw, th, sort=False, n_cameras=C)
+    ids1, order = torch.sort(ids_u, stable=True)
+    flat1 = flat_u[order]
     monkeypatch.setenv("GSX_BIN_PRESORT", presort)
     _, ids2, flat2 = ops.isect_tiles(m2d, radii, dep, 16, tw, th, n_cameras=C)
     assert ids1.shape[0] > 100000 and torch.equal(ids1, ids2) and torch.equal(flat1, flat2)

@@ -76,13 +76,12 @@ def test_tile_lists_full_size(dev, n, c, W, H):
     off = ops.isect_offset_encode(ids, c, tw, th)
     assert int(tpg.sum()) == ids.shape[0] > 0
     _check_tile_lists(radii, m2d, dep, ids, flat, off, c, tw, th)
-    if n <= 1_000_000:     # second implementation: device-wide rocPRIM radix sort of the 64-bit keys
-        os.environ["GSX_SORT_V1"] = "1"
-        try:
-            _, ids1, flat1 = ops.isect_tiles(m2d, radii, dep, 16, tw, th, n_cameras=c)
-        finally:
-            os.environ["GSX_SORT_V1"] = "0"
-        assert torch.equal(ids1, ids) and torch.equal(flat1, flat)
+    if n <= 1_000_000:     # second implementation: unsorted emission + a device-wide stable sort of the 64-bit keys
+        _, ids_u, flat_u = ops.isect_tiles(m2d, radii, dep, 16, tw, th, sort=False, n_cameras=c)
+        assert ids_u.shape[0] == ids.shape[0]
+        ids1, order = torch.sort(ids_u, stable=True)
+        assert torch.equal(ids1, ids) and torch.equal(flat_u[order], flat)
+        del ids_u, flat_u, ids1, order
     # sync-free path (capacity buffers, offsets with T+1 entries) gives the same lists
     cap = int(ids.shape[0] * 1.5) + 4096
     flat_buf = torch.empty(cap, dtype=torch.int32, device=dev)

@@ -205,3 +205,76 @@ def test_refiner_after_eager_ba_and_prune(dev):
     torch.cuda.synchronize()
     after = [float((f.pose()[:3, 3] - f.gt_pose[:3, 3]).norm()) for f in window]
     assert after[0] == before[0]                             # frame 0 fixed (backend.py:459-462)
+
+
+@pytest.mark.parametrize("n,n_cams,grads", [(20000, 1, 'full'), (20000, 1, 'pose'), (9000, 3, 'full'), (300000, 1, 'pose'),
+                                            (37, 2, 'full')])
+def test_fused_front_equals_projection_plus_bin_sort(dev, n, n_cams, grads):
+    """gsx_front_fwd (projection + count rows + instance records, in-kernel offset scan, striped placement) against
+    gsx_project_fwd + gsx_isect_bin_sort: every integer output bit for bit, and the render that follows"""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.plan import RenderPlan, current_stream_ptr
+    from gslam_amd.synthetic import make_cameras, make_scene
+    W, H = 640, 480
+    sc = make_scene(n, 5)
+    sc["scales"] = sc["scales"] + (0.3 if n <= 20000 else 0.0)
+    m = GaussianSplattingData.from_dict(sc, dev).no_grad_clone()
+    viewmats, Ks = make_cameras(n_cams, W, H)
+    plans = []
+    for front in (False, True):
+        r = RenderPlan(m, n_cams, W, H, render_depth=(grads == 'full'), grads=grads, front=front)
+        assert r.front == front
+        r.Ks.copy_(Ks.to(dev))
+        r.viewmats.copy_(viewmats.to(dev))
+        r.probe()
+        if r.v_rec is not None:
+            r.v_rec.fill_(7.0)                              # the forward must clear the rows it will accumulate into
+        r.forward(current_stream_ptr(dev))
+        torch.cuda.synchronize()
+        assert r.check_capacity()
+        plans.append(r)
+    a, b = plans
+    M = a.last_M
+    assert M == b.last_M and M == int(a.tiles.sum())
+    assert torch.equal(a.radii, b.radii) and torch.equal(a.tiles, b.tiles) and torch.equal(a.vis_count, b.vis_count)
+    assert torch.equal(a.offsets, b.offsets)
+    assert torch.equal(a.flat[:M], b.flat[:M])              # the sorted (tile, depth, id) order: bit-exact assignment
+    vis = a.radii > 0
+    assert torch.equal(a.rec[vis], b.rec[vis])
+    if grads == 'full':                                      # not lean: culled rows are zeros, separate arrays filled
+        assert torch.equal(a.rec, b.rec) and torch.equal(a.means2d, b.means2d) and torch.equal(a.conics, b.conics)
+        assert torch.equal(a.depths, b.depths) and float(b.v_rec.abs().max()) == 0.0
+    else:
+        assert float(b.v_rec[vis].abs().max()) == 0.0
+    assert torch.equal(a.render, b.render) and torch.equal(a.alphas, b.alphas) and torch.equal(a.last_ids, b.last_ids)
+
+
+@pytest.mark.parametrize("n,n_cams", [(30000, 1), (12000, 3)])
+def test_front_pose_backward_equals_projection_backward(dev, n, n_cams):
+    """gsx_front_pose_bwd (one thread per visible instance record) against gsx_project_bwd's pose-only pass over all
+    Gaussians: the summed pose partials d loss / d [R | t] of every camera"""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.plan import RenderPlan, current_stream_ptr
+    from gslam_amd.synthetic import make_cameras, make_scene
+    W, H = 320, 240
+    sc = make_scene(n, 8)
+    sc["scales"] = sc["scales"] + 0.4
+    m = GaussianSplattingData.from_dict(sc, dev).no_grad_clone()
+    viewmats, Ks = make_cameras(n_cams, W, H)
+    sums = []
+    for front in (False, True):
+        r = RenderPlan(m, n_cams, W, H, render_depth=False, grads='pose', front=front)
+        r.Ks.copy_(Ks.to(dev))
+        r.viewmats.copy_(viewmats.to(dev))
+        r.probe()
+        st = current_stream_ptr(dev)
+        r.forward(st)
+        r.v_render.copy_(torch.randn(r.v_render.shape, generator=torch.Generator().manual_seed(3)).to(dev) * 1e-3)
+        r.backward(st)
+        torch.cuda.synchronize()
+        assert r.check_capacity()
+        part = r.pose_ws[:r.pose_blocks * n_cams * 48].view(torch.float32).view(r.pose_blocks, n_cams, 12)
+        sums.append(part.double().sum(dim=0))
+    a, b = sums
+    assert float(a.abs().max()) > 0
+    assert float((a - b).abs().max()) < 2e-4 * float(a.abs().max()), (a, b)

@@ -1,0 +1,66 @@
+"""Workload for rocprofv3: the tracking closure (and optionally BA iterations) of the headline configuration, nothing else.
+
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_X -o X -- python3 tools/prof_closure.py [--frames 5]
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d ... -- python3 tools/prof_closure.py --eager --frames 1
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gaussians", type=int, default=500_000)
+    ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--ba", type=int, default=0, help="BA iterations over an 8-keyframe window after the tracking")
+    ap.add_argument("--eager", action="store_true", help="issue the launches eagerly (counter passes cannot attribute graph nodes)")
+    ap.add_argument("--front", type=int, default=-1, help="1 / 0 force the fused front on / off")
+    args = ap.parse_args()
+    import bench
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.mapping import BundleAdjuster, MapConfig
+    from gslam_amd.plan import current_stream_ptr
+    from gslam_amd.synthetic import make_scene
+    from gslam_amd.tracking import GraphedTracker, TrackingConfig
+    dev = torch.device("cuda:0")
+    N, W, H = args.gaussians, 640, 480
+    gt_scene = GaussianSplattingData.from_dict(make_scene(N, 1), dev)
+    m = GaussianSplattingData.from_dict(make_scene(N, 0), dev)
+    frames, cam = bench.make_frames(range(8 + args.frames), W, H, dev, gt_scene)
+    del gt_scene
+    fm = m.no_grad_clone()
+    conf = TrackingConfig()
+    tr = GraphedTracker(fm, cam, conf)
+    if args.front >= 0:
+        tr.plan.r.front = bool(args.front)
+    tr.track(frames[8])
+    torch.cuda.synchronize()
+    for i in range(args.frames):
+        f = frames[8 + i]
+        if args.eager:
+            tr.load(f)
+            tr.plan.init_optimizer(conf.n_adam_warmup, conf.pose_optim_lr, conf.lbfgs_history, 25)
+            st = current_stream_ptr(dev)
+            for _ in range(36):
+                tr.plan.enqueue(st)
+        else:
+            tr.track(f, sync=False)
+    torch.cuda.synchronize()
+    assert tr.capacity_ok()
+    if args.ba:
+        ba = BundleAdjuster(m, MapConfig(), capturable=True)
+        plan = ba.plan(frames[:8])
+        plan.prepare()
+        for _ in range(args.ba):
+            plan.step(graphed=not args.eager)
+        torch.cuda.synchronize()
+        assert plan.capacity_ok()
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
