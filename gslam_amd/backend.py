@@ -64,6 +64,7 @@ class MapConfig(_CoreConfig):
     kf_m: float = 0.15
     kf_cos: float = math.cos(math.pi / 30)
     use_gt_depths: bool = False
+    seed: int = 0                       # multi-rank only: common seed of the replicas' random draws
     densify_every: int = 200            # backend.py:329 (`total_step % 200`)
     sync_every: int = 5                 # backend.py:864 (`frame.index % 5`)
 
@@ -87,6 +88,12 @@ class Backend:
         self.total_step = 0
         self.pause_map_optim = False
         self.ba: Optional[BundleAdjuster] = None
+        # keyframe-sharded mapping (one Backend replica per rank): every replica makes the same random draws
+        # (window sampling, depth-map insertion, densification splits), so their maps stay identical between collectives
+        import torch.distributed as td
+        if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+            random.seed(int(getattr(conf, "seed", 0)))
+            torch.manual_seed(int(getattr(conf, "seed", 0)))
         self.last_outputs: Optional[RasterizationOutput] = None
         self.last_kf_depthmap = self.last_kf_rgbs = None
 
@@ -167,10 +174,20 @@ class Backend:
             if decay:
                 plan.decay_opacities()
         outputs = self._window_outputs(plan, window)
-        if outputs is not None:
-            mine = plan.mine if (plan is not None and plan.matches(self.splats, window)) else range(len(window))
-            for i, d in zip(mine, outputs.depthmaps):
-                window[i].est_depths = d.detach().clone()
+        sharded = self.ba.shard.world_size > 1 and plan is not None and plan.matches(self.splats, window)
+        if not sharded:
+            if outputs is not None:
+                for f, d in zip(window, outputs.depthmaps):
+                    f.est_depths = d.detach().clone()
+        else:
+            # every replica needs every keyframe's depth map (insertion.py:245-277 tests new splats against them): the rank
+            # that rendered a camera broadcasts its row (1.2 MB each at 640x480, once per optimize_map call)
+            import torch.distributed as td
+            local = {i: d for i, d in zip(plan.mine, outputs.depthmaps)} if outputs is not None else {}
+            for i, f in enumerate(window):
+                buf = local[i].detach().clone() if i in local else torch.empty(plan.H, plan.W, device=self.splats.means.device)
+                td.broadcast(buf, src=i % self.ba.shard.world_size, group=self.ba.shard.group)
+                f.est_depths = buf
         if prune:
             self._prune(outputs, len(window) >= 2)
         self._render_last_keyframe()

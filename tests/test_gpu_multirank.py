@@ -1,0 +1,121 @@
+"""Keyframe-sharded bundle adjustment on two ranks: a real BA iteration - render, loss, backward,
+all-reduce of the step bucket, Adam - run by two processes that share the one GPU of the test box (gloo between them; the
+driver's multi-GPU runs use one rank per GPU over RCCL), against the same iteration on one rank.  Run with -m gpu."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(dev, n_kf, n=8000, W=320, H=240):
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.primitives import Camera, Frame, PoseZhou
+    from gslam_amd.synthetic import make_cameras, make_scene
+    sc = make_scene(n, 21)
+    sc["scales"] = sc["scales"] + 0.5
+    splats = GaussianSplattingData.from_dict(sc, dev)
+    viewmats, Ks = make_cameras(n_kf, W, H)
+    gt = torch.rand(n_kf, H, W, 3, generator=torch.Generator().manual_seed(17)).to(dev)
+    window = [Frame(img=gt[i].contiguous(), timestamp=0.0, camera=Camera(Ks[i].to(dev), H, W),
+                    pose=PoseZhou(viewmats[i].to(dev), is_learnable=(i != 0)).to(dev), gt_pose=viewmats[i].to(dev), index=i,
+                    exposure_params=torch.tensor([0.02 * i, -0.01 * i], device=dev)) for i in range(n_kf)]
+    return splats, window
+
+
+def _worker(rank, world, port, n_kf, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from gslam_amd import dist as gdist
+    from gslam_amd.mapping import BundleAdjuster
+    from gslam_amd.plan import MappingStep
+    assert gdist.init_from_env(backend="gloo") == (rank, world)
+    # ---- one rank (no shard): the reference of this very process ---------------------------------------------------------
+    s1, w1 = _build(dev, n_kf)
+    ba1 = BundleAdjuster(s1, capturable=True)
+    ref = MappingStep(s1, ba1.optimizers, w1, ba1.conf, shard=None)
+    assert ref.world == 1
+    ref.render_backward()
+    torch.cuda.synchronize()
+    ref_flat = ref.flat.clone()
+    ref_vis = ref.r.vis_count.clone()
+    ref.step(graphed=False)                                  # same start: render_backward moved nothing
+    ref.step(graphed=False)
+    torch.cuda.synchronize()
+    # ---- two ranks ---------------------------------------------------------------------------------------------------------
+    s2, w2 = _build(dev, n_kf)
+    ba2 = BundleAdjuster(s2, capturable=True)
+    assert ba2.shard.world_size == world
+    plan = ba2.plan(w2)
+    assert plan.world == world and plan.mine == [i for i in range(n_kf) if i % world == rank]
+    plan.render_backward()                                   # includes the collective
+    torch.cuda.synchronize()
+    ok = plan.capacity_ok()
+    flat = plan.flat.clone()
+    n15 = s2.means.shape[0] * 15
+    scale = float(ref_flat[:n15].abs().max())
+    d_map = float((flat[:n15] - ref_flat[:n15]).abs().max()) / scale
+    # in the sharded step the isotropic term is added after the reduction; the one-rank bucket holds it already: compare
+    # the scale gradients after adding it here
+    d_cnt = int((plan.vis_i32 - ref_vis).abs().max())
+    tail = slice(n15 + s2.means.shape[0], None)
+    d_pose = float((flat[tail][:-2] - ref_flat[tail][:-2]).abs().max()) / (float(ref_flat[tail][:-2].abs().max()) + 1e-9)
+    d_photo = abs(float(flat[-1]) - float(ref_flat[-1])) / abs(float(ref_flat[-1]))
+    # two full iterations (graph | all-reduce | graph), then the parameters against the one-rank run
+    plan.step()
+    plan.step()
+    torch.cuda.synchronize()
+    ok = ok and plan.capacity_ok() and plan.graph.captured and plan.graph2.captured
+    d_par = {k: float((getattr(s1, k) - getattr(s2, k)).abs().mean()) for k in
+             ("means", "quats", "scales", "opacities", "colors", "log_uncertainties")}
+    d_posepar = max(float((a.pose.dR - b.pose.dR).abs().max()) for a, b in zip(w1, w2))
+    n_learn = sum(plan.learnable)
+    moved = max([float(f.pose.dR.abs().max()) for f in w2[1:]], default=1.0)
+    # every replica holds the same poses: compare rank 0's and rank 1's after the steps
+    mine = torch.cat([torch.cat([f.pose.dR, f.pose.dt]) for f in w2]).detach().cpu()
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    td.all_gather(both, mine)
+    same_poses = bool(torch.equal(both[0], both[1]))
+    means = s2.means.detach().cpu()
+    mboth = [torch.zeros_like(means) for _ in range(world)]
+    td.all_gather(mboth, means)
+    same_map = bool(torch.equal(mboth[0], mboth[1]))
+    q.put((rank, ok, d_map, d_cnt, d_pose, d_photo, d_par, d_posepar, moved, same_poses, same_map))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_kf", [2, 5, 1])
+def test_two_rank_ba_step_equals_one_rank(n_kf):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_kf, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, d_map, d_cnt, d_pose, d_photo, d_par, d_posepar, moved, same_poses, same_map in res:
+        assert ok, rank
+        # the scale columns differ by the isotropic term (added after the reduction when sharded): bounded by its weight
+        assert d_map < 5e-3, (rank, d_map)
+        assert d_cnt == 0 and d_pose < 2e-3 and d_photo < 1e-5, (rank, d_cnt, d_pose, d_photo)
+        for k, v in d_par.items():
+            assert v < 2e-5, (rank, k, v)
+        assert d_posepar < 2e-3 and moved > 0, (rank, d_posepar, moved)
+        assert same_poses and same_map                        # replicas stay bit-identical: no pose broadcast needed

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--ba", type=int, default=0, help="BA iterations over an 8-keyframe window after the tracking")
     ap.add_argument("--eager", action="store_true", help="issue the launches eagerly (counter passes cannot attribute graph nodes)")
     ap.add_argument("--front", type=int, default=-1, help="1 / 0 force the fused front on / off")
+    ap.add_argument("--ba-front", type=int, default=-1, help="1 / 0 force the fused front of the BA plan on / off")
     args = ap.parse_args()
     import bench
     from gslam_amd.map import GaussianSplattingData
@@ -30,7 +31,7 @@ def main():
     N, W, H = args.gaussians, 640, 480
     gt_scene = GaussianSplattingData.from_dict(make_scene(N, 1), dev)
     m = GaussianSplattingData.from_dict(make_scene(N, 0), dev)
-    frames, cam = bench.make_frames(range(8 + args.frames), W, H, dev, gt_scene)
+    frames, cam = bench.make_frames(range(8 + max(args.frames, 1)), W, H, dev, gt_scene)
     del gt_scene
     fm = m.no_grad_clone()
     conf = TrackingConfig()
@@ -53,6 +54,14 @@ def main():
     assert tr.capacity_ok()
     if args.ba:
         ba = BundleAdjuster(m, MapConfig(), capturable=True)
+        if args.ba_front >= 0:
+            import gslam_amd.plan as P
+            orig = P.RenderPlan.__init__
+
+            def patched(self, *a, **k):
+                k["front"] = bool(args.ba_front)
+                orig(self, *a, **k)
+            P.RenderPlan.__init__ = patched
         plan = ba.plan(frames[:8])
         plan.prepare()
         for _ in range(args.ba):
