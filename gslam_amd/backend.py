@@ -17,7 +17,6 @@ import math
 import random
 import time
 from collections import defaultdict
-import os
 from copy import deepcopy
 from dataclasses import dataclass
 from itertools import combinations
@@ -65,6 +64,7 @@ class MapConfig(_CoreConfig):
     kf_cos: float = math.cos(math.pi / 30)
     use_gt_depths: bool = False
     seed: int = 0                       # multi-rank only: common seed of the replicas' random draws
+    device_pose_refiner: bool = True    # window pose L-BFGS on the device (False: torch.optim.LBFGS on the host)
     densify_every: int = 200            # backend.py:329 (`total_step % 200`)
     sync_every: int = 5                 # backend.py:864 (`frame.index % 5`)
 
@@ -266,7 +266,7 @@ class Backend:
         window = self.optimization_window()
         learn = [x for x in window if x.index != 0]
         if (not self.splats.means.is_cuda or not learn or 9 * len(learn) > 80
-                or os.environ.get("GSX_POSE_REFINER", "device") == "host"):
+                or not getattr(self.conf, "device_pose_refiner", True)):
             return optimize_poses_lbfgs(self.splats, window, self.conf)
         # one refiner (buffers + captured closure) per window SHAPE over the current map tensors: the window's poses,
         # images and exposure are copied into its slots, so sliding the window does not re-capture; a re-packed map does

@@ -17,8 +17,8 @@
 //   3. place         : LDS cursors start at offsets[tile] + base[workgroup][tile]; 8-byte entries
 //                      (depth_bits<<32 | flatten_id) go straight to their tile's range.  No global atomic anywhere
 //                      (the first version reserved ranges with one contended atomic per ~3 entries and needed a
-//                      difference-grid pass for the totals; kept behind GSX_BIN_ATOMIC=1 for A/B runs).  What bounds
-//                      this step now is the 8-byte granularity of the scattered stores.
+//                      difference-grid pass for the totals).  What bounds this step now is the 8-byte granularity of
+//                      the scattered stores.
 //   4. tile_sort     : one workgroup per tile.  Tiles of up to 2048 keys: counting sort on a monotone depth -> bucket
 //                      map plus an exact in-bucket rank (two LDS atomics per key, no search).  Larger tiles (and
 //                      degenerate depth distributions): merge sort by ranks in an LDS window of up to 8192 keys,
@@ -30,7 +30,7 @@
 namespace {
 
 constexpr int BIN_THREADS = 256;
-constexpr int BIN_ITEMS = 4;          // Gaussians per thread in tile_diff / emit_binned
+constexpr int BIN_ITEMS = 4;          // Gaussians per thread of the coarse pre-sort passes
 constexpr int SORT_THREADS = 512;
 constexpr int COOP_AREA = 16;         // rectangles with more tiles than this are walked by the whole wavefront
 
@@ -64,95 +64,6 @@ __device__ __forceinline__ Rect load_rect(const float *__restrict__ means2d, con
         if (rad > 0) r = tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rad, tile_w, tile_h);
     }
     return r;
-}
-
-// ---- 1. 2-D difference grid ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BIN_THREADS) void tile_diff_kernel(const float *__restrict__ means2d,
-                                                                const int32_t *__restrict__ radii, int64_t N,
-                                                                int tile_w, int tile_h, int *__restrict__ diff) {
-    extern __shared__ int s_diff[];
-    const int c = blockIdx.y;
-    const int gw = tile_w + 1;
-    const int G = gw * (tile_h + 1);
-    for (int i = threadIdx.x; i < G; i += BIN_THREADS) s_diff[i] = 0;
-    __syncthreads();
-    for (int it = 0; it < BIN_ITEMS; ++it) {
-        const int64_t g = ((int64_t)blockIdx.x * BIN_ITEMS + it) * BIN_THREADS + threadIdx.x;
-        const Rect r = load_rect(means2d, radii, (int64_t)c * N + g, tile_w, tile_h, g < N);
-        if (r.x1 > r.x0 && r.y1 > r.y0) {
-            atomicAdd(&s_diff[r.y0 * gw + r.x0], 1);
-            atomicAdd(&s_diff[r.y0 * gw + r.x1], -1);
-            atomicAdd(&s_diff[r.y1 * gw + r.x0], -1);
-            atomicAdd(&s_diff[r.y1 * gw + r.x1], 1);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < G; i += BIN_THREADS) {
-        const int v = s_diff[i];
-        if (v != 0) atomicAdd(&diff[(int64_t)c * G + i], v);
-    }
-}
-
-// ---- 2. counts -> offsets ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void tile_offsets_kernel(const int *__restrict__ diff, int C, int tile_w, int tile_h,
-                                                            int64_t M_cap, int32_t *__restrict__ offsets /*[T+1]*/,
-                                                            int32_t *__restrict__ cursor /*[T]*/,
-                                                            int64_t *__restrict__ M_dev, int32_t *__restrict__ status) {
-    extern __shared__ int s_g[];           // (tile_h+1)*(tile_w+1) grid, then reused as the 1024-entry scan buffer
-    __shared__ long long s_scan[1024];
-    const int t = threadIdx.x;
-    const int gw = tile_w + 1, gh = tile_h + 1;
-    const int G = gw * gh;
-    const int n_tiles = tile_w * tile_h;
-    const int T = C * n_tiles;
-    for (int c = 0; c < C; ++c) {
-        for (int i = t; i < G; i += 1024) s_g[i] = diff[(int64_t)c * G + i];
-        __syncthreads();
-        if (t < gh) {  // prefix along x
-            int run = 0;
-            for (int x = 0; x < gw; ++x) { run += s_g[t * gw + x]; s_g[t * gw + x] = run; }
-        }
-        __syncthreads();
-        if (t < gw) {  // prefix along y
-            int run = 0;
-            for (int y = 0; y < gh; ++y) { run += s_g[y * gw + t]; s_g[y * gw + t] = run; }
-        }
-        __syncthreads();
-        for (int i = t; i < n_tiles; i += 1024) {
-            const int y = i / tile_w, x = i - y * tile_w;
-            const int cnt = s_g[y * gw + x];
-            if (cnt < 0) atomicOr(status, 2);                     // corrupt difference grid (never from a sane input)
-            offsets[(int64_t)c * n_tiles + i] = max(cnt, 0);      // per-tile count, scanned in place below
-        }
-        __syncthreads();
-    }
-    // exclusive scan of the T counts: contiguous chunk per thread + block scan of the chunk sums
-    const int per = (T + 1023) / 1024;
-    const int lo = min(T, t * per), hi = min(T, lo + per);
-    long long sum = 0;
-    for (int i = lo; i < hi; ++i) sum += offsets[i];
-    s_scan[t] = sum;
-    for (int off = 1; off < 1024; off <<= 1) {
-        __syncthreads();
-        const long long add = (t >= off) ? s_scan[t - off] : 0;
-        __syncthreads();
-        s_scan[t] += add;
-    }
-    __syncthreads();
-    long long run = s_scan[t] - sum;  // exclusive base of this thread's chunk
-    const long long total = s_scan[1023];
-    for (int i = lo; i < hi; ++i) {
-        const int cnt = offsets[i];
-        const int32_t o = (int32_t)min(run, (long long)0x7fffffff);
-        offsets[i] = o;
-        cursor[i] = o;
-        run += cnt;
-    }
-    if (t == 0) {
-        offsets[T] = (int32_t)min(total, (long long)0x7fffffff);
-        M_dev[0] = total;
-        if (total > M_cap || total > 0x7fffffffLL) atomicOr(status, 1);
-    }
 }
 
 // ---- 3. binning ---------------------------------------------------------------------------------------------------
@@ -215,7 +126,7 @@ __device__ __forceinline__ void place_rects(const Rect &r, int tile_w, unsigned 
 }
 
 // ---- 3b. binning without global atomics --------------------------------------------------------------------------
-// emit_binned_kernel reserves a range per (workgroup, touched tile) with a global atomic; a workgroup of 1024 random
+// The first version reserved a range per (workgroup, touched tile) with a global atomic; a workgroup of 1024 random
 // Gaussians touches most tiles with ~3 entries each, so that is one contended atomic per ~3 entries (3.5 M atomics on
 // 9600 addresses at 500 k x 8 cameras: 188 us, the largest kernel of the sort).  Here the per-(workgroup, tile) counts
 // go to a matrix instead, a column scan turns them into each workgroup's base inside every tile and into the per-tile
@@ -288,11 +199,6 @@ __global__ __launch_bounds__(64 * CS_GROUPS) void column_scan_kernel(int32_t *__
 // `order` (nullable, [T]): the tiles grouped by descending list length (256 buckets relative to the longest list):
 // the launch order of the rasteriser's workgroups.  Heaviest first spreads the long lists over the CUs instead of
 // leaving them where the image puts them (-5..7 % rasteriser time at 100 k Gaussians, tools/ab_raster.py).
-__global__ void iota_kernel(int32_t *__restrict__ p, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = i;
-}
-
 __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, int64_t M_cap, int32_t *__restrict__ offsets,
                                                          int64_t *__restrict__ M_dev, int32_t *__restrict__ status,
                                                          int32_t *__restrict__ order) {
@@ -541,44 +447,6 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_place_kernel(const PreRec *
     }
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void emit_binned_kernel(const float *__restrict__ means2d,
-                                                                  const int32_t *__restrict__ radii,
-                                                                  const float *__restrict__ depths, int64_t N,
-                                                                  int tile_w, int tile_h, int64_t M_cap,
-                                                                  int32_t *__restrict__ cursor,
-                                                                  unsigned long long *__restrict__ entries) {
-    extern __shared__ int s_cnt[];  // [n_tiles]
-    const int c = blockIdx.y;
-    const int n_tiles = tile_w * tile_h;
-    for (int i = threadIdx.x; i < n_tiles; i += BIN_THREADS) s_cnt[i] = 0;
-    __syncthreads();
-    Rect rects[BIN_ITEMS];
-#pragma unroll
-    for (int it = 0; it < BIN_ITEMS; ++it) {
-        const int64_t g = ((int64_t)blockIdx.x * BIN_ITEMS + it) * BIN_THREADS + threadIdx.x;
-        rects[it] = load_rect(means2d, radii, (int64_t)c * N + g, tile_w, tile_h, g < N);
-        walk_rects(rects[it], tile_w, 0u, 0u, [&](int tile, unsigned int, unsigned int) { atomicAdd(&s_cnt[tile], 1); });
-    }
-    __syncthreads();
-    // reserve one contiguous range per touched tile; s_cnt becomes the workgroup's absolute write cursor
-    for (int i = threadIdx.x; i < n_tiles; i += BIN_THREADS) {
-        const int n = s_cnt[i];
-        s_cnt[i] = (n > 0) ? atomicAdd(&cursor[(int64_t)c * n_tiles + i], n) : 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < BIN_ITEMS; ++it) {
-        const int64_t g = ((int64_t)blockIdx.x * BIN_ITEMS + it) * BIN_THREADS + threadIdx.x;
-        const int64_t idx = (int64_t)c * N + g;
-        const bool has = (rects[it].x1 > rects[it].x0) && (rects[it].y1 > rects[it].y0);
-        const unsigned int klo = (unsigned int)idx, khi = has ? __float_as_uint(depths[idx]) : 0u;
-        walk_rects(rects[it], tile_w, klo, khi, [&](int tile, unsigned int lo, unsigned int hi) {
-            const int pos = atomicAdd(&s_cnt[tile], 1);
-            if ((uint64_t)(uint32_t)pos < (uint64_t)M_cap) entries[pos] = ((unsigned long long)hi << 32) | lo;
-        });
-    }
-}
-
 // ---- 4. per-tile sort -----------------------------------------------------------------------------------------------
 // One workgroup per tile.  Up to `cap` keys (LDS window chosen by the host from the capacity) are merge-sorted by
 // RANKS, ping-ponging between two LDS buffers:
@@ -642,47 +510,6 @@ __device__ __forceinline__ unsigned long long *lds_sort(const unsigned long long
         unsigned long long *t = src; src = dst; dst = t;
     }
     return src;
-}
-
-__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(unsigned long long *__restrict__ entries,
-                                                                 unsigned long long *__restrict__ scratch,
-                                                                 const int32_t *__restrict__ offsets, int n_tiles,
-                                                                 int tile_n_bits, int64_t M_cap, int cap,
-                                                                 int n_lo, int n_hi, uint32_t id_max,
-                                                                 int64_t *__restrict__ isect_ids,
-                                                                 int32_t *__restrict__ flatten_ids) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
-    const int tile = blockIdx.x;
-    const int64_t start = max((int64_t)0, min((int64_t)offsets[tile], M_cap));
-    const int64_t end = max((int64_t)0, min((int64_t)offsets[tile + 1], M_cap));
-    const int n = (int)(end - start);
-    if (n <= n_lo || n > n_hi) return;                       // not this launch's size class (n_lo >= 0: empty tiles)
-    const int c = tile / n_tiles, tl = tile - c * n_tiles;
-    const long long hi_part = ((long long)c << (32 + tile_n_bits)) | ((long long)tl << 32);
-    unsigned long long *seg = entries + start;
-    const unsigned long long *sorted;
-    if (n <= cap) {
-        sorted = lds_sort(seg, n, s_mem, s_mem + cap);
-    } else {
-        for (int cb = 0; cb < n; cb += cap) {              // window-sized chunks: sort in LDS, write back in place
-            const int len = min(cap, n - cb);
-            const unsigned long long *res = lds_sort(seg + cb, len, s_mem, s_mem + cap);
-            for (int i = threadIdx.x; i < len; i += SORT_THREADS) seg[cb + i] = res[i];
-        }
-        __syncthreads();
-        unsigned long long *src = seg, *dst = scratch + start;
-        for (int run = cap; run < n; run <<= 1) {          // remaining merge levels through global memory (L2)
-            merge_level(src, dst, n, run);
-            __syncthreads();
-            unsigned long long *t = src; src = dst; dst = t;
-        }
-        sorted = src;
-    }
-    for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
-        const unsigned long long k = sorted[i];
-        flatten_ids[start + i] = (int32_t)min((uint32_t)k, id_max);   // never hand an out-of-range gather index on
-        if (isect_ids) isect_ids[start + i] = hi_part | (long long)(k >> 32);
-    }
 }
 
 // ---- 4b. per-tile sort by counting ------------------------------------------------------------------------------------
@@ -989,44 +816,22 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
     int32_t *cursor = (int32_t *)(ws + L.cursor_off);
     unsigned long long *entries = (unsigned long long *)(ws + L.entries_off);
     unsigned long long *scratch = (unsigned long long *)(ws + L.scratch_off);
-    const char *bm = getenv("GSX_BIN_ATOMIC");
-    if (bm && bm[0] == '1') {                       // A/B: the difference grid + global-atomic binning
-        if (!gsx_zero_async(diff, C * G, st)) return GSX_E_LAUNCH;
-        const unsigned gblocks = (unsigned)((N + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
-        if (N > 0) {
-            hipLaunchKernelGGL(tile_diff_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(G * 4), st,
-                               means2d, radii, N, tile_w, tile_h, diff);
-            GSX_CHECK_LAUNCH();
-        }
-        hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), (size_t)(G * 4), st, diff, (int)C, tile_w, tile_h,
-                           M_cap, offsets, cursor, M_dev, status);
-        GSX_CHECK_LAUNCH();
-        if (tile_order) {                               // this A/B path keeps the spatial launch order
-            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, tile_order, (int)T);
-            GSX_CHECK_LAUNCH();
-        }
-        if (N > 0 && M_cap > 0) {
-            hipLaunchKernelGGL(emit_binned_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4),
-                               st, means2d, radii, depths, N, tile_w, tile_h, M_cap, cursor, entries);
-            GSX_CHECK_LAUNCH();
-        }
-    } else {
+    {
         // count matrix -> column scan -> tile scan -> placement; the Gaussians of a workgroup grow with N so that the
         // matrix never has more than GB_MAX rows per camera
         int32_t *cnt = (int32_t *)(ws + L.matrix_off);
         int64_t items = BIN_ITEMS;
         while ((N + BIN_THREADS * items - 1) / (BIN_THREADS * items) > GB_MAX) items *= 2;
-        // large maps: spatial pre-sort of the visible instances first (see 3c); GSX_BIN_PRESORT=0/1 forces the choice
-        const char *ps = getenv("GSX_BIN_PRESORT");
+        // large maps: spatial pre-sort of the visible instances first (see 3c)
         const int sw = (tile_w + SUPER - 1) / SUPER, S = sw * ((tile_h + SUPER - 1) / SUPER);
         const int64_t rec_cap = C * N;
         const bool presort_ok = N > 0 && M_cap > 0 && workspace_bytes >= L.total + rec_cap * 16 && T <= 16000 &&
                                 C * G * 4 <= 65536 && C <= 255 && tile_w < 4096 && tile_h < 4096 &&
                                 S * (int64_t)sizeof(int) <= 65536;
-        // measured (MI355X, tools/dbg/ab_presort.sh, whole tile-list build): 100 k x 8 cameras 138 vs 145 us (direct vs
-        // pre-sorted), 250 k x 8: 209 vs 178, 1M x 1: 143 vs 121, 500 k x 8: 330 vs 262, 2M x 8: 1774 vs 1123, 5M at
-        // 1080p: count + placement 1.70 ms vs 0.6 - the pre-sort pays from about a million instances on
-        const bool presort = presort_ok && (ps ? ps[0] == '1' : C * N >= ((int64_t)1 << 20));
+        // measured (MI355X, whole tile-list build, direct vs pre-sorted): 100 k x 8 cameras 138 vs 145 us, 250 k x 8: 209 vs
+        // 178, 1M x 1: 143 vs 121, 500 k x 8: 330 vs 262, 2M x 8: 1774 vs 1123, 5M at 1080p: count + placement 1.70 ms vs
+        // 0.6 - the pre-sort pays from about a million instances on
+        const bool presort = presort_ok && C * N >= ((int64_t)1 << 20);
         if (presort) {
             const unsigned gblocks = (unsigned)((N + BIN_THREADS * items - 1) / (BIN_THREADS * items));
             int32_t *coff = cursor;                          // [C * S + 1] (S <= tiles per camera)
@@ -1063,64 +868,43 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
                 GSX_CHECK_LAUNCH();
             }
         } else {
-        // Gaussians per thread (tools/dbg/ab_items.sh, MI355X): the grid has to cover the chip (>= 512 workgroups over all
-        // cameras: 100 k Gaussians at one camera want ONE Gaussian per thread, 36 vs 50 us for the whole tile-list
-        // build), beyond that fatter workgroups write longer runs per tile, up to 8 per thread; the count matrix caps the
-        // workgroups per camera at GB_MAX
-        const char *bi = getenv("GSX_BIN_ITEMS");
-        auto blocks_of = [&](int64_t it) { return (N + BIN_THREADS * it - 1) / (BIN_THREADS * it); };
-        items = 1;
-        while (items < 8 && C * blocks_of(items * 2) >= 512) items *= 2;
-        if (bi && atoi(bi) > 0) items = atoi(bi);
-        while (blocks_of(items) > GB_MAX) items *= 2;
-        const unsigned gblocks = (unsigned)((N + BIN_THREADS * items - 1) / (BIN_THREADS * items));
-        if (N > 0) {
-            hipLaunchKernelGGL(count_matrix_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4),
-                               st, means2d, radii, N, tile_w, tile_h, (int)items, cnt);
+            // Gaussians per thread (measured, MI355X): the grid has to cover the chip (>= 512 workgroups over all
+            // cameras: 100 k Gaussians at one camera want ONE Gaussian per thread, 36 vs 50 us for the whole tile-list
+            // build), beyond that fatter workgroups write longer runs per tile, up to 8 per thread; the count matrix caps
+            // the workgroups per camera at GB_MAX
+            auto blocks_of = [&](int64_t it) { return (N + BIN_THREADS * it - 1) / (BIN_THREADS * it); };
+            items = 1;
+            while (items < 8 && C * blocks_of(items * 2) >= 512) items *= 2;
+            while (blocks_of(items) > GB_MAX) items *= 2;
+            const unsigned gblocks = (unsigned)((N + BIN_THREADS * items - 1) / (BIN_THREADS * items));
+            if (N > 0) {
+                hipLaunchKernelGGL(count_matrix_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS),
+                                   (size_t)(n_tiles * 4), st, means2d, radii, N, tile_w, tile_h, (int)items, cnt);
+                GSX_CHECK_LAUNCH();
+                hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((n_tiles + 63) / 64), (unsigned)C),
+                                   dim3(64 * CS_GROUPS), 0, st, cnt, (int)gblocks, (int)n_tiles, offsets);
+                GSX_CHECK_LAUNCH();
+            } else {
+                if (!gsx_zero_async(offsets, T, st)) return GSX_E_LAUNCH;
+            }
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, (int)T, M_cap, offsets, M_dev, status,
+                               tile_order);
             GSX_CHECK_LAUNCH();
-            hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((n_tiles + 63) / 64), (unsigned)C),
-                               dim3(64 * CS_GROUPS), 0, st, cnt, (int)gblocks, (int)n_tiles, offsets);
-            GSX_CHECK_LAUNCH();
-        } else {
-            if (!gsx_zero_async(offsets, T, st)) return GSX_E_LAUNCH;
-        }
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, (int)T, M_cap, offsets, M_dev, status, tile_order);
-        GSX_CHECK_LAUNCH();
-        if (N > 0 && M_cap > 0) {
-            hipLaunchKernelGGL(place_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4), st,
-                               means2d, radii, depths, N, tile_w, tile_h, (int)items, M_cap, offsets, cnt, entries);
-            GSX_CHECK_LAUNCH();
-        }
+            if (N > 0 && M_cap > 0) {
+                hipLaunchKernelGGL(place_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4),
+                                   st, means2d, radii, depths, N, tile_w, tile_h, (int)items, M_cap, offsets, cnt,
+                                   entries);
+                GSX_CHECK_LAUNCH();
+            }
         }
     }
     if (N > 0 && M_cap > 0) {
         // Tile sizes are only known on the device (sync-free): one launch over all tiles, each workgroup picks its
-        // regime from its tile's size.  GSX_TILE_SORT=merge (A/B): the merge sort in two size classes instead, tiles of
-        // up to 2048 keys in a 32 KiB LDS window, larger ones in an 8192-key window (128 KiB) + global merge levels.
-        const int small_cap = 2048, big_cap = 8192;
+        // regime from its tile's size (counting sort in LDS, streamed counting sort, merge sort for degenerate depths)
         const uint32_t id_max = (uint32_t)(C * N - 1);
         const int tnb = bit_length((uint32_t)n_tiles);
-        const char *ts = getenv("GSX_TILE_SORT");
-        if (ts && ts[0] == 'm') {
-            hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), (size_t)(2 * small_cap * 8), st,
-                               entries, scratch, offsets, (int)n_tiles, tnb, M_cap, small_cap, 0, small_cap, id_max,
-                               isect_ids, flatten_ids);
-            GSX_CHECK_LAUNCH();
-            if (M_cap > small_cap) {
-                const size_t lds_bytes = (size_t)(2 * big_cap * 8);
-                if (hipFuncSetAttribute((const void *)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_bytes) != hipSuccess) {
-                    gsx_set_error("gsx_isect_bin_sort: cannot raise the dynamic LDS limit to %zu bytes", lds_bytes);
-                    return GSX_E_LAUNCH;
-                }
-                hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)T), dim3(SORT_THREADS), lds_bytes, st, entries,
-                                   scratch, offsets, (int)n_tiles, tnb, M_cap, big_cap, small_cap, 0x7fffffff, id_max,
-                                   isect_ids, flatten_ids);
-            }
-        } else {
-            hipLaunchKernelGGL(tile_sort_count_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, scratch,
-                               offsets, (int)n_tiles, tnb, M_cap, id_max, isect_ids, flatten_ids);
-        }
+        hipLaunchKernelGGL(tile_sort_count_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, scratch,
+                           offsets, (int)n_tiles, tnb, M_cap, id_max, isect_ids, flatten_ids);
         GSX_CHECK_LAUNCH();
     }
     return GSX_OK;

@@ -2,24 +2,22 @@
 // Replaces the gsplat fork's `rasterize_to_pixels` (gslam/rasterization.py:325-339; 3-tuple return with n_touched).
 // Maths: SURVEY.md §9.3 / §9.4.
 //
-// wave64-native mapping (v2).  A workgroup is still one 16x16 tile, but each of its four wavefronts owns an
-// 8x8-pixel quadrant and walks the tile's depth-sorted list in chunks of 64 entries with the LANES MAPPED TO
-// ENTRIES first:
+// wave64-native mapping.  A workgroup is one 16x16 tile; each of its wavefronts owns an 8x8-pixel quadrant (or a 16x8
+// half tile with two pixels per lane when the chip is full) and walks the tile's depth-sorted list in chunks of 64 entries
+// with the LANES MAPPED TO ENTRIES first:
 //   1. lane i loads entry i of the chunk (coalesced id load + one 48-byte record gather),
 //   2. lane i decides - exactly and conservatively - whether its Gaussian can reach alpha >= 1/255 anywhere in
-//      the wavefront's 8x8 quadrant (minimum of the conic quadratic over the quadrant rectangle),
-//   3. a 64-bit ballot compacts the survivors; the wavefront then visits only the set bits, broadcasting the
-//      surviving record from its lane's VGPRs to SGPRs with v_readlane (no LDS, no barrier, no wait),
-//   4. now LANES = PIXELS: the usual compositing step with scalar (SGPR) Gaussian operands.
-// Entries that cannot touch the quadrant cost ~1 instruction per 64 instead of a full loop trip, termination is
-// voted per wavefront, and the forward needs no LDS or barriers at all.  The backward keeps one LDS accumulator
-// row per staged entry so that the four quadrants merge before a single record-shaped (48 B contiguous) atomic
-// flush per (tile, Gaussian); per-Gaussian sums over the 64 lanes use DPP row/bcast adds.
+//      the wavefront's pixel block (minimum of the conic quadratic over the block's rectangle),
+//   3. a 64-bit ballot compacts the survivors into a per-wavefront LDS list (raster_v4.inc),
+//   4. now LANES = PIXELS: a counted loop over the list with broadcast LDS reads and branch-free compositing.
+// The kernels that ship: raster_fwd_kernel4q (forward), raster_bwd_kernel4q (backward, one camera / geometry-only),
+// raster_bwd_kernel4 (backward, full chip), raster_bwd_kernel2 (absgrad side channel only).  The earlier generations
+// (block-per-tile LDS staging, v_readlane broadcast loop, LDS-atomic accumulation modes) are gone from the product; the
+// parity tests check these kernels against the CPU oracle.
 #include <stdlib.h>
 
 #include "gsx_common.h"
 
-#include "raster_v1.inc"
 
 namespace {
 
@@ -140,212 +138,6 @@ __device__ __forceinline__ Quad make_quad(int tile_w, int tile_h, int W, int H, 
     return q;
 }
 
-template <int CH, int RS>
-__global__ __launch_bounds__(256) void raster_fwd_kernel(const float *__restrict__ rec, const float *__restrict__ bg,
-                                                         const int32_t *__restrict__ offsets,
-                                                         const int32_t *__restrict__ flatten_ids, int64_t M,
-                                                         int has_end, int W, int H, int tile_w, int tile_h,
-                                                         float vis_min_T, float *__restrict__ render,
-                                                         float *__restrict__ alphas, int32_t *__restrict__ last_ids,
-                                                         int32_t *__restrict__ n_touched) {
-    const Quad q = make_quad(tile_w, tile_h, W, H);
-    const int n_tiles_total = gridDim.x;
-    // has_end: offsets holds T+1 entries and M is the CAPACITY of flatten_ids (sync-free path); otherwise M is exact
-    const int start = max(0, min(offsets[q.tile], (int)M));
-    const int end = (has_end || q.tile + 1 < n_tiles_total) ? max(0, min(offsets[q.tile + 1], (int)M)) : (int)M;
-
-    // The CU has ONE scalar unit for its four SIMDs, so the per-entry loop keeps its state in vector registers and
-    // arithmetic instead of lane masks and branches: a finished pixel simply carries a live transmittance of 0.
-    float Tl = q.inside ? 1.0f : 0.0f;   // live transmittance (0 once the pixel has terminated / is outside the image)
-    float T_out = 1.0f;                  // transmittance to report: frozen at termination
-    float pix[CH];
-#pragma unroll
-    for (int k = 0; k < CH; ++k) pix[k] = 0.f;
-    int last = -1;
-
-    for (int base = start; base < end; base += 64) {
-        if (__all(Tl == 0.0f)) break;  // once per 64 entries: every pixel of the quadrant is saturated
-        const int e = base + q.lane;
-        const bool have = e < end;
-        const int g = have ? flatten_ids[e] : 0;
-        const Rec<RS> r = load_record<RS>(rec, g);
-        const bool maybe = have && may_touch(r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5], q.x0, q.y0, q.x1, q.y1);
-        unsigned long long mask = __ballot(maybe);
-        int touched_cnt = 0;             // lane j counts the pixels that entry j "touched" (T' > visibility_min_T)
-        // LANES = PIXELS from here on; the Gaussian's record is broadcast into scalar registers with v_readlane
-        // (measured faster here than re-fetching it through the scalar cache: nothing to wait for)
-        while (mask != 0ull) {
-            const int j = __ffsll((long long)mask) - 1;
-            mask &= mask - 1ull;
-            const SRec<RS> cur = bcast_record<RS>(r.v, j);
-            const float dx = cur.a.x - q.fx, dy = cur.a.y - q.fy;
-            const float sigma = 0.5f * (cur.a.z * dx * dx + cur.b.x * dy * dy) + cur.a.w * dx * dy;
-            const float alpha = fminf(GSX_ALPHA_MAX, cur.b.y * __expf(-sigma));
-            const float a_eff = ((sigma >= 0.0f) && (alpha >= GSX_ALPHA_MIN)) ? alpha : 0.0f;
-            const float nT = Tl * (1.0f - a_eff);
-            const bool stop = nT <= GSX_T_MIN;                 // terminates now, or was already dead (Tl == 0)
-            const float vis = stop ? 0.0f : a_eff * Tl;
-#pragma unroll
-            for (int k = 0; k < CH; ++k) pix[k] += cur.color(k) * vis;
-            last = (vis > 0.0f) ? base + j : last;
-            const unsigned long long tm = __ballot((vis > 0.0f) && (nT > vis_min_T));
-            touched_cnt += (q.lane == j) ? __popcll(tm) : 0;
-            T_out = stop ? T_out : nT;
-            Tl = stop ? 0.0f : nT;
-        }
-        if (touched_cnt > 0) atomicAdd(&n_touched[g], touched_cnt);
-    }
-    if (q.inside) {
-        const int64_t p = ((int64_t)q.c * H + q.py) * W + q.px;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) render[p * CH + k] = pix[k] + (bg ? T_out * bg[q.c * CH + k] : 0.f);
-        alphas[p] = 1.0f - T_out;
-        last_ids[p] = last;
-    }
-}
-
-template <int CH, int RS, bool ABS, bool SCALAR = false>
-__global__ __launch_bounds__(256) void raster_bwd_kernel(
-    const float *__restrict__ rec, const float *__restrict__ bg, const int32_t *__restrict__ offsets,
-    const int32_t *__restrict__ flatten_ids, int64_t M, int has_end, int W, int H, int tile_w, int tile_h,
-    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
-    const float *__restrict__ v_alphas, float *__restrict__ v_rec, float *__restrict__ v_abs) {
-    constexpr int NG = 6 + CH;  // gradient entries per record: xy(2) conic(3) opacity(1) colors(CH)
-    __shared__ __attribute__((aligned(16))) float s_grad[256 * RS];
-    __shared__ float s_abs[ABS ? 512 : 2];
-    __shared__ int s_id[256];
-    __shared__ int s_wmax[4];
-
-    const Quad q = make_quad(tile_w, tile_h, W, H);
-    const int t = threadIdx.x;
-    const int64_t p = ((int64_t)q.c * H + min(q.py, H - 1)) * W + min(q.px, W - 1);
-    const int start = max(0, min(offsets[q.tile], (int)M));
-    const int last = q.inside ? last_ids[p] : -1;
-    int wmax = last;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
-    if (q.lane == 0) s_wmax[q.wave] = wmax;
-    __syncthreads();
-    const int bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-    if (bmax < start) return;  // nothing composited in this tile (uniform over the workgroup)
-
-    const float T_final = q.inside ? 1.0f - alphas[p] : 1.0f;
-    float T = T_final;
-    float vo[CH], buf[CH];
-    float bg_dot = 0.f;
-#pragma unroll
-    for (int k = 0; k < CH; ++k) {
-        vo[k] = q.inside ? v_render[p * CH + k] : 0.f;
-        buf[k] = 0.f;
-        if (bg) bg_dot += bg[q.c * CH + k] * vo[k];
-    }
-    const float va_out = (q.inside && v_alphas) ? v_alphas[p] : 0.f;
-
-    const int n = bmax - start + 1;
-    const int n_batches = (n + 255) / 256;
-    for (int b = n_batches - 1; b >= 0; --b) {
-        const int batch_start = start + b * 256;
-        const int bsize = min(256, start + n - batch_start);
-        __syncthreads();  // the previous batch's flush has finished reading s_grad / s_id
-        if (t < bsize) s_id[t] = flatten_ids[batch_start + t];
-#pragma unroll
-        for (int k = 0; k < RS; ++k) s_grad[k * 256 + t] = 0.f;
-        if (ABS) { s_abs[t] = 0.f; s_abs[256 + t] = 0.f; }
-        __syncthreads();
-        for (int sub = 3; sub >= 0; --sub) {
-            const int cbase = batch_start + sub * 64;
-            if (cbase >= batch_start + bsize || cbase > wmax) continue;  // wave-uniform
-            const int e = cbase + q.lane;
-            const bool have = (e < batch_start + bsize) && (e <= wmax);
-            const int g = have ? s_id[sub * 64 + q.lane] : 0;
-            Rec<RS> r = load_record<RS>(rec, g);
-            const bool maybe = have && may_touch(r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5], q.x0, q.y0, q.x1, q.y1);
-            unsigned long long mask = __ballot(maybe);
-            SRec<RS> nxt;
-            int jn = 0;
-            if (SCALAR && mask != 0ull) {
-                jn = 63 - __clzll((long long)mask);  // back to front
-                nxt = sload_record<RS>(rec, __builtin_amdgcn_readlane(g, jn));
-            }
-            while (mask != 0ull) {
-                SRec<RS> cur;
-                int j;
-                if (SCALAR) {   // record re-fetched through the scalar cache, one entry ahead
-                    cur = nxt;
-                    j = jn;
-                    mask &= ~(1ull << j);
-                    if (mask != 0ull) {
-                        jn = 63 - __clzll((long long)mask);
-                        nxt = sload_record<RS>(rec, __builtin_amdgcn_readlane(g, jn));
-                    }
-                } else {        // record broadcast from lane j's registers
-                    j = 63 - __clzll((long long)mask);
-                    mask &= ~(1ull << j);
-                    cur = bcast_record<RS>(r.v, j);
-                }
-                const float a = cur.a.z, bq = cur.a.w, cq = cur.b.x, opac = cur.b.y;
-                const float dx = cur.a.x - q.fx, dy = cur.a.y - q.fy;
-                const float sigma = 0.5f * (a * dx * dx + cq * dy * dy) + bq * dx * dy;
-                const float vis = __expf(-sigma);
-                const float alpha = fminf(GSX_ALPHA_MAX, opac * vis);
-                // scalar-light body (one scalar unit per CU): an entry that does not composite on this pixel simply
-                // carries alpha 0, which makes ra = 1, fac = 0 and v_sigma = 0 without any lane-mask logic
-                const float a_eff = ((cbase + j <= last) && (sigma >= 0.0f) && (alpha >= GSX_ALPHA_MIN)) ? alpha : 0.0f;
-                if (!__any(a_eff > 0.0f)) continue;
-                const float ra = __builtin_amdgcn_rcpf(1.0f - a_eff);
-                T *= ra;
-                const float fac = a_eff * T;
-                float gr[NG];
-                float v_alpha = 0.f;
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    const float ck = cur.color(k);
-                    gr[6 + k] = fac * vo[k];
-                    v_alpha += (ck * T - buf[k] * ra) * vo[k];
-                    buf[k] += ck * fac;
-                }
-                v_alpha += T_final * ra * (va_out - bg_dot);
-                // gradient reaches sigma / opacity only where alpha was not clamped at 0.999
-                const float visw = ((a_eff > 0.0f) && (opac * vis <= GSX_ALPHA_MAX)) ? vis : 0.0f;
-                const float v_sigma = -opac * visw * v_alpha;
-                gr[2] = 0.5f * v_sigma * dx * dx;
-                gr[3] = v_sigma * dx * dy;
-                gr[4] = 0.5f * v_sigma * dy * dy;
-                gr[0] = v_sigma * (a * dx + bq * dy);
-                gr[1] = v_sigma * (bq * dx + cq * dy);
-                gr[5] = visw * v_alpha;
-                const float gax = ABS ? fabsf(gr[0]) : 0.f, gay = ABS ? fabsf(gr[1]) : 0.f;
-                // 16-lane row sums of all NG entries, interleaved (DPP), then the four row leaders add into the
-                // entry's LDS accumulator row: one exec-mask change, NG ds_add_f32 with 4 active lanes each
-                const int slot = sub * 64 + j;
-                gsx_row16_sum<NG>(gr);
-                float ab[2] = {gax, gay};
-                if (ABS) gsx_row16_sum<2>(ab);
-                if ((q.lane & 15) == 15) {
-                    gsx_lds_fadd_row<NG>((unsigned)(uintptr_t)&s_grad[slot * RS], gr);
-                    if (ABS) { gsx_lds_fadd(&s_abs[2 * slot], ab[0]); gsx_lds_fadd(&s_abs[2 * slot + 1], ab[1]); }
-                }
-            }
-        }
-        __syncthreads();
-        // record-shaped flush: consecutive lanes -> consecutive floats of one 48-byte record row
-        for (int i = t; i < bsize * RS; i += 256) {
-            const int j = i / RS, k = i - j * RS;
-            if (k < NG) {
-                const float v = s_grad[i];
-                if (v != 0.f) atomicAdd(&v_rec[(int64_t)s_id[j] * RS + k], v);
-            }
-        }
-        if (ABS) {
-            for (int i = t; i < bsize * 2; i += 256) {
-                const float v = s_abs[i];
-                if (v != 0.f) atomicAdd(&v_abs[(int64_t)s_id[i >> 1] * 2 + (i & 1)], v);
-            }
-        }
-    }
-}
-
-
 // =====================================================================================================================
 // v3: two pixels per lane.  A wavefront owns a 16x8 half tile: lane l composites the pixels (x, y) and (x, y + 4) with
 // x = l & 15, y = l >> 4.  Both pixels share dx, so half of the conic quadratic is computed once; the per-entry fixed
@@ -378,83 +170,6 @@ __device__ __forceinline__ Half make_half(int tile_w, int tile_h, int W, int H, 
     q.x0 = (float)bx + 0.5f; q.y0 = (float)by + 0.5f;
     q.x1 = (float)(bx + 15) + 0.5f; q.y1 = (float)(by + 7) + 0.5f;
     return q;
-}
-
-template <int CH, int RS>
-__global__ __launch_bounds__(128) void raster_fwd_kernel2(const float *__restrict__ rec, const float *__restrict__ bg,
-                                                          const int32_t *__restrict__ offsets,
-                                                          const int32_t *__restrict__ flatten_ids, int64_t M,
-                                                          int has_end, int W, int H, int tile_w, int tile_h,
-                                                          float vis_min_T, float *__restrict__ render,
-                                                          float *__restrict__ alphas, int32_t *__restrict__ last_ids,
-                                                          int32_t *__restrict__ n_touched) {
-    const Half q = make_half(tile_w, tile_h, W, H);
-    const int n_tiles_total = gridDim.x;
-    const int start = max(0, min(offsets[q.tile], (int)M));
-    const int end = (has_end || q.tile + 1 < n_tiles_total) ? max(0, min(offsets[q.tile + 1], (int)M)) : (int)M;
-
-    float T0 = 1.0f, T1 = 1.0f;
-    float pix0[CH], pix1[CH];
-#pragma unroll
-    for (int k = 0; k < CH; ++k) { pix0[k] = 0.f; pix1[k] = 0.f; }
-    int last0 = -1, last1 = -1;
-    bool done0 = !q.in0, done1 = !q.in1;
-
-    for (int base = start; base < end; base += 64) {
-        if (__all(done0 && done1)) break;
-        const int e = base + q.lane;
-        const bool have = e < end;
-        const int g = have ? flatten_ids[e] : 0;
-        Rec<RS> r = load_record<RS>(rec, have ? g : 0);
-        const bool maybe = have && may_touch(r.v[0], r.v[1], r.v[2], r.v[3], r.v[4], r.v[5], q.x0, q.y0, q.x1, q.y1);
-        unsigned long long mask = __ballot(maybe);
-        while (mask != 0ull) {
-            const int j = __ffsll((long long)mask) - 1;
-            mask &= mask - 1ull;
-            const SRec<RS> cur = bcast_record<RS>(r.v, j);
-            const float dx = cur.a.x - q.fx, dy0 = cur.a.y - q.fy0, dy1 = dy0 - 4.0f;
-            const float h = 0.5f * cur.a.z * dx * dx, bdx = cur.a.w * dx, hc = 0.5f * cur.b.x;
-            const float sig0 = h + dy0 * (hc * dy0 + bdx), sig1 = h + dy1 * (hc * dy1 + bdx);
-            const float al0 = fminf(GSX_ALPHA_MAX, cur.b.y * __expf(-sig0));
-            const float al1 = fminf(GSX_ALPHA_MAX, cur.b.y * __expf(-sig1));
-            bool v0 = !done0 && (sig0 >= 0.0f) && (al0 >= GSX_ALPHA_MIN);
-            bool v1 = !done1 && (sig1 >= 0.0f) && (al1 >= GSX_ALPHA_MIN);
-            const float nT0 = T0 * (1.0f - al0), nT1 = T1 * (1.0f - al1);
-            if (v0 && nT0 <= GSX_T_MIN) { done0 = true; v0 = false; }
-            if (v1 && nT1 <= GSX_T_MIN) { done1 = true; v1 = false; }
-            if (!__any(v0 || v1)) {
-                if (__all(done0 && done1)) break;
-                continue;
-            }
-            const float vis0 = v0 ? al0 * T0 : 0.0f, vis1 = v1 ? al1 * T1 : 0.0f;
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const float ck = cur.color(k);
-                pix0[k] += ck * vis0;
-                pix1[k] += ck * vis1;
-            }
-            const bool t0 = v0 && (nT0 > vis_min_T), t1 = v1 && (nT1 > vis_min_T);
-            if (v0) { last0 = base + j; T0 = nT0; }
-            if (v1) { last1 = base + j; T1 = nT1; }
-            const unsigned long long tm0 = __ballot(t0), tm1 = __ballot(t1);
-            if ((tm0 | tm1) != 0ull && q.lane == 0)
-                atomicAdd(&n_touched[__builtin_amdgcn_readlane(g, j)], __popcll(tm0) + __popcll(tm1));
-        }
-    }
-    if (q.in0) {
-        const int64_t p = ((int64_t)q.c * H + q.py0) * W + q.px;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) render[p * CH + k] = pix0[k] + (bg ? T0 * bg[q.c * CH + k] : 0.f);
-        alphas[p] = 1.0f - T0;
-        last_ids[p] = last0;
-    }
-    if (q.in1) {
-        const int64_t p = ((int64_t)q.c * H + q.py1) * W + q.px;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) render[p * CH + k] = pix1[k] + (bg ? T1 * bg[q.c * CH + k] : 0.f);
-        alphas[p] = 1.0f - T1;
-        last_ids[p] = last1;
-    }
 }
 
 template <int CH, int RS, bool ABS>
@@ -590,23 +305,6 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel2(
 
 #include "raster_v4.inc"
 
-// Kernel generation per launch: 1 = first generation, 2 = one pixel per lane (4 wavefronts per tile), 3 = two pixels
-// per lane (2 wavefronts per tile), 4 = v3's mapping with the LDS-compacted survivor list (raster_v4.inc), 5 = the
-// same with one pixel per lane in the forward.  GSX_RASTER forces one (A/B runs, parity tests); otherwise 5: forward
-// with one pixel per lane (fastest at every size tried on MI355X, 1 and 8 cameras, tools/ab_raster.py), backward with
-// two (its per-entry cross-lane reduction is paid per wavefront); absgrad launches use the v3 backward.
-int raster_variant(bool backward, int64_t n_tiles) {
-    const char *e = getenv("GSX_RASTER");
-    if (e && e[0] >= '1' && e[0] <= '5') return e[0] - '0';
-    (void)backward; (void)n_tiles;
-    return 5;
-}
-
-bool use_v1() {
-    const char *e = getenv("GSX_RASTER_V1");
-    return e && e[0] == '1';
-}
-
 }  // namespace
 
 extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
@@ -620,42 +318,17 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
     const int64_t T = C * tile_w * tile_h;
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
     hipStream_t st = (hipStream_t)stream;
-    const int variant = n_touched ? raster_variant(false, T) : 5;   // only the v4 kernels can skip the touched counts
-    const char *pf = getenv("GSX_PAD_F");
-    const size_t pad_f = pf ? (size_t)atoi(pf) * 1024 : 0;
-    const bool v1 = (use_v1() || variant == 1) && !offsets_has_end && n_touched;
-#define LAUNCH(ch, rs)                                                                                              \
-    do {                                                                                                            \
-        if (variant == 5 && !v1) {                                                                                  \
-            if (n_touched)                                                                                          \
-                hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, true>), dim3((unsigned)T), dim3(256), pad_f, st, rec,   \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   visibility_min_T, render, alphas, last_ids, n_touched, tile_order);                          \
-            else                                                                                                    \
-                hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, false>), dim3((unsigned)T), dim3(256), pad_f, st, rec,  \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   visibility_min_T, render, alphas, last_ids, n_touched, tile_order);                          \
-        } else if (variant == 4 && !v1) {                                                                           \
-            if (n_touched)                                                                                          \
-                hipLaunchKernelGGL((raster_fwd_kernel4<ch, rs, true>), dim3((unsigned)T), dim3(128), 0, st, rec,    \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   visibility_min_T, render, alphas, last_ids, n_touched);                          \
-            else                                                                                                    \
-                hipLaunchKernelGGL((raster_fwd_kernel4<ch, rs, false>), dim3((unsigned)T), dim3(128), 0, st, rec,   \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   visibility_min_T, render, alphas, last_ids, n_touched);                          \
-        } else if (v1)                                                                                              \
-            hipLaunchKernelGGL((raster_fwd_kernel_v1<ch, rs>), dim3((unsigned)T), dim3(256), 0, st, rec,           \
-                               backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, visibility_min_T,       \
-                               render, alphas, last_ids, n_touched);                                                \
-        else if (variant == 2)                                                                                      \
-            hipLaunchKernelGGL((raster_fwd_kernel<ch, rs>), dim3((unsigned)T), dim3(256), 0, st, rec, backgrounds, \
-                               offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, visibility_min_T,  \
-                               render, alphas, last_ids, n_touched);                                                \
-        else                                                                                                        \
-            hipLaunchKernelGGL((raster_fwd_kernel2<ch, rs>), dim3((unsigned)T), dim3(128), 0, st, rec, backgrounds, \
-                               offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, visibility_min_T,  \
-                               render, alphas, last_ids, n_touched);                                                \
+    // one pixel per lane, four quadrant wavefronts per tile: fastest forward at every size tried on MI355X (1 and 8 cameras)
+#define LAUNCH(ch, rs)                                                                                               \
+    do {                                                                                                             \
+        if (n_touched)                                                                                               \
+            hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, rec,        \
+                               backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,          \
+                               visibility_min_T, render, alphas, last_ids, n_touched, tile_order);                   \
+        else                                                                                                         \
+            hipLaunchKernelGGL((raster_fwd_kernel4q<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, rec,       \
+                               backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,          \
+                               visibility_min_T, render, alphas, last_ids, n_touched, tile_order);                   \
     } while (0)
     switch (CH) {
         case 1: LAUNCH(1, 8); break;
@@ -682,82 +355,38 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     GSX_CHECK_ARG(rec && flatten_ids && v_rec);
     const int64_t T = C * tile_w * tile_h;
     hipStream_t st = (hipStream_t)stream;
-    const int variant = raster_variant(true, T);
-    const char *pb = getenv("GSX_PAD_B");
-    const size_t pad_b = pb ? (size_t)atoi(pb) * 1024 : 0;
-    const bool v1 = (use_v1() || variant == 1) && !offsets_has_end;
-    const char *bb = getenv("GSX_BWD_MODE");
-    // Gradient accumulation without LDS atomics (reduce-scatter + cross-row sums in registers, plain stores into
-    // per-wavefront accumulator copies).  Full chip (>= 4096 tiles): two pixels per lane, two wavefronts per tile, batches
-    // of 128 (mode 4: -16..18 % at eight cameras against the LDS-atomic modes).  One camera: the time is that of the
-    // most loaded SIMD (1200 tiles, everything resident at once), so four quadrant wavefronts per tile with one pixel
-    // per lane balance better although they execute more instructions in total (modes 5 / 6 = batches of 64 / 128:
-    // another -4..5 %; batches of 128 pay off with deep tile lists).  GSX_BWD_MODE=0..6 for A/B runs (tools/ab_raster.py).
-    const int bwd_auto = T >= 4096 ? 4 : (M / (T > 0 ? T : 1) > 1000 ? 6 : 5);
-    // geometry-only gradients exist in the quadrant kernels; a caller that asks for them gets those kernels
+    // Gradient accumulation without LDS atomics everywhere (reduce-scatter + cross-row sums in registers, plain stores into
+    // per-wavefront accumulator copies).  Selection by launch shape (measured on MI355X):
+    //   absgrad wanted                 : the two-pixels-per-lane kernel with LDS row sums (the only one with the |v_xy| channel)
+    //   geometry-only (frozen map)     : quadrant kernel, batches of 64 - all 1200 workgroups of a camera resident at once
+    //                                    (25 KiB of LDS, 73 VGPRs; with batches of 128 15 % of the tiles wait for a second
+    //                                    round: 86.9 -> 80.9 us at 500 k)
+    //   full chip (>= 4096 tiles)      : two pixels per lane, two wavefronts per tile, batches of 128
+    //   one camera                     : quadrant kernel; batches of 128 with deep tile lists, 64 otherwise
     const bool geom_only = geometry_only != 0 && !v_abs;
-    // geometry-only: batches of 64 (all 1200 workgroups of a camera resident at once: 25 KiB of LDS, 73 VGPRs; with
-    // batches of 128 only 4 workgroups fit a CU and 15 % of the tiles wait for a second round: 86.9 -> 80.9 us at 500 k)
-    const int bwd_mode = geom_only ? ((bb && (bb[0] == '5' || bb[0] == '6')) ? bb[0] - '0' : 5)
-                                   : (bb && bb[0] >= '0' && bb[0] <= '6') ? bb[0] - '0' : bwd_auto;
-    const char *sb = getenv("GSX_BWD_SCALAR");
-    const bool scalar_bwd = sb && sb[0] == '1';
-#define ARGS1 rec, backgrounds, offsets, flatten_ids, M, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
-#define ARGS rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas, last_ids, v_render, v_alphas, v_rec, v_abs
-#define LAUNCH(ch, rs)                                                                                              \
-    do {                                                                                                            \
-        if (variant >= 4 && !v1 && !v_abs) {                                                                        \
-            if (bwd_mode == 5)                                                                                      \
-                if (geom_only)                                                                                      \
-                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, true>), dim3((unsigned)T), dim3(256), pad_b, st, \
-                                       rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
-                                       tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
-                else                                                                                                \
-                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, false>), dim3((unsigned)T), dim3(256), pad_b, st, \
-                                       rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
-                                       tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
-            else if (bwd_mode == 6)                                                                                 \
-                if (geom_only)                                                                                      \
-                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128, true>), dim3((unsigned)T), dim3(256), pad_b, st, \
-                                       rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
-                                       tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
-                else                                                                                                \
-                    hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128, false>), dim3((unsigned)T), dim3(256), pad_b, st, \
-                                       rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w,     \
-                                       tile_h, alphas, last_ids, v_render, v_alphas, v_rec, tile_order);             \
-            else if (bwd_mode == 3)                                                                                 \
-                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 3>), dim3((unsigned)T), dim3(128), 0, st, rec, \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
-            else if (bwd_mode == 4)                                                                                 \
-                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 128, 3>), dim3((unsigned)T), dim3(128), 0, st, rec, \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec, tile_order);                                    \
-            else if (bwd_mode == 2)                                                                                 \
-                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 2>), dim3((unsigned)T), dim3(128), 0, st, rec, \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
-            else if (bwd_mode == 0)                                                                                 \
-                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 0>), dim3((unsigned)T), dim3(128), 0, st, rec, \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
-            else                                                                                                    \
-                hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 256, 1>), dim3((unsigned)T), dim3(128), 0, st, rec, \
-                                   backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h,     \
-                                   alphas, last_ids, v_render, v_alphas, v_rec);                                    \
-        } else if (v1) {                                                                                            \
-            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS1); \
-            else hipLaunchKernelGGL((raster_bwd_kernel_v1<ch, rs, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS1);      \
-        } else if (variant >= 3) {                                                                                  \
-            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel2<ch, rs, true>), dim3((unsigned)T), dim3(128), 0, st, ARGS);   \
-            else hipLaunchKernelGGL((raster_bwd_kernel2<ch, rs, false>), dim3((unsigned)T), dim3(128), 0, st, ARGS);        \
-        } else if (scalar_bwd) {                                                                                    \
-            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, true, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS);  \
-            else hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, false, true>), dim3((unsigned)T), dim3(256), 0, st, ARGS);       \
-        } else {                                                                                                    \
-            if (v_abs) hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, true, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS); \
-            else hipLaunchKernelGGL((raster_bwd_kernel<ch, rs, false, false>), dim3((unsigned)T), dim3(256), 0, st, ARGS);      \
-        }                                                                                                           \
+    const int64_t per_tile = M / (T > 0 ? T : 1);
+#define LAUNCH(ch, rs)                                                                                               \
+    do {                                                                                                             \
+        if (v_abs)                                                                                                   \
+            hipLaunchKernelGGL((raster_bwd_kernel2<ch, rs, true>), dim3((unsigned)T), dim3(128), 0, st, rec,         \
+                               backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas,  \
+                               last_ids, v_render, v_alphas, v_rec, v_abs);                                          \
+        else if (geom_only)                                                                                          \
+            hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, true>), dim3((unsigned)T), dim3(256), 0, st, rec,    \
+                               backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas,  \
+                               last_ids, v_render, v_alphas, v_rec, tile_order);                                     \
+        else if (T >= 4096)                                                                                          \
+            hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 128>), dim3((unsigned)T), dim3(128), 0, st, rec,          \
+                               backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas,  \
+                               last_ids, v_render, v_alphas, v_rec, tile_order);                                     \
+        else if (per_tile > 1000)                                                                                    \
+            hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 128, false>), dim3((unsigned)T), dim3(256), 0, st, rec,  \
+                               backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas,  \
+                               last_ids, v_render, v_alphas, v_rec, tile_order);                                     \
+        else                                                                                                         \
+            hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, false>), dim3((unsigned)T), dim3(256), 0, st, rec,   \
+                               backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas,  \
+                               last_ids, v_render, v_alphas, v_rec, tile_order);                                     \
     } while (0)
     switch (CH) {
         case 1: LAUNCH(1, 8); break;
@@ -768,8 +397,6 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
         default: gsx_set_error("gsx_raster_bwd: CH=%d unsupported (1..5)", CH); return GSX_E_UNSUPPORTED;
     }
 #undef LAUNCH
-#undef ARGS
-#undef ARGS1
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }

@@ -198,7 +198,7 @@ class RenderPlan:
         dev = self.dev
         self.flat = torch.empty(cap, dtype=torch.int32, device=dev)
         # heaviest-first launch order pays off while the tile lists are short (see rasterization.rasterization)
-        self.tile_order = torch.empty(self.T, dtype=torch.int32, device=dev) if (cap < 1000 * self.T or __import__('os').environ.get('GSX_FORCE_ORDER') == '1') else None
+        self.tile_order = torch.empty(self.T, dtype=torch.int32, device=dev) if cap < 1000 * self.T else None
         if self.front:
             nbytes = int(lib.gsx_front_workspace_bytes(self.N, self.C, self.tile_w, self.tile_h, cap))
         else:

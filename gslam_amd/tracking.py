@@ -95,11 +95,11 @@ def warp_track(new_frame: Frame, ref_frame: Frame, ref_img: torch.Tensor, ref_de
     n_iters = conf.num_tracking_iters if n_iters is None else n_iters
     K = new_frame.camera.intrinsics
     warp = Warp(K, new_frame.camera.height, new_frame.camera.width).to(K.device)
-    params = list(new_frame.pose.parameters())
-    if conf.learn_exposure_params:
-        params.append(new_frame.exposure_params)
-    opt = torch.optim.SGD(params, lr=conf.pose_optim_lr, momentum=0.8, nesterov=True)
+    # frontend.py:193-210: Nesterov SGD on the pose, exponential decay, the exposure pair as a second group at lr 0.01
+    opt = torch.optim.SGD(list(new_frame.pose.parameters()), lr=conf.pose_optim_lr, momentum=0.8, nesterov=True)
     sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=conf.pose_optim_lr_decay)
+    if conf.learn_exposure_params:
+        opt.add_param_group({'params': new_frame.exposure_params, 'lr': 0.01})
     loss = None
     ref_pose = ref_frame.pose().detach()
     for _ in range(n_iters):

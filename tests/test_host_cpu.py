@@ -19,7 +19,7 @@ def test_library_is_rebuilt_from_current_sources():
     from gslam_amd.csrc.build import OUT, SOURCES, HERE, build
     build()                                                    # no-op when fresh, recompiles what changed
     so = os.path.getmtime(OUT)
-    for src in list(SOURCES) + ["gsx_common.h", "raster_v1.inc"]:
+    for src in list(SOURCES) + ["gsx_common.h", "raster_v4.inc", "project_core.h", "track_opt.h"]:
         assert os.path.getmtime(os.path.join(HERE, src)) <= so, f"{src} is newer than libgsx.so"
 
 
