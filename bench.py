@@ -59,7 +59,8 @@ def parse():
 
 
 def make_frames(indices, W, H, dev, gt_scene, learnable=True):
-    """Synthetic frames: pose c = 0.05*c m along x + 1 deg*c yaw; image = render of scene(seed+1)."""
+    """Synthetic frames: pose c = 0.05*c m along x + 1 deg*c yaw; image = render of scene(seed+1).
+    ``indices`` may be fractional (gslam_amd.synthetic.sequence_param: the tracked frames of the sequence)."""
     from gslam_amd.primitives import Camera, Frame, PoseZhou
     from gslam_amd.synthetic import make_intrinsics, make_viewmat
     K = make_intrinsics(W, H).to(dev)
@@ -69,15 +70,17 @@ def make_frames(indices, W, H, dev, gt_scene, learnable=True):
         V = make_viewmat(c).to(dev)
         with torch.no_grad():
             img = gt_scene([cam], [PoseZhou(V, is_learnable=False).to(dev)], render_depth=False).rgbs[0].clamp(0, 1)
-        frames.append(Frame(img=img.contiguous(), timestamp=c / 30.0, camera=cam, pose=PoseZhou(V, is_learnable=learnable).to(dev),
-                            gt_pose=V, index=c, exposure_params=torch.zeros(2, device=dev)))
+        frames.append(Frame(img=img.contiguous(), timestamp=len(frames) / 30.0, camera=cam,
+                            pose=PoseZhou(V, is_learnable=learnable).to(dev), gt_pose=V, index=len(frames),
+                            exposure_params=torch.zeros(2, device=dev)))
     return frames, cam
 
 
 class StageTimer:
     """Times every C-ABI launch with HIP events on the stream the kernels are launched on (torch's current stream: the
     instrumented passes issue their plans' launches there)."""
-    STAGES = ("gsx_pose_zhou_fwd", "gsx_project_fwd", "gsx_isect_bin_sort", "gsx_raster_fwd", "gsx_ssim_fwd",
+    STAGES = ("gsx_pose_zhou_fwd", "gsx_project_fwd", "gsx_isect_bin_sort", "gsx_front_fwd", "gsx_front_pose_bwd",
+              "gsx_raster_fwd", "gsx_ssim_fwd",
               "gsx_ssim_bwd", "gsx_map_loss", "gsx_raster_bwd", "gsx_project_bwd", "gsx_pose_zhou_bwd_partials",
               "gsx_isotropic_loss_acc", "gsx_loss_finish", "gsx_counters_add", "gsx_adam_multi_steps",
               "gsx_adam_multi_steps_decay", "gsx_track_opt_tail")
@@ -123,6 +126,8 @@ def algorithmic_bytes(N, C, M, P, CH, T):
     return {
         "gsx_project_fwd": C * N * (40 + 28),
         "gsx_isect_bin_sort": C * N * 16 + C * N * 4 + M * 12 + M * 24 + M * 8 + T * 4,
+        "gsx_front_fwd": C * N * (40 + 28) + C * N * 16 + C * N * 4 + M * 12 + M * 24 + M * 8 + T * 4,
+        "gsx_front_pose_bwd": C * N * (40 + 28 + 24) + N * 40 + C * 64,
         "gsx_map_loss": P * (4 * CH + 4 + 12 + 4 * CH),
         "gsx_raster_fwd": M * (28 + 4 * CH) + P * (4 * CH + 8) + C * N * 4,
         "gsx_raster_bwd": P * (4 * CH + 12) + M * (28 + 4 * CH) + C * N * (24 + 4 * CH),
@@ -173,7 +178,10 @@ def run_headline(args, dev):
     gt_scene = GaussianSplattingData.from_dict(make_scene(N, 1), dev)
     backend_map = GaussianSplattingData.from_dict(make_scene(N, 0), dev)
     n_frames = warmup + steps
-    frames, cam = make_frames(range(WINDOW + n_frames), W, H, dev, gt_scene)
+    # 8 keyframes (c = 0..7, the BA window) + the tracked sequence: a bounded sweep over the same pose range, so that every
+    # frame sees the scene (with c = frame index the camera has turned away from it after ~60 frames and closures get cheap)
+    from gslam_amd.synthetic import sequence_param
+    frames, cam = make_frames(list(range(WINDOW)) + [sequence_param(i) for i in range(n_frames)], W, H, dev, gt_scene)
     del gt_scene
     keyframes = frames[:WINDOW]                             # pre-seeded window: BA runs at its full size from the start
     mailbox = MapMailbox()

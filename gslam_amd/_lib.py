@@ -98,6 +98,7 @@ PROTOTYPES = {
     "gsx_zero_words": (i32, [vp, i64, vp]),
     "gsx_front_workspace_bytes": (i64, [i64, i64, i32, i32, i64]),
     "gsx_front_rows": (i64, [i64, i64, i32, i32]),
+    "gsx_front_layout": (i32, [i64, i64, i32, i32, i64, C.POINTER(i64)]),
     "gsx_front_pose_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, i64, vp, i64, vp, vp]),
     "gsx_front_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                             vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp]),

@@ -951,7 +951,29 @@ struct FrontArgs {
     int32_t *cnt;        // [C][R][n_tiles]
     int32_t *n_inst;     // [C][R]
     PreRec *recs;        // [C][R][1024 * items]
+    int compact;         // rec / v_rec rows are indexed by instance slot ((c * R + row) * seg_cap + position), not flatten id
 };
+
+// Position of every flagged thread of the workgroup among the flagged ones, IN THREAD ORDER (a deterministic, monotone
+// compaction: ballot prefix inside the wavefront, wavefront bases from a scan of the per-wavefront counts in LDS), and
+// their number.  Two barriers; must be reached by every thread.  Monotone on purpose: slots follow the flatten ids, so a
+// sort key (depth, slot) orders ties exactly like (depth, flatten id).
+__device__ __forceinline__ int ordered_position(bool flag, int *s_wcnt, int &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) s_wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < FRONT_THREADS / 64; ++w) {
+        const int cw = s_wcnt[w];
+        base += (w < wave) ? cw : 0;
+        tot += cw;
+    }
+    __syncthreads();
+    total = tot;
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+}
 
 // Conservative screen-space cull of one Gaussian for one camera from its mean and its largest scale alone (no covariance
 // algebra): true only if the full projection is CERTAIN to cull it - same near / far comparison on the same expression, and
@@ -972,28 +994,41 @@ __device__ __forceinline__ bool surely_culled(const float mean[3], float smax2, 
     return (pmx + rb <= 0.0f) || (pmx - rb >= (float)W) || (pmy + rb <= 0.0f) || (pmy - rb >= (float)H);
 }
 
+template <int ITEMS>
 __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs a) {
     extern __shared__ int s_front[];                        // [C * n_tiles] counts, [C] instance counters, survivors
     const int n_tiles = a.tile_w * a.tile_h;
     const int C = a.C;
     int *s_cnt = s_front, *s_ninst = s_front + C * n_tiles;
-    int *s_nsurv = s_ninst + C;
-    unsigned short *s_list = reinterpret_cast<unsigned short *>(s_nsurv + 1);     // [1024 * items] local indices
-    for (int i = threadIdx.x; i < C * n_tiles + C + 1; i += FRONT_THREADS) s_front[i] = 0;
+    int *s_wcnt = s_ninst + C;                                                     // [FRONT_THREADS / 64] scratch
+    unsigned short *s_list = reinterpret_cast<unsigned short *>(s_wcnt + FRONT_THREADS / 64);   // [1024 * items] local indices
+    int n_surv = 0;
+    for (int i = threadIdx.x; i < C * n_tiles + C; i += FRONT_THREADS) s_front[i] = 0;
     __syncthreads();
-    const int seg_cap = FRONT_THREADS * a.items;
-    const int lane = threadIdx.x & 63;
+    const int seg_cap = FRONT_THREADS * ITEMS;
     const bool skip_culled = (a.flags & GSX_PROJ_SKIP_CULLED) != 0;
     const int64_t g0 = (int64_t)blockIdx.x * seg_cap;
-    // ---- phase 1: cheap conservative cull; the survivors' local indices are compacted into LDS ------------------------------
-    for (int it = 0; it < a.items; ++it) {
+    // ---- phase 1: cheap conservative cull; the survivors' local indices are compacted into LDS.  The loads of all ITEMS
+    // Gaussians of a thread are issued before any of them is used (one memory round trip for the phase, not ITEMS) ---------
+    float pm[ITEMS][3], psm[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t g = g0 + it * FRONT_THREADS + threadIdx.x;
+        const bool active = g < a.N;
+        pm[it][0] = active ? a.means[3 * g] : 0.f;
+        pm[it][1] = active ? a.means[3 * g + 1] : 0.f;
+        pm[it][2] = active ? a.means[3 * g + 2] : 0.f;
+        psm[it] = active ? fmaxf(a.scales[3 * g], fmaxf(a.scales[3 * g + 1], a.scales[3 * g + 2])) : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
         const int loc = it * FRONT_THREADS + threadIdx.x;
         const int64_t g = g0 + loc;
         const bool active = g < a.N;
         bool survive = false;
         if (active) {
-            const float mean[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
-            float sm = fmaxf(a.scales[3 * g], fmaxf(a.scales[3 * g + 1], a.scales[3 * g + 2]));
+            const float mean[3] = {pm[it][0], pm[it][1], pm[it][2]};
+            float sm = psm[it];
             if (a.flags & GSX_PROJ_LOG_SCALES) sm = expf(sm);
             const float smax2 = sm * sm;
             for (int c = 0; c < C; ++c) {
@@ -1011,22 +1046,18 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
                 else if (!skip_culled) survive = true;      // rows of culled instances are wanted as zeros: full path writes them
                 else {
                     const int64_t idx = (int64_t)c * a.N + g;
-                    a.radii[idx] = 0;
-                    a.tiles[idx] = 0;
+                    if (a.radii) a.radii[idx] = 0;
+                    if (a.tiles) a.tiles[idx] = 0;
                 }
             }
             if (!survive && a.vis_count) a.vis_count[g] = 0;
         }
-        const unsigned long long m = __ballot(survive);
-        if (m != 0ull) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(s_nsurv, __popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (survive) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)loc;
-        }
+        int tot;
+        const int pos = ordered_position(survive, s_wcnt, tot);
+        if (survive) s_list[n_surv + pos] = (unsigned short)loc;
+        n_surv += tot;
     }
     __syncthreads();
-    const int n_surv = *s_nsurv;
     // ---- phase 2: the projection proper, dense over the survivors (whole wavefronts of real work) ---------------------------
     for (int s0 = 0; s0 < n_surv; s0 += FRONT_THREADS) {
         const int si = s0 + threadIdx.x;
@@ -1077,11 +1108,19 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
             Rect r = {0, 0, 0, 0};
             if (vis) r = tile_rect(mx, my, radius_i, a.tile_w, a.tile_h);
             const bool has = (r.x1 > r.x0) && (r.y1 > r.y0);
+            // slot of this instance in the workgroup's segment of camera c: monotone in the flatten id (ordered compaction)
+            const int run = s_ninst[c];
+            int tot;
+            const int pos = run + ordered_position(has, s_wcnt, tot);
+            if (threadIdx.x == 0) s_ninst[c] = run + tot;      // read again only behind the barrier that ends the trip
+            const int64_t slot = ((int64_t)c * a.R + blockIdx.x) * seg_cap + pos;
             if (active) {
-                a.radii[idx] = radius_i;
-                a.tiles[idx] = has ? (r.y1 - r.y0) * (r.x1 - r.x0) : 0;
+                if (a.radii) a.radii[idx] = radius_i;
+                if (a.tiles) a.tiles[idx] = has ? (r.y1 - r.y0) * (r.x1 - r.x0) : 0;
                 n_vis += vis ? 1 : 0;
-                if (vis || !skip_culled) {
+                const bool write_row = a.compact ? has : (vis || !skip_culled);
+                if (write_row) {
+                    const int64_t row = a.compact ? slot : idx;
                     if (a.means2d) { a.means2d[2 * idx] = mx; a.means2d[2 * idx + 1] = my; }
                     if (a.depths) a.depths[idx] = depth;
                     if (a.conics) { a.conics[3 * idx] = con0; a.conics[3 * idx + 1] = con1; a.conics[3 * idx + 2] = con2; }
@@ -1089,36 +1128,29 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
                     int n = 3;
                     if (a.flags & GSX_PROJ_RENDER_DEPTH) ch[n++] = depth;
                     if (a.flags & GSX_PROJ_BETAS) ch[n++] = beta;
-                    float4 *o = reinterpret_cast<float4 *>(a.rec + idx * 12);
+                    float4 *o = reinterpret_cast<float4 *>(a.rec + row * 12);
                     o[0] = make_float4(mx, my, con0, con1);
                     o[1] = make_float4(con2, opac, vis ? ch[0] : 0.f, vis ? ch[1] : 0.f);
                     o[2] = make_float4(vis ? ch[2] : 0.f, vis ? ch[3] : 0.f, vis ? ch[4] : 0.f, 0.f);
                     if (a.v_rec) {
-                        float4 *z = reinterpret_cast<float4 *>(a.v_rec + idx * 12);
+                        float4 *z = reinterpret_cast<float4 *>(a.v_rec + row * 12);
                         z[0] = z[1] = z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
-            }
-            // instance record: position = wavefront's reservation in the workgroup's segment + rank inside the wavefront
-            const unsigned long long m = __ballot(has);
-            if (m != 0ull) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_ninst[c], __popcll(m));
-                base = __builtin_amdgcn_readfirstlane(base);
                 if (has) {
-                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
                     PreRec pr;
                     pr.xs = (uint32_t)r.x0 | ((uint32_t)r.x1 << 16);
                     pr.ys_c = (uint32_t)r.y0 | ((uint32_t)r.y1 << 12) | ((uint32_t)c << 24);
                     pr.depth = __float_as_uint(depth);
                     pr.id = (uint32_t)idx;
-                    a.recs[((int64_t)c * a.R + blockIdx.x) * seg_cap + pos] = pr;
+                    a.recs[slot] = pr;
                 }
             }
             walk_rects(r, a.tile_w, 0u, 0u, [&](int tile, unsigned int, unsigned int) { atomicAdd(&s_cnt[tile], 1); },
                        c * n_tiles);
         }
         if (active && a.vis_count) a.vis_count[g] = n_vis;
+        __syncthreads();                                     // s_ninst is read again at the top of the next trip
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C * n_tiles; i += FRONT_THREADS) {
@@ -1134,7 +1166,7 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
     const PreRec *__restrict__ recs, const int32_t *__restrict__ n_inst, int R, int seg_cap, int C, int tile_w,
     int tile_h, int stripes, int rps, int64_t M_cap, const int32_t *__restrict__ counts, int prescanned,
     const int32_t *__restrict__ cnt, int32_t *__restrict__ offsets_out, int64_t *__restrict__ M_dev,
-    int32_t *__restrict__ status, unsigned long long *__restrict__ entries) {
+    int32_t *__restrict__ status, unsigned long long *__restrict__ entries, int compact) {
     extern __shared__ int s_cur[];                          // [T]: exclusive offsets, then this stripe's write cursors
     __shared__ long long s_wsum[FPLACE_THREADS / 64];
     const int n_tiles = tile_w * tile_h, T = C * n_tiles;
@@ -1154,11 +1186,22 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
     if (prescanned) {
         for (int i = t; i < T; i += FPLACE_THREADS) s_cur[i] = counts[i];
     } else {
-        // exclusive scan of the T totals: contiguous chunk per thread, wavefront scan of the chunk sums, 4 wavefront sums
+        // exclusive scan of the T totals: contiguous chunk per thread, wavefront scan of the chunk sums, 4 wavefront sums.
+        // Up to 8 totals per thread (one camera at 640x480: 5) are fetched with independent loads into registers and reused
+        // for the second pass - two loops of dependent loads were 5 us of a 20 us kernel.
         const int per = (T + FPLACE_THREADS - 1) / FPLACE_THREADS;
         const int lo = min(T, t * per), hi = min(T, lo + per);
+        constexpr int PER_REG = 8;
+        int cv[PER_REG];
         long long sum = 0;
-        for (int i = lo; i < hi; ++i) sum += max(counts[i], 0);
+        if (per <= PER_REG) {
+#pragma unroll
+            for (int k = 0; k < PER_REG; ++k) cv[k] = (lo + k < hi) ? counts[lo + k] : 0;
+#pragma unroll
+            for (int k = 0; k < PER_REG; ++k) sum += max(cv[k], 0);
+        } else {
+            for (int i = lo; i < hi; ++i) sum += max(counts[i], 0);
+        }
         long long incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -1174,13 +1217,27 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
             total += ws;
         }
         const bool pub = blockIdx.x == 0;
-        for (int i = lo; i < hi; ++i) {
-            const int cval = counts[i];
-            if (cval < 0 && pub) atomicOr(status, 2);
-            const int32_t o = (int32_t)min(run, (long long)0x7fffffff);
-            s_cur[i] = o;
-            if (pub) offsets_out[i] = o;
-            run += max(cval, 0);
+        if (per <= PER_REG) {
+#pragma unroll
+            for (int k = 0; k < PER_REG; ++k) {
+                const int i = lo + k;
+                if (i < hi) {
+                    if (cv[k] < 0 && pub) atomicOr(status, 2);
+                    const int32_t o = (int32_t)min(run, (long long)0x7fffffff);
+                    s_cur[i] = o;
+                    if (pub) offsets_out[i] = o;
+                    run += max(cv[k], 0);
+                }
+            }
+        } else {
+            for (int i = lo; i < hi; ++i) {
+                const int cval = counts[i];
+                if (cval < 0 && pub) atomicOr(status, 2);
+                const int32_t o = (int32_t)min(run, (long long)0x7fffffff);
+                s_cur[i] = o;
+                if (pub) offsets_out[i] = o;
+                run += max(cval, 0);
+            }
         }
         if (pub && t == 0) {
             offsets_out[T] = (int32_t)min(total, (long long)0x7fffffff);
@@ -1209,7 +1266,8 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
                 const PreRec pr = (c == 0 && i0 == 0) ? pre0 : seg[i];
                 r.x0 = (int)(pr.xs & 0xffffu); r.x1 = (int)(pr.xs >> 16);
                 r.y0 = max((int)(pr.ys_c & 0xfffu), ys0); r.y1 = min((int)((pr.ys_c >> 12) & 0xfffu), ys1);
-                klo = pr.id; khi = pr.depth;
+                // the low key word: flatten id, or the instance's slot (same order - slots are monotone in the flatten id)
+                klo = compact ? (unsigned int)(((int64_t)c * R + row) * seg_cap + i) : pr.id; khi = pr.depth;
                 if (r.y1 <= r.y0) r = Rect{0, 0, 0, 0};
             }
             place_rects(r, tile_w, klo, khi, s_cur, M_cap, entries, c * n_tiles);
@@ -1229,7 +1287,7 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
     const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ viewmats, const float *__restrict__ Ks, int64_t N, int C, int W, int H, float eps2d,
     float near_p, float far_p, int flags, const float *__restrict__ v_rec, const PreRec *__restrict__ recs,
-    const int32_t *__restrict__ n_inst, int R, int seg_cap, float *__restrict__ partials /*[R][C][12]*/) {
+    const int32_t *__restrict__ n_inst, int R, int seg_cap, float *__restrict__ partials /*[R][C][12]*/, int compact) {
     __shared__ float s_part[FPB_THREADS / 64][12];
     const int row = blockIdx.x, c = blockIdx.y;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -1246,7 +1304,8 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
         const float q[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
         float s[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
         if (flags & GSX_PROJ_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
-        const float4 *r4 = reinterpret_cast<const float4 *>(v_rec + idx * 12);
+        const int64_t vrow = compact ? (((int64_t)c * R + row) * seg_cap + i) : idx;
+        const float4 *r4 = reinterpret_cast<const float4 *>(v_rec + vrow * 12);
         const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2];
         QuatRot qr;
         quat_to_rotmat(q, qr);
@@ -1363,7 +1422,9 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
                              int32_t *offsets, int64_t *M_dev, int32_t *status, int32_t *flatten_ids, int32_t *tile_order,
                              void *workspace, int64_t workspace_bytes, void *stream) {
     GSX_CHECK_ARG(N >= 1 && C >= 1 && C <= 255 && W > 0 && H > 0 && C * N < ((int64_t)1 << 31));
-    GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && logit_opacities && logit_colors && radii && tiles_per_gauss && rec);
+    const int compact = (flags & GSX_PROJ_COMPACT) ? 1 : 0;
+    GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && logit_opacities && logit_colors && rec);
+    GSX_CHECK_ARG(compact || (radii && tiles_per_gauss));
     GSX_CHECK_ARG(!(flags & GSX_PROJ_BETAS) || log_uncertainties);
     GSX_CHECK_ARG(offsets && M_dev && status && flatten_ids && M_cap >= 1 && M_cap < ((int64_t)1 << 31));
     const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
@@ -1385,13 +1446,21 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
     a.radii = radii; a.tiles = tiles_per_gauss; a.vis_count = vis_count; a.means2d = means2d; a.depths = depths;
     a.conics = conics; a.rec = rec; a.v_rec = v_rec_clear;
     a.cnt = (int32_t *)(ws + L.matrix_off); a.n_inst = (int32_t *)(ws + L.ninst_off); a.recs = (PreRec *)(ws + L.recs_off);
-    const size_t front_lds = (size_t)((T + C + 1) * 4 + 2 * FRONT_THREADS * L.items);   // histogram + survivor list
-    if (front_lds > 65536 || L.items > 63) {
+    a.compact = compact;
+    const size_t front_lds = (size_t)((T + C + FRONT_THREADS / 64) * 4 + 2 * FRONT_THREADS * L.items);   // histogram + survivor list
+    if (front_lds > 65536 || L.items > 8) {
         gsx_set_error("gsx_front_fwd: %lld tiles over all cameras / %d Gaussians per thread do not fit the LDS plan",
                       (long long)T, L.items);
         return GSX_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(front_project_kernel, dim3((unsigned)L.R), dim3(FRONT_THREADS), front_lds, st, a);
+    switch (L.items) {
+        case 1: hipLaunchKernelGGL(front_project_kernel<1>, dim3((unsigned)L.R), dim3(FRONT_THREADS), front_lds, st, a); break;
+        case 2: hipLaunchKernelGGL(front_project_kernel<2>, dim3((unsigned)L.R), dim3(FRONT_THREADS), front_lds, st, a); break;
+        case 4: hipLaunchKernelGGL(front_project_kernel<4>, dim3((unsigned)L.R), dim3(FRONT_THREADS), front_lds, st, a); break;
+        case 8: hipLaunchKernelGGL(front_project_kernel<8>, dim3((unsigned)L.R), dim3(FRONT_THREADS), front_lds, st, a); break;
+        default: gsx_set_error("gsx_front_fwd: %d Gaussians per thread unsupported (N too large for the fused front)", L.items);
+                 return GSX_E_UNSUPPORTED;
+    }
     GSX_CHECK_LAUNCH();
     // with a launch order wanted the totals are scanned (and bucketed) by the one-workgroup kernel into `offsets` itself;
     // otherwise every placement workgroup scans them on its own and workgroup 0 publishes the offsets
@@ -1409,9 +1478,9 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
     unsigned long long *scratch = (unsigned long long *)(ws + L.scratch_off);
     hipLaunchKernelGGL(front_place_kernel, dim3((unsigned)(L.R * stripes)), dim3(FPLACE_THREADS), (size_t)(T * 4), st,
                        a.recs, a.n_inst, L.R, FRONT_THREADS * L.items, (int)C, tile_w, tile_h, stripes, rps, M_cap,
-                       col_out, tile_order ? 1 : 0, a.cnt, offsets, M_dev, status, entries);
+                       col_out, tile_order ? 1 : 0, a.cnt, offsets, M_dev, status, entries, compact);
     GSX_CHECK_LAUNCH();
-    const uint32_t id_max = (uint32_t)(C * N - 1);
+    const uint32_t id_max = compact ? (uint32_t)(C * (int64_t)L.R * FRONT_THREADS * L.items - 1) : (uint32_t)(C * N - 1);
     hipLaunchKernelGGL(tile_sort_count_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, scratch, offsets,
                        (int)n_tiles, bit_length((uint32_t)n_tiles), M_cap, id_max, (int64_t *)nullptr, flatten_ids);
     GSX_CHECK_LAUNCH();
@@ -1439,7 +1508,17 @@ extern "C" int gsx_front_pose_bwd(const float *means, const float *quats, const 
     hipLaunchKernelGGL(front_pose_bwd_kernel, dim3((unsigned)L.R, (unsigned)C), dim3(FPB_THREADS), 0, (hipStream_t)stream,
                        means, quats, scales, viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, flags, v_rec,
                        (const PreRec *)(ws + L.recs_off), (const int32_t *)(ws + L.ninst_off), L.R,
-                       FRONT_THREADS * L.items, partials);
+                       FRONT_THREADS * L.items, partials, (flags & GSX_PROJ_COMPACT) ? 1 : 0);
     GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+// out4 = { rows R, slots per (camera, row) segment, byte offset of the instance records in the workspace, byte offset of the
+// per-segment instance counts }: instance slot s = (c * R + row) * out4[1] + position; record s = 16 bytes
+// {x0 | x1 << 16, y0 | y1 << 12 | c << 24, depth bits, flatten id} at workspace + out4[2] + 16 s
+extern "C" int gsx_front_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int64_t *out4) {
+    GSX_CHECK_ARG(out4 && N >= 1 && C >= 1);
+    const FrontLayout L = front_layout(N, C, tile_w, tile_h, M_cap);
+    out4[0] = L.R; out4[1] = (int64_t)FRONT_THREADS * L.items; out4[2] = L.recs_off; out4[3] = L.ninst_off;
     return GSX_OK;
 }

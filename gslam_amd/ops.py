@@ -406,9 +406,12 @@ class _PackRecords(torch.autograd.Function):
 def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor, image_width: int,
                         image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
                         backgrounds: Optional[Tensor] = None, masks: Optional[Tensor] = None, packed: bool = False,
-                        absgrad: bool = False, visibility_min_T: float = 0.5) -> Tuple[Tensor, Tensor, Tensor]:
+                        absgrad: bool = False, visibility_min_T: float = 0.5, offsets_have_end: bool = False,
+                        tile_order: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """The gsplat FORK's op as called at gslam/rasterization.py:325-339: returns the 3-tuple
-    (render_colors[C,H,W,CH], render_alphas[C,H,W,1], n_touched[C,N] int32)."""
+    (render_colors[C,H,W,CH], render_alphas[C,H,W,1], n_touched[C,N] int32).
+    offsets_have_end (extension, sync-free callers): ``isect_offsets`` is the flat int32 [T+1] array of isect_bin_sort and
+    ``flatten_ids`` a capacity-sized buffer - tile ranges are clamped to it, nothing is read back."""
     if packed:
         raise NotImplementedError("packed rasterize_to_pixels is not on the gslam hot path")
     if masks is not None:
@@ -424,7 +427,7 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
         rec = _PackRecords.apply(means2d, conics, cols, opacities)
         r, a, nt, _ = _RasterizeRecords.apply(rec, means2d, conics, bg, isect_offsets, flatten_ids, ch,
                                               int(image_width), int(image_height), float(visibility_min_T),
-                                              bool(absgrad))
+                                              bool(absgrad), bool(offsets_have_end), True, None, tile_order, False)
         renders.append(r)
         if alphas is None:
             alphas, n_touched = a, nt

@@ -31,6 +31,7 @@ from .ops import PROJ_BETAS, PROJ_LOG_SCALES, PROJ_RENDER_DEPTH
 TILE = 16
 _VIEW_PARTIALS = 8      # GSX_PROJ_VIEW_PARTIALS
 _SKIP_CULLED = 16       # GSX_PROJ_SKIP_CULLED
+_COMPACT = 32           # GSX_PROJ_COMPACT
 
 
 def _arr(ptrs: Sequence[Optional[int]]):
@@ -182,9 +183,20 @@ class RenderPlan:
         self.front = (fits and Cn * N < (1 << 20)) if front is None else (bool(front) and fits)
         # a pose-only closure never reads the rows of culled instances nor the separate means2d / depths / conics arrays
         self.lean = grads == 'pose'
+        self.compact = False
         if self.front and grads == 'pose':
             # pose gradient over the visible instances the front leaves behind: one partial row per (front row, camera)
             self.pose_blocks = int(lib.gsx_front_rows(N, Cn, self.tile_w, self.tile_h))
+            # records and gradient records live per visible INSTANCE (slot-indexed, written densely by the projection's
+            # workgroups) instead of per flatten id: a third of a 500 k map is visible, and 48-byte rows scattered over a
+            # [N,12] array leave as partial-line writes; self.flat then carries slots (same order: GSX_PROJ_COMPACT)
+            self.compact = True
+            lay = (C.c_int64 * 4)()
+            check(lib.gsx_front_layout(N, Cn, self.tile_w, self.tile_h, 4096, lay), "gsx_front_layout")
+            self.front_rows, self.front_seg = int(lay[0]), int(lay[1])
+            n_slots = Cn * self.front_rows * self.front_seg
+            self.rec = torch.empty(n_slots, 12, dtype=f32, device=dev)
+            self.v_rec = torch.empty(n_slots, 12, dtype=f32, device=dev)
         self.capacity = 0
         self.flat = self.tile_order = self.isect_ws = None
         self.last_M = 0
@@ -235,11 +247,23 @@ class RenderPlan:
         ts = [splats.means, splats.quats, splats.scales, splats.opacities, splats.colors, splats.log_uncertainties]
         return all(a.data_ptr() == b.data_ptr() and a.shape == b.shape for a, b in zip(ts, self.map))
 
+    def slot_flatten_ids(self) -> torch.Tensor:
+        """compact plans: int64 [n_slots] flatten id (c * N + g) of every instance slot, from the front's instance records
+        (valid for the slots below each segment's count; for tests and debugging - one small gather)"""
+        assert self.compact
+        lay = (C.c_int64 * 4)()
+        check(lib.gsx_front_layout(self.N, self.C, self.tile_w, self.tile_h, self.capacity, lay), "gsx_front_layout")
+        n_slots = self.C * int(lay[0]) * int(lay[1])
+        recs = self.isect_ws[int(lay[2]):int(lay[2]) + n_slots * 16].view(torch.int32).view(n_slots, 4)
+        return recs[:, 3].long() & 0xFFFFFFFF
+
     def as_output(self):
         """the plan's buffers seen as the reference's RasterizationOutput (views, no copies): what pruning, insertion and
         the SYNC payload read after a render (gslam/rasterization.py:17-41).  ``means2d.grad`` is the view of the
         gradient records that ``means2d.retain_grad()`` would have produced (backend.py:326)."""
         from .rasterization import RasterizationOutput
+        if self.compact:
+            raise RuntimeError("a pose-only plan keeps its records per visible instance: no RasterizationOutput view")
         means2d = self.means2d
         if self.v_rec is not None:
             means2d = self.means2d.view(self.C, self.N, 2)
@@ -270,11 +294,14 @@ class RenderPlan:
     def _front(self, st: int):
         m = self.map
         lean = self.lean
+        flags = self.flags | (_SKIP_CULLED if lean else 0) | (_COMPACT if self.compact else 0)
         check(lib.gsx_front_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
-                                self.H, self.eps2d, self.near, self.far, self.flags | (_SKIP_CULLED if lean else 0),
-                                _p(m[3]), _p(m[4]), _p(m[5]), _p(self.radii), None if lean else _p(self.means2d),
-                                None if lean else _p(self.depths), None if lean else _p(self.conics), _p(self.tiles),
-                                _p(self.rec), _p(self.v_rec), _p(self.vis_count), self.capacity, _p(self.offsets),
+                                self.H, self.eps2d, self.near, self.far, flags,
+                                _p(m[3]), _p(m[4]), _p(m[5]), None if self.compact else _p(self.radii),
+                                None if lean else _p(self.means2d), None if lean else _p(self.depths),
+                                None if lean else _p(self.conics), None if self.compact else _p(self.tiles),
+                                _p(self.rec), _p(self.v_rec), None if self.compact else _p(self.vis_count),
+                                self.capacity, _p(self.offsets),
                                 _p(self.M_dev), _p(self.status), _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
                                 self.isect_ws.numel(), st), "gsx_front_fwd")
 
@@ -308,7 +335,8 @@ class RenderPlan:
         vr = self.v_rec.data_ptr()
         if self.grads == 'pose' and self.front:
             check(lib.gsx_front_pose_bwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C,
-                                         self.W, self.H, self.eps2d, self.near, self.far, self.flags, vr, self.capacity,
+                                         self.W, self.H, self.eps2d, self.near, self.far,
+                                         self.flags | (_COMPACT if self.compact else 0), vr, self.capacity,
                                          _p(self.isect_ws), self.isect_ws.numel(), _p(self.pose_ws), st),
                   "gsx_front_pose_bwd")
             return

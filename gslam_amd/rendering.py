@@ -19,10 +19,14 @@ def rasterization(
     eps2d: float = 0.3, sh_degree: Optional[int] = None, packed: bool = True, tile_size: int = 16,
     backgrounds: Optional[Tensor] = None, render_mode: str = "RGB", sparse_grad: bool = False, absgrad: bool = False,
     rasterize_mode: str = "classic", channel_chunk: int = 32, distributed: bool = False,
-    camera_model: str = "pinhole", covars: Optional[Tensor] = None, visibility_min_T: float = 0.5,
+    camera_model: str = "pinhole", covars: Optional[Tensor] = None, visibility_min_T: float = 0.5, capacity=None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Inputs are post-activation.  ``packed`` only changes upstream's memory layout, not the result; this build
-    always computes the dense [C,N] layout and reports it in ``meta`` (camera_ids/gaussian_ids are None)."""
+    always computes the dense [C,N] layout and reports it in ``meta`` (camera_ids/gaussian_ids are None).
+    ``capacity`` (extension): a gslam_amd.rasterization.IsectCapacity makes the render sync-free - the tile lists go into
+    capacity-sized buffers without the read-back of the intersection count, so the call can sit inside a captured HIP graph;
+    ``meta['flatten_ids']`` is then the capacity-sized buffer, ``meta['isect_ids']`` None and ``meta['n_isects']`` the
+    device-side count (poll ``capacity.validate()`` for overflow)."""
     N, C = means.shape[0], viewmats.shape[0]
     assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
     if distributed:
@@ -39,7 +43,15 @@ def rasterization(
     if sh_degree is None:
         cols = colors if colors.dim() == 3 else colors.unsqueeze(0).expand(C, -1, -1)
     else:
-        campos = torch.inverse(viewmats)[:, :3, 3]                        # [C,3]
+        # camera centre = inv(viewmat)[:3, 3] = -A^-1 t of the affine [A | t]; the 3x3 inverse is written out with cross
+        # products (rows r0, r1, r2: A^-1 = [r1 x r2, r2 x r0, r0 x r1] / det) - torch.inverse goes through a solver
+        # library that synchronises, which a captured HIP graph does not permit
+        A, tv = viewmats[:, :3, :3], viewmats[:, :3, 3]
+        c0 = torch.cross(A[:, 1], A[:, 2], dim=-1)
+        c1 = torch.cross(A[:, 2], A[:, 0], dim=-1)
+        c2 = torch.cross(A[:, 0], A[:, 1], dim=-1)
+        det = (A[:, 0] * c0).sum(-1, keepdim=True)
+        campos = -(c0 * tv[:, 0:1] + c1 * tv[:, 1:2] + c2 * tv[:, 2:3]) / det         # [C,3]
         dirs = means[None, :, :] - campos[:, None, :]                     # [C,N,3]
         coeffs = colors if colors.dim() == 3 else None
         if coeffs is None:
@@ -56,12 +68,38 @@ def rasterization(
             backgrounds = torch.zeros(C, 1, device=backgrounds.device)
 
     tile_width, tile_height = math.ceil(width / float(tile_size)), math.ceil(height / float(tile_size))
-    tiles_per_gauss, isect_ids, flatten_ids = ops.isect_tiles(means2d, radii, depths, tile_size, tile_width,
-                                                              tile_height, packed=False, n_cameras=C)
-    isect_offsets = ops.isect_offset_encode(isect_ids, C, tile_width, tile_height)
-    render_colors, render_alphas, n_touched = ops.rasterize_to_pixels(
-        means2d, conics, cols.contiguous(), opac.contiguous(), width, height, tile_size, isect_offsets, flatten_ids,
-        backgrounds=backgrounds, packed=False, absgrad=absgrad, visibility_min_T=visibility_min_T)
+    n_isects = None
+    if capacity is None:
+        tiles_per_gauss, isect_ids, flatten_ids = ops.isect_tiles(means2d, radii, depths, tile_size, tile_width,
+                                                                  tile_height, packed=False, n_cameras=C)
+        isect_offsets = ops.isect_offset_encode(isect_ids, C, tile_width, tile_height)
+        render_colors, render_alphas, n_touched = ops.rasterize_to_pixels(
+            means2d, conics, cols.contiguous(), opac.contiguous(), width, height, tile_size, isect_offsets, flatten_ids,
+            backgrounds=backgrounds, packed=False, absgrad=absgrad, visibility_min_T=visibility_min_T)
+    else:
+        if tile_size != 16:
+            raise NotImplementedError("tile_size must be 16")
+        dev = means.device
+        with torch.no_grad():
+            tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
+            from ._lib import check, lib, ptr, stream_ptr
+            check(lib.gsx_isect_count(ptr(means2d.detach()), ptr(radii), C * N, tile_width, tile_height,
+                                      ptr(tiles_per_gauss), stream_ptr(dev)), "gsx_isect_count")
+            if capacity.capacity == 0:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("render this shape once eagerly before capturing (intersection capacity probe)")
+                capacity.ensure(int(tiles_per_gauss.sum().item()))
+            cap = capacity.capacity
+            flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
+            off1, n_isects, _ = ops.isect_bin_sort(means2d.detach(), radii, depths.detach(), tile_width, tile_height, cap,
+                                                   None, flatten_ids, status=capacity.status)
+            capacity.M_dev = n_isects
+        isect_ids = None
+        isect_offsets = off1[:-1].view(C, tile_height, tile_width)
+        render_colors, render_alphas, n_touched = ops.rasterize_to_pixels(
+            means2d, conics, cols.contiguous(), opac.contiguous(), width, height, tile_size, off1, flatten_ids,
+            backgrounds=backgrounds, packed=False, absgrad=absgrad, visibility_min_T=visibility_min_T,
+            offsets_have_end=True)
     if render_mode in ("ED", "RGB+ED"):
         render_colors = torch.cat([render_colors[..., :-1],
                                    render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
@@ -70,6 +108,6 @@ def rasterization(
         "conics": conics, "opacities": opac, "tile_width": tile_width, "tile_height": tile_height,
         "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids, "flatten_ids": flatten_ids,
         "isect_offsets": isect_offsets, "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
-        "n_touched": n_touched,
+        "n_touched": n_touched, "n_isects": n_isects,
     }
     return render_colors, render_alphas, meta

@@ -47,8 +47,16 @@ def make_intrinsics(width: int = 640, height: int = 480, dtype=torch.float32) ->
     return torch.tensor(((f, 0.0, (width - 1) / 2.0), (0.0, f, (height - 1) / 2.0), (0.0, 0.0, 1.0)), dtype=dtype)
 
 
-def make_viewmat(c: int, dtype=torch.float32, noise: torch.Tensor | None = None) -> torch.Tensor:
-    """world->camera pose of synthetic frame ``c``: 0.05*c m along x and 1 deg * c of yaw."""
+def sequence_param(i: int, period: int = 120) -> float:
+    """pose parameter of frame ``i`` of the synthetic TUM-shape SEQUENCE: a sweep back and forth over the pose range of an
+    8-keyframe window, c(i) = 4 + 4 sin(2 pi i / period) - at most ~1 cm and ~0.2 degrees between consecutive frames (hand-held
+    motion at 30 Hz) and, unlike c = i, the camera keeps looking at the scene however long the sequence is"""
+    return 4.0 + 4.0 * math.sin(2.0 * math.pi * i / period)
+
+
+def make_viewmat(c: float, dtype=torch.float32, noise: torch.Tensor | None = None) -> torch.Tensor:
+    """world->camera pose with parameter ``c``: 0.05*c m along x and 1 deg * c of yaw (c = 0..7 are the
+    keyframes of a BA window)."""
     yaw = math.radians(1.0) * c
     cy, sy = math.cos(yaw), math.sin(yaw)
     R = torch.tensor(((cy, 0.0, -sy), (0.0, 1.0, 0.0), (sy, 0.0, cy)), dtype=torch.float64)

@@ -50,6 +50,11 @@ extern "C" {
                                      consumer (gsx_track_opt_tail) and skip the finishing launch; v_viewmats is ignored */
 #define GSX_PROJ_SKIP_CULLED 16   /* gsx_front_fwd only: rows of culled (camera, Gaussian) pairs get radii = 0 and
                                      tiles_per_gauss = 0 and nothing else (nobody reads them in a pose-only closure) */
+#define GSX_PROJ_COMPACT 32       /* gsx_front_fwd / gsx_front_pose_bwd: rec and v_rec hold one row per visible INSTANCE, indexed
+                                     by its slot ((c * R + row) * slots_per_segment + position, gsx_front_layout) instead of one
+                                     row per flatten id, and flatten_ids carries slots.  Slots are assigned in flatten-id order,
+                                     so (depth, slot) sorts exactly like (depth, flatten id); record s of the front's workspace
+                                     holds the flatten id of slot s.  radii / tiles_per_gauss become nullable. */
 #define GSX_PROJ_BETAS 4          /* gslam record: append beta=clamp(exp(log_unc),0.01) (rasterization.py:149,249-256) */
 
 int gsx_version(void);
@@ -144,6 +149,9 @@ int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, const float *
  * flatten_ids [M_cap], tile_order (nullable).  means2d / depths / conics are nullable (the rasteriser reads the record).
  * v_rec_clear nullable.  Limits: C <= 255, C * tile_w * tile_h * 4 + 64 bytes of LDS <= 64 KiB. */
 int64_t gsx_front_workspace_bytes(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap);
+/* out4 = {rows R, slots per (camera, row) segment, byte offset of the 16-byte instance records in the workspace, byte offset
+ * of the int32 instance counts [C][R]}; a record = {x0 | x1 << 16, y0 | y1 << 12 | c << 24, depth bits, flatten id} */
+int gsx_front_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int64_t *out4);
 int gsx_front_fwd(const float *means, const float *quats, const float *scales, const float *viewmats, const float *Ks,
                   int64_t N, int64_t C, int W, int H, float eps2d, float near_plane, float far_plane, int flags,
                   const float *logit_opacities, const float *logit_colors, const float *log_uncertainties,

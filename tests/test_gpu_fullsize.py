@@ -227,3 +227,32 @@ def test_sh3_1080p_5m(dev):
     c0b, _, _ = rasterization(sc["means"], sc["quats"], torch.exp(sc["scales"]), torch.sigmoid(sc["opacities"]), flat_col,
                               viewmats.to(dev), Ks.to(dev), W, H, packed=False)
     assert float((c0 - c0b).abs().max()) < 1e-5
+
+
+def test_gsplat_entry_point_sync_free_equals_default(dev):
+    """gsplat.rendering.rasterization-shaped entry point (pipeline.py:106-116) with a caller-owned IsectCapacity: no read-back
+    of the intersection count, same render and gradients as the default (exact-size) path, SH degree 3"""
+    from gslam_amd.rasterization import IsectCapacity
+    from gslam_amd.rendering import rasterization
+    from gslam_amd.synthetic import make_cameras, make_scene
+    n, W, H = 200_000, 640, 480
+    sc = {k: v.to(dev) for k, v in make_scene(n, 2, sh_degree=3).items()}
+    viewmats, Ks = make_cameras(2, W, H)
+    viewmats, Ks = viewmats.to(dev), Ks.to(dev)
+    cap = IsectCapacity(dev)
+    res = []
+    for capacity in (None, cap, cap):
+        coeffs = sc["sh_coeffs"].clone().requires_grad_(True)
+        means = sc["means"].clone().requires_grad_(True)
+        colors, alphas, meta = rasterization(means, sc["quats"], torch.exp(sc["scales"]), torch.sigmoid(sc["opacities"]),
+                                             coeffs, viewmats, Ks, W, H, sh_degree=3, packed=False, capacity=capacity)
+        (colors.sum() + alphas.sum()).backward()
+        res.append((colors.detach(), alphas.detach(), coeffs.grad, means.grad, meta))
+    assert cap.validate() and cap.last_M == int(res[0][4]["flatten_ids"].shape[0])
+    assert res[1][4]["isect_ids"] is None and int(res[1][4]["n_isects"]) == cap.last_M
+    for a, b in zip(res[0][:2], res[1][:2]):
+        assert torch.equal(a, b)
+    for k in (2, 3):
+        scale = float(res[0][k].abs().max())
+        assert float((res[0][k] - res[1][k]).abs().max()) < 2e-3 * scale           # float atomics in the backward
+    assert torch.equal(res[1][0], res[2][0])

@@ -12,7 +12,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gslam_amd.rasterization import rasterization, validate  # noqa: E402
+from gslam_amd.rasterization import IsectCapacity, rasterization  # noqa: E402
 from gslam_amd.rendering import rasterization as gs_rasterization  # noqa: E402
 from gslam_amd.synthetic import make_cameras, make_scene  # noqa: E402
 
@@ -58,6 +58,7 @@ def run(name, N, C, W, H, sh=False):
     viewmats, Ks = viewmats.to(dev), Ks.to(dev)
     bg = torch.zeros(C, 3, device=dev)
     state = {}
+    cap = IsectCapacity(dev)        # sync-free renders: no read-back of M inside a step (both entry points)
     # fresh leaves per timing mode: autograd pins a leaf's AccumulateGrad node to the stream of its first backward, and
     # the graph is captured on a side stream
     p = {k: v.to(dev).requires_grad_(v.is_floating_point()) for k, v in sc.items()}
@@ -68,33 +69,28 @@ def run(name, N, C, W, H, sh=False):
         if sh:
             render, alphas, info = gs_rasterization(p["means"], p["quats"], torch.exp(p["scales"]),
                                                     torch.sigmoid(p["opacities"]), p["sh_coeffs"], viewmats, Ks, W, H,
-                                                    sh_degree=3, packed=False, backgrounds=bg)
+                                                    sh_degree=3, packed=False, backgrounds=bg, capacity=cap)
             (render.sum() + alphas.sum()).backward()
-            state["M"] = int(info["flatten_ids"].shape[0])
         else:
             out = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], viewmats, Ks, W, H,
                                 packed=False, render_mode="RGB+D", log_uncertainties=p["log_uncertainties"],
-                                backgrounds=bg)
+                                backgrounds=bg, capacity=cap)
             (out._render.sum() + out.alphas.sum()).backward()
-            state["out"] = out
 
     step()
-    validate(dev)
+    assert cap.validate()
     step()
-    if not sh:
-        state["M"] = int(state["out"].flatten_ids.shape[0])
+    assert cap.validate()
+    state["M"] = cap.last_M
     ms = timed(step, 6 if N >= 2_000_000 else 10)
     try:
-        if sh:      # the gsplat-signature entry point (rendering.py) reads the intersection count back: not capturable
-            raise RuntimeError("eager only")
         for k in list(p):
             p[k] = p[k].detach().clone().requires_grad_(p[k].is_floating_point())
         torch.cuda.synchronize()
         gms = timed(graphed(step), 6 if N >= 2_000_000 else 20)
-        assert validate(dev), "tile lists overflowed under replay"
+        assert cap.validate(), "tile lists overflowed under replay"
     except Exception as e:  # noqa: BLE001 - report the eager number alone
-        if not sh:
-            print(f"graph replay unavailable for {name}: {e!r}", file=sys.stderr)
+        print(f"graph replay unavailable for {name}: {e!r}", file=sys.stderr)
         gms = None
     best = min(ms, gms) if gms else ms
     M, P, CH = state["M"], C * W * H, 3 if sh else 5

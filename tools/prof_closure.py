@@ -31,7 +31,8 @@ def main():
     N, W, H = args.gaussians, 640, 480
     gt_scene = GaussianSplattingData.from_dict(make_scene(N, 1), dev)
     m = GaussianSplattingData.from_dict(make_scene(N, 0), dev)
-    frames, cam = bench.make_frames(range(8 + max(args.frames, 1)), W, H, dev, gt_scene)
+    from gslam_amd.synthetic import sequence_param
+    frames, cam = bench.make_frames(list(range(8)) + [sequence_param(i) for i in range(max(args.frames, 1))], W, H, dev, gt_scene)
     del gt_scene
     fm = m.no_grad_clone()
     conf = TrackingConfig()
