@@ -87,6 +87,7 @@ class StageTimer:
 
     def __init__(self):
         self.events = {s: [] for s in self.STAGES}
+        self.last_args = {}
 
     def __enter__(self):
         from gslam_amd import _lib
@@ -102,6 +103,7 @@ class StageTimer:
                 rc = _o(*a)
                 e1.record()
                 self.events[_s].append((e0, e1))
+                self.last_args[_s] = a
                 return rc
 
             setattr(self._lib, s, wrapped)
@@ -111,6 +113,20 @@ class StageTimer:
         for s, o in self._orig.items():
             setattr(self._lib, s, o)
         torch.cuda.synchronize()
+
+    def back_to_back_us(self, stage, reps=40):
+        """the stage's last launch repeated ``reps`` times between ONE pair of events: the launch duration without the host
+        gaps an eager event pair around a single launch includes (what rocprofv3's kernel trace reports as its average)"""
+        fn, a = self._orig[stage], self.last_args[stage]
+        for _ in range(5):
+            fn(*a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn(*a)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
 
     def mean_us(self, skip=0):
         out = {}
@@ -312,11 +328,13 @@ def run_headline(args, dev):
                 c.enqueue(st)
         stages = timer.mean_us(skip=8)
         algo = algorithmic_bytes(N, 1, M1, P, 4, T)
-        dom = max((s for s in stages if s in algo), key=lambda s: stages[s])
-        achieved = algo[dom] / (stages[dom] * 1e-6) / 1e9
+        dom = max((s for s in stages if s in algo and s != "gsx_front_fwd"), key=lambda s: stages[s])
+        dom_us = timer.back_to_back_us(dom)                  # HIP events on the launch stream, launches back to back
+        achieved = algo[dom] / (dom_us * 1e-6) / 1e9
         line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for(dom, N),
-                            "algorithmic_bytes": int(algo[dom]), "avg_launch_us": round(stages[dom], 2), "n_isects": M1,
+                            "algorithmic_bytes": int(algo[dom]), "avg_launch_us": round(dom_us, 2), "n_isects": M1,
+                            "avg_launch_us_in_closure": round(stages[dom], 2),
                             "whole_closure_frac": line["closure"]["frac_of_hbm_peak"]}
         line["stage_us"] = {k: round(v, 2) for k, v in stages.items()}
         tracker.capacity_ok()
