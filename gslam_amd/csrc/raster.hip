@@ -112,16 +112,10 @@ __device__ __forceinline__ bool may_touch(float mx, float my, float a, float b, 
     return !(smin > tau * 1.001f + 1e-3f);
 }
 
-// XCD-aware launch order (when the caller gives no order of its own): workgroups are dealt round-robin over the 8 XCDs
-// (observed; speed only), each with its own L2, and neighbouring tiles gather mostly the same splat records (a Gaussian
-// covers ~7 adjacent tiles).  Workgroup b renders tile chunk(b % 8) + b / 8, so the workgroups that share an XCD - and its
-// L2 - walk one contiguous band of tile rows instead of every eighth tile.  Bijective for any tile count.
-__device__ __forceinline__ int xcd_tile_index() {
-    const int total = (int)gridDim.x, b = (int)blockIdx.x;
-    const int xcd = b & 7, k = b >> 3, q = total >> 3, r = total & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
+// Launch order: workgroup b renders tile b (or tile_order[b]).  An XCD-band order (the workgroups that share an XCD - and
+// its L2 - walk one contiguous band of tile rows, as ssim.hip does) was measured and dropped: the per-tile work is not
+// uniform, a band through the image centre is heavier than one along its border, and the imbalance between XCDs cost 6 %
+// in the headline loop (73.7 -> 78.1 us backward, 33.5 -> 35.6 forward) for a traffic the kernel is not bound by.
 struct Quad {
     int tile, c, px, py, wave, lane;
     bool inside;
@@ -131,7 +125,7 @@ struct Quad {
 __device__ __forceinline__ Quad make_quad(int tile_w, int tile_h, int W, int H, int tile = -1) {
     Quad q;
     const int tiles_per_cam = tile_w * tile_h;
-    q.tile = tile >= 0 ? tile : xcd_tile_index();
+    q.tile = tile >= 0 ? tile : (int)blockIdx.x;
     q.c = q.tile / tiles_per_cam;
     const int tl = q.tile - q.c * tiles_per_cam;
     const int ty = tl / tile_w, tx = tl - ty * tile_w;
@@ -163,7 +157,7 @@ struct Half {
 __device__ __forceinline__ Half make_half(int tile_w, int tile_h, int W, int H, int tile = -1) {
     Half q;
     const int tiles_per_cam = tile_w * tile_h;
-    q.tile = tile >= 0 ? tile : xcd_tile_index();
+    q.tile = tile >= 0 ? tile : (int)blockIdx.x;
     q.c = q.tile / tiles_per_cam;
     const int tl = q.tile - q.c * tiles_per_cam;
     const int ty = tl / tile_w, tx = tl - ty * tile_w;
