@@ -114,11 +114,13 @@ class StageTimer:
             setattr(self._lib, s, o)
         torch.cuda.synchronize()
 
-    def back_to_back_us(self, stage, reps=40):
-        """the stage's last launch repeated ``reps`` times between ONE pair of events: the launch duration without the host
-        gaps an eager event pair around a single launch includes (what rocprofv3's kernel trace reports as its average)"""
+    def back_to_back_us(self, stage, reps=200, warm=600):
+        """the stage's last launch repeated ``reps`` times between ONE pair of events, after ``warm`` untimed repetitions:
+        the launch duration without the host gaps an eager event pair around a single launch includes, and with the GPU
+        at the clocks of a busy queue (the eager instrumented pass is host-bound: the chip idles between launches, clocks
+        down and the same kernel reads ~25 % longer) - what rocprofv3's kernel trace of the bench reports as its average"""
         fn, a = self._orig[stage], self.last_args[stage]
-        for _ in range(5):
+        for _ in range(warm):
             fn(*a)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

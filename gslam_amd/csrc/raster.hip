@@ -347,6 +347,25 @@ extern "C" int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds
     return GSX_OK;
 }
 
+extern "C" int gsx_raster_fwd_track_loss(const float *rec, const float *backgrounds, const int32_t *offsets,
+                                         const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W,
+                                         int H, const float *gt, const float *exposure, float w_photo, float *render,
+                                         float *alphas, int32_t *last_ids, float *v_render, float *loss_rows,
+                                         const int32_t *tile_order, void *stream) {
+    GSX_CHECK_ARG(offsets && alphas && last_ids && gt && exposure && v_render && loss_rows && C >= 1 && W > 0 && H > 0);
+    GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31) && (M == 0 || (rec && flatten_ids)));
+    const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
+    const int64_t T = C * tile_w * tile_h;
+    GSX_CHECK_ARG(T < ((int64_t)1 << 31));
+    TrackLossArgs la;
+    la.gt = gt; la.exposure = exposure; la.w_photo = w_photo; la.v_render = v_render; la.rows = loss_rows;
+    hipLaunchKernelGGL((raster_fwd_kernel4q<4, 12, false, true>), dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, rec,
+                       backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, 0.5f, render, alphas,
+                       last_ids, (int32_t *)nullptr, tile_order, la);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
 extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
                               const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
                               int tile_w, int tile_h, const float *alphas, const int32_t *last_ids,

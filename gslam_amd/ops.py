@@ -158,7 +158,9 @@ class _Projection(torch.autograd.Function):
         ws_bytes = lib.gsx_project_bwd_workspace_bytes(N, Cn)
         if link is not None:        # the partials outlive this call: their own buffer, not the shared workspace
             ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
-            link.partials = (ws, int(lib.gsx_project_bwd_blocks(N)))
+            # tagged with the id of this backward pass: a pose backward of ANOTHER pass must not pick them up (a pass that
+            # never reaches the pose nodes - autograd.grad with restricted inputs - would otherwise leave them behind)
+            link.partials = (ws, int(lib.gsx_project_bwd_blocks(N)), torch._C._current_graph_task_id())
         else:
             ws = workspace(ws_bytes, dev, "proj_bwd")
         check(lib.gsx_project_bwd(ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), N, Cn, width, height,

@@ -305,7 +305,10 @@ class RenderPlan:
                                 _p(self.M_dev), _p(self.status), _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
                                 self.isect_ws.numel(), st), "gsx_front_fwd")
 
-    def forward(self, st: int):
+    def forward(self, st: int, track_loss=None):
+        """track_loss = (gt [C,H,W,3], exposure [C,2], w_photo, loss_rows [T,6]): the forward rasteriser evaluates the
+        active-nerf tracking loss in its epilogue (CH = 4 plans): self.v_render and the loss rows come out of the same
+        launch, the render itself is not written"""
         if self.capacity == 0:
             raise RuntimeError("RenderPlan.probe() first (tile-list capacity)")
         if self.front:
@@ -316,6 +319,15 @@ class RenderPlan:
                                          self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status),
                                          None, _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
                                          self.isect_ws.numel(), st), "gsx_isect_bin_sort")
+        if track_loss is not None:
+            gt, exposure, w_photo, rows = track_loss
+            assert self.CH == 4 and self.n_touched is None
+            check(lib.gsx_raster_fwd_track_loss(_p(self.rec), _p(self.backgrounds), _p(self.offsets), _p(self.flat),
+                                                self.capacity, 1, self.C, self.W, self.H, _p(gt), _p(exposure),
+                                                float(w_photo), None, _p(self.alphas), _p(self.last_ids),
+                                                _p(self.v_render), _p(rows), _p(self.tile_order), st),
+                  "gsx_raster_fwd_track_loss")
+            return
         if self.n_touched is not None:
             check(lib.gsx_zero_words(_p(self.n_touched), self.n_touched.numel(), st), "gsx_zero_words")
         check(lib.gsx_raster_fwd(_p(self.rec), self.CH, _p(self.backgrounds), _p(self.offsets), _p(self.flat),
@@ -437,6 +449,8 @@ class TrackClosure:
         self.map_ws = torch.empty(int(lib.gsx_map_loss_workspace_bytes(1, self.r.H, self.r.W)), dtype=torch.uint8,
                                   device=dev)
         self.n_rows = (self.r.H * self.r.W + 255) // 256
+        # fused tail: the loss is evaluated in the forward rasteriser's epilogue, one row of partials per tile
+        self.loss_rows = torch.zeros(self.r.T, 6, device=dev)
         self.stream = torch.cuda.Stream(device=dev)
         self.graph = HipGraph()
 
@@ -465,16 +479,18 @@ class TrackClosure:
 
     def enqueue(self, st: int):
         r = self.r
-        if self.tail != 'fused':
-            self.slots.forward(r.viewmats, st)
+        if self.tail == 'fused':
+            denom = r.C * r.H * r.W
+            r.forward(st, track_loss=(self.img, self.exposure, 1.0 / denom, self.loss_rows))
+            r.backward(st)
+            check(lib.gsx_track_opt_tail(_p(self.state), _p(r.pose_ws), r.pose_blocks, _p(self.slots.Rt), _p(self.slots.dt),
+                                         _p(self.slots.dR), _p(self.exposure), None, None, _p(r.viewmats),
+                                         _p(self.loss_rows), r.T, 1.0 / denom, st), "gsx_track_opt_tail")
+            return
+        self.slots.forward(r.viewmats, st)
         r.forward(st)
         denom = _photometric_loss(r, self.img, self.exposure, 2, 1.0, self.map_ws, st, use_alphas=False)
         r.backward(st)
-        if self.tail == 'fused':
-            check(lib.gsx_track_opt_tail(_p(self.state), _p(r.pose_ws), r.pose_blocks, _p(self.slots.Rt), _p(self.slots.dt),
-                                         _p(self.slots.dR), _p(self.exposure), None, None, _p(r.viewmats), _p(self.map_ws),
-                                         self.n_rows, 1.0 / denom, st), "gsx_track_opt_tail")
-            return
         self.slots.backward_partials(r, st)
         pm = 1.0 / denom
         c0 = (C.c_float * 5)(pm, pm, 0.0, 0.0, 0.0)

@@ -84,6 +84,8 @@ class _PoseBatch(torch.autograd.Function):
         Rts, dRs, dts = tensors[0::3], tensors[1::3], tensors[2::3]
         link = ctx.link
         partials, link.partials = link.partials, None
+        if partials is not None and partials[2] != torch._C._current_graph_task_id():
+            partials = None                               # left behind by an earlier backward pass: stale
         if v_view is None and partials is None:
             return (None, None) + (None,) * len(tensors)
         dev = Rts[0].device
@@ -93,7 +95,7 @@ class _PoseBatch(torch.autograd.Function):
         if partials is not None:
             # the projection backward left its per-workgroup pose partials (ops._Projection.backward): summed and
             # pushed through the pose algebra in one launch; v_view holds what reached the view matrices otherwise
-            buf, n_blocks = partials
+            buf, n_blocks = partials[0], partials[1]
             extra = None if v_view is None else v_view.contiguous()
             check(lib.gsx_pose_zhou_bwd_partials(n, arr(Rts), arr(dRs), arr(dts), (C.c_int * n)(*learnable),
                                                  buf.data_ptr(), n_blocks, None if extra is None else extra.data_ptr(),

@@ -184,6 +184,17 @@ int gsx_raster_fwd(const float *rec, int CH, const float *backgrounds /*[C,CH] n
                    float visibility_min_T, float *render, float *alphas, int32_t *last_ids, int32_t *n_touched,
                    const int32_t *tile_order /*[T] nullable: workgroup i renders tile tile_order[i] (gsx_isect_bin_sort)*/,
                    void *stream);
+/* K8 for the tracking closure (gslam/frontend.py:621-649): RGB + beta records (CH = 4), and in the same launch the
+ * active-nerf tracking loss with the exposure affine (frontend.py:113-138,632-636; mode 2 of gsx_map_loss with
+ * w_photo = weight / (C*H*W)): v_render [C,H,W,4] = d loss / d render, loss_rows [T][6] = one row of partial sums per tile
+ * in the layout gsx_track_opt_tail / gsx_loss_finish read ([0] = sum of S / beta^2, [3], [4] = exposure gradient).
+ * render is nullable (the closure never reads it); alphas and last_ids are what gsx_raster_bwd needs. */
+int gsx_raster_fwd_track_loss(const float *rec, const float *backgrounds, const int32_t *offsets,
+                              const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
+                              const float *gt, const float *exposure, float w_photo, float *render, float *alphas,
+                              int32_t *last_ids, float *v_render, float *loss_rows, const int32_t *tile_order,
+                              void *stream);
+
 /* ---- K9: rasterize_to_pixels bwd.  v_rec [C*N, stride] must be zeroed by the caller; gradients are accumulated
  * in record layout: v_xy(2) v_conic(3) v_opacity(1) v_colors(CH).  v_abs (nullable, [C*N,2], zeroed): absgrad.
  * v_alphas nullable (= zero gradient).                                                                              */

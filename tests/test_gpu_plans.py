@@ -96,6 +96,20 @@ def test_track_closure_matches_autograd_operators(dev):
     assert abs(float(c.loss) - float(loss)) < 1e-6 * abs(float(loss))
     for a, b in ((c.g_dR, pose.dR.grad), (c.g_dt, pose.dt.grad), (c.g_exposure, ex.grad)):
         assert (a - b).abs().max() < 2e-4 * b.abs().max() + 1e-9, (a, b)
+    # the fused variant evaluates the same loss in the forward rasteriser's epilogue (gsx_raster_fwd_track_loss): same
+    # gradient of the render, same loss and exposure gradient from its per-tile rows
+    c2 = TrackClosure(mf, cam, tail='fused')
+    c2.load(f.pose.Rt, f.img, exposure)
+    c2.r.viewmats.copy_(c.r.viewmats)
+    c2.r.probe()
+    denom = c2.r.H * c2.r.W
+    c2.r.forward(current_stream_ptr(dev), track_loss=(c2.img, c2.exposure, 1.0 / denom, c2.loss_rows))
+    torch.cuda.synchronize()
+    assert torch.equal(c2.r.alphas, c.r.alphas) and torch.equal(c2.r.last_ids, c.r.last_ids)
+    assert (c2.r.v_render - c.r.v_render).abs().max() <= 1e-6 * c.r.v_render.abs().max()
+    rows = c2.loss_rows.double().sum(0)
+    assert abs(float(rows[0]) / denom - float(loss)) < 1e-5 * abs(float(loss))
+    assert (rows[3:5].float() - c.g_exposure).abs().max() < 1e-4 * c.g_exposure.abs().max() + 1e-9
     # captured and replayed: same numbers, idempotent
     c.prepare()
     vals = []
