@@ -264,6 +264,27 @@ class Backend:
         """backend.py:447-506.  On the GPU the L-BFGS state machine runs on the device (mapping.GraphedPoseRefiner, one
         captured closure per window composition); the host version remains for CPU tensors and oversized windows."""
         window = self.optimization_window()
+        loss = self._refine_window_poses(window)
+        self._hand_back_poses(window)
+        return loss
+
+    def _hand_back_poses(self, window):
+        """Multi-GPU: the refinement above runs replicated (every rank renders the whole window), and its backward pass sums
+        with floating-point atomics whose order differs from run to run - the replicas' poses could drift apart in the last
+        bits.  Rank 0's result is handed to all of them: one broadcast of 25 floats per window pose."""
+        shard = None if self.ba is None else self.ba.shard
+        if shard is None or shard.world_size == 1 or not window:
+            return
+        with torch.no_grad():
+            buf = torch.stack([torch.cat([f.pose.Rt.reshape(-1), f.pose.dR.reshape(-1), f.pose.dt.reshape(-1)])
+                               for f in window]).contiguous()
+            shard.broadcast_([buf], src=0)
+            for f, row in zip(window, buf):
+                f.pose.Rt.copy_(row[:16].view_as(f.pose.Rt))
+                f.pose.dR.copy_(row[16:22].view_as(f.pose.dR))
+                f.pose.dt.copy_(row[22:25].view_as(f.pose.dt))
+
+    def _refine_window_poses(self, window):
         learn = [x for x in window if x.index != 0]
         if (not self.splats.means.is_cuda or not learn or 9 * len(learn) > 80
                 or not getattr(self.conf, "device_pose_refiner", True)):

@@ -119,3 +119,93 @@ def test_two_rank_ba_step_equals_one_rank(n_kf):
             assert v < 2e-5, (rank, k, v)
         assert d_posepar < 2e-3 and moved > 0, (rank, d_posepar, moved)
         assert same_poses and same_map                        # replicas stay bit-identical: no pose broadcast needed
+
+
+def _backend_worker(rank, world, port, q):
+    """one Backend replica per rank through the reference's message loop (REQUEST_INIT, ADD_FRAME -> keyframes, BA with a
+    densification every 7th iteration, pruning, window pose refinement): everything that must stay identical between the
+    replicas is gathered at the end"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import queue
+
+    import torch.distributed as td
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from gslam_amd import dist as gdist
+    from gslam_amd.backend import Backend, MapConfig
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.messages import FrontendMessage
+    from gslam_amd.primitives import Camera, Frame, PoseZhou
+    from gslam_amd.synthetic import make_intrinsics, make_scene, make_viewmat
+    assert gdist.init_from_env(backend="gloo") == (rank, world)
+    W, H = 320, 240
+    cam = Camera(make_intrinsics(W, H).to(dev), H, W)
+    sc = make_scene(30000, 3)
+    sc["scales"] = sc["scales"] + 0.6
+    scene = GaussianSplattingData.from_dict(sc, dev)
+
+    def sensor_frame(i):
+        V = make_viewmat(2.0 * i).to(dev)
+        with torch.no_grad():
+            img = scene([cam], [PoseZhou(V, is_learnable=False).to(dev)], render_depth=False).rgbs[0].clamp(0, 1)
+        # the tracked pose the frontend would ship: the true one, off by a millimetre
+        Vt = V.clone()
+        Vt[:3, 3] += 1e-3
+        return Frame(img=img.contiguous(), timestamp=i / 30.0, camera=cam, pose=PoseZhou(Vt).to(dev), gt_pose=V, index=i,
+                     exposure_params=torch.zeros(2, device=dev))
+
+    conf = MapConfig(num_iters_initialization=20, num_iters_mapping=5, kf_m=0.02, densify_every=7, seed=5)
+    be = Backend(conf, queue.Queue(), queue.Queue())
+    assert be.handle((FrontendMessage.REQUEST_INIT, sensor_frame(0)))
+    assert be.ba.shard.world_size == world
+    n_hist = [be.splats.means.shape[0]]
+    for i in range(1, 6):
+        assert be.handle((FrontendMessage.ADD_FRAME, sensor_frame(i)))
+        be.idle_step()
+        n_hist.append(be.splats.means.shape[0])
+    torch.cuda.synchronize()
+
+    def same(t):
+        t = t.detach().contiguous().cpu()
+        both = [torch.zeros_like(t) for _ in range(world)]
+        td.all_gather(both, t)
+        return all(torch.equal(both[0], b) for b in both[1:])
+
+    sizes = torch.tensor(n_hist + [len(be.keyframes), be.total_step])
+    ok_sizes = same(sizes)                                    # before any tensor gather: shapes must agree first
+    res = dict(sizes=ok_sizes, n=n_hist, n_kf=len(be.keyframes), steps=be.total_step)
+    if ok_sizes:
+        for k in ("means", "quats", "scales", "opacities", "colors", "log_uncertainties", "ages"):
+            res[k] = same(getattr(be.splats, k))
+        res["adam"] = same(be.ba.optimizers.splat_opt.state[be.splats.means]["exp_avg"])
+        res["poses"] = same(torch.stack([f.pose().detach() for f in be.keyframes.values()]))
+        res["depths"] = same(torch.stack([f.est_depths for f in be.keyframes.values() if f.est_depths is not None
+                                          and f.est_depths.dim() == 2][:2]))
+        res["finite"] = bool(torch.isfinite(be.splats.means).all())
+    q.put((rank, res))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_two_backend_replicas_keep_identical_maps():
+    """keyframe-sharded mapping inside the whole backend loop - depth-map insertion and densification draw the
+    same random numbers, the pruning statistics are reduced over ranks, the refined window poses are handed back from rank
+    0 - so two replicas fed the same frames hold bit-identical maps, Adam state and keyframe poses afterwards."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_backend_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, r in res:
+        assert r["sizes"], (rank, r)
+        assert r["n_kf"] >= 3 and r["steps"] >= 40, (rank, r)
+        assert len(set(r["n"])) > 2, (rank, r)                # the map grew / shrank along the way
+        for k, v in r.items():
+            if isinstance(v, bool):
+                assert v, (rank, k, r)
