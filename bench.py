@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads of the 1-GPU line")
     ap.add_argument("--ba-only", action="store_true", help="1 GPU: run the G > 1 workload (configs[3]) on one GPU")
+    ap.add_argument("--diag", default="", help="DIAGNOSTIC runs of the headline with work left out (comma list of "
+                    "'no-ba', 'no-out'): the line is marked invalid, it only tells where the frame time goes")
     return ap.parse_args()
 
 
@@ -80,7 +82,7 @@ class StageTimer:
     """Times every C-ABI launch with HIP events on the stream the kernels are launched on (torch's current stream: the
     instrumented passes issue their plans' launches there)."""
     STAGES = ("gsx_pose_zhou_fwd", "gsx_project_fwd", "gsx_isect_bin_sort", "gsx_front_fwd", "gsx_front_pose_bwd",
-              "gsx_raster_fwd", "gsx_ssim_fwd",
+              "gsx_raster_fwd", "gsx_raster_fwd_track_loss", "gsx_ssim_fwd",
               "gsx_ssim_bwd", "gsx_map_loss", "gsx_raster_bwd", "gsx_project_bwd", "gsx_pose_zhou_bwd_partials",
               "gsx_isotropic_loss_acc", "gsx_loss_finish", "gsx_counters_add", "gsx_adam_multi_steps",
               "gsx_adam_multi_steps_decay", "gsx_track_opt_tail")
@@ -148,6 +150,8 @@ def algorithmic_bytes(N, C, M, P, CH, T):
         "gsx_front_pose_bwd": C * N * (40 + 28 + 24) + N * 40 + C * 64,
         "gsx_map_loss": P * (4 * CH + 4 + 12 + 4 * CH),
         "gsx_raster_fwd": M * (28 + 4 * CH) + P * (4 * CH + 8) + C * N * 4,
+        # forward + tracking loss in its epilogue: reads the frame (12 B/px), writes v_render instead of the render
+        "gsx_raster_fwd_track_loss": M * (28 + 4 * CH) + P * (4 * CH + 8 + 12) + C * N * 4,
         "gsx_raster_bwd": P * (4 * CH + 12) + M * (28 + 4 * CH) + C * N * (24 + 4 * CH),
         "gsx_project_bwd": C * N * (40 + 28 + 24) + N * 40 + C * 64,
         "gsx_ssim_fwd": 72 * P,
@@ -222,7 +226,13 @@ def run_headline(args, dev):
     out_graph.capture(out_stream, out_render.forward)
     torch.cuda.synchronize()
 
-    map_stream, track_stream = torch.cuda.Stream(), torch.cuda.Stream()
+    diag = set(x for x in args.diag.split(",") if x)
+    if "prio" in diag:
+        lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        print("priority range", lo, hi, file=sys.stderr)
+        map_stream, track_stream = torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)
+    else:
+        map_stream, track_stream = torch.cuda.Stream(), torch.cuda.Stream()
     closures_per_frame = N_ADAM + MAX_EVAL + 1
 
     def run(first, count):
@@ -241,9 +251,10 @@ def run_headline(args, dev):
                 pending = None
                 n_sync += 1
             tracker.track(f, sync=False)                             # 36 graph launches + report, no read-back
-            out_render.viewmats.copy_(tracker.plan.r.viewmats)       # the tracked pose (left there by the closure's tail)
-            out_graph.launch()
-            if (i + 1) % KF_EVERY == 0:
+            if "no-out" not in diag:
+                out_render.viewmats.copy_(tracker.plan.r.viewmats)   # the tracked pose (left there by the closure's tail)
+                out_graph.launch()
+            if (i + 1) % KF_EVERY == 0 and "no-ba" not in diag:
                 # the backend's map is its own copy; its BA round only waits for the previous one and overlaps the
                 # tracking of the following frames
                 with torch.cuda.stream(map_stream):
@@ -292,6 +303,8 @@ def run_headline(args, dev):
         },
     }
 
+    if diag:
+        line["INVALID"] = "diagnostic run with work left out: " + ",".join(sorted(diag))
     # ---- tracking alone / mapping alone (serial, for the breakdown) ---------------------------------------------------------
     f = frames[WINDOW + 1]
     tracker.track(f, sync=False)

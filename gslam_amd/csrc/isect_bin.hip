@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "gsx_common.h"
+#include "tile_balance.h"
 
 namespace {
 
@@ -952,6 +953,7 @@ struct FrontArgs {
     int32_t *n_inst;     // [C][R]
     PreRec *recs;        // [C][R][1024 * items]
     int compact;         // rec / v_rec rows are indexed by instance slot ((c * R + row) * seg_cap + position), not flatten id
+    gsx_bal::Args bal;   // bal.order != nullptr: workgroup R of the launch computes the CU-balanced launch order instead
 };
 
 // Position of every flagged thread of the workgroup among the flagged ones, IN THREAD ORDER (a deterministic, monotone
@@ -996,7 +998,13 @@ __device__ __forceinline__ bool surely_culled(const float mean[3], float smax2, 
 
 template <int ITEMS>
 __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs a) {
-    extern __shared__ int s_front[];                        // [C * n_tiles] counts, [C] instance counters, survivors
+    extern __shared__ __attribute__((aligned(16))) int s_front[];   // [C * n_tiles] counts, [C] instance counters, survivors
+    if (blockIdx.x == (unsigned)a.R) {
+        // one extra workgroup: the launch order of this render's rasteriser kernels from the tile work of the previous one
+        // (tile_balance.h) - ~20 us of one CU hidden behind the projection instead of a launch of its own on the chain
+        gsx_bal::run(a.bal, reinterpret_cast<unsigned char *>(s_front));
+        return;
+    }
     const int n_tiles = a.tile_w * a.tile_h;
     const int C = a.C;
     int *s_cnt = s_front, *s_ninst = s_front + C * n_tiles;
@@ -1420,8 +1428,11 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
                              const float *log_uncertainties, int32_t *radii, float *means2d, float *depths, float *conics,
                              int32_t *tiles_per_gauss, float *rec, float *v_rec_clear, int32_t *vis_count, int64_t M_cap,
                              int32_t *offsets, int64_t *M_dev, int32_t *status, int32_t *flatten_ids, int32_t *tile_order,
-                             void *workspace, int64_t workspace_bytes, void *stream) {
+                             const int32_t *tile_work, int32_t *balanced_order, float chunk_cost, float light_rate,
+                             int n_cus, void *workspace, int64_t workspace_bytes, void *stream) {
     GSX_CHECK_ARG(N >= 1 && C >= 1 && C <= 255 && W > 0 && H > 0 && C * N < ((int64_t)1 << 31));
+    GSX_CHECK_ARG(!balanced_order || (tile_work && n_cus >= 1 && n_cus <= gsx_bal::MAX_BINS && chunk_cost >= 0.f &&
+                                      chunk_cost < 1e6f && light_rate > 0.f && light_rate <= 1.f));
     const int compact = (flags & GSX_PROJ_COMPACT) ? 1 : 0;
     GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && logit_opacities && logit_colors && rec);
     GSX_CHECK_ARG(compact || (radii && tiles_per_gauss));
@@ -1447,17 +1458,25 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
     a.conics = conics; a.rec = rec; a.v_rec = v_rec_clear;
     a.cnt = (int32_t *)(ws + L.matrix_off); a.n_inst = (int32_t *)(ws + L.ninst_off); a.recs = (PreRec *)(ws + L.recs_off);
     a.compact = compact;
-    const size_t front_lds = (size_t)((T + C + FRONT_THREADS / 64) * 4 + 2 * FRONT_THREADS * L.items);   // histogram + survivor list
+    size_t front_lds = (size_t)((T + C + FRONT_THREADS / 64) * 4 + 2 * FRONT_THREADS * L.items);   // histogram + survivor list
+    a.bal.order = nullptr;
+    if (balanced_order) {
+        GSX_CHECK_ARG(T <= gsx_bal::MAX_TILES);
+        a.bal.work = tile_work; a.bal.order = balanced_order; a.bal.T = (int)T; a.bal.G = n_cus;
+        a.bal.chunk_cost = chunk_cost; a.bal.light_rate = light_rate;
+        front_lds = front_lds > (size_t)gsx_bal::LDS_BYTES ? front_lds : (size_t)gsx_bal::LDS_BYTES;
+    }
+    const unsigned front_grid = (unsigned)L.R + (balanced_order ? 1u : 0u);
     if (front_lds > 65536 || L.items > 8) {
         gsx_set_error("gsx_front_fwd: %lld tiles over all cameras / %d Gaussians per thread do not fit the LDS plan",
                       (long long)T, L.items);
         return GSX_E_UNSUPPORTED;
     }
     switch (L.items) {
-        case 1: hipLaunchKernelGGL(front_project_kernel<1>, dim3((unsigned)L.R), dim3(FRONT_THREADS), front_lds, st, a); break;
-        case 2: hipLaunchKernelGGL(front_project_kernel<2>, dim3((unsigned)L.R), dim3(FRONT_THREADS), front_lds, st, a); break;
-        case 4: hipLaunchKernelGGL(front_project_kernel<4>, dim3((unsigned)L.R), dim3(FRONT_THREADS), front_lds, st, a); break;
-        case 8: hipLaunchKernelGGL(front_project_kernel<8>, dim3((unsigned)L.R), dim3(FRONT_THREADS), front_lds, st, a); break;
+        case 1: hipLaunchKernelGGL(front_project_kernel<1>, dim3(front_grid), dim3(FRONT_THREADS), front_lds, st, a); break;
+        case 2: hipLaunchKernelGGL(front_project_kernel<2>, dim3(front_grid), dim3(FRONT_THREADS), front_lds, st, a); break;
+        case 4: hipLaunchKernelGGL(front_project_kernel<4>, dim3(front_grid), dim3(FRONT_THREADS), front_lds, st, a); break;
+        case 8: hipLaunchKernelGGL(front_project_kernel<8>, dim3(front_grid), dim3(FRONT_THREADS), front_lds, st, a); break;
         default: gsx_set_error("gsx_front_fwd: %d Gaussians per thread unsupported (N too large for the fused front)", L.items);
                  return GSX_E_UNSUPPORTED;
     }

@@ -307,6 +307,29 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel2(
     }
 }
 
+// DIAGNOSTIC build only (-DGSX_WG_TRACE, tools/dbg/wg_trace.sh): every wavefront of the quadrant kernels stamps its start /
+// end (s_memrealtime, 100 MHz) and where it ran (HW_ID, XCC_ID) into a buffer of its own.  Nothing of this is compiled into
+// the product library.
+#ifdef GSX_WG_TRACE
+__device__ unsigned long long *g_wg_trace[2] = {nullptr, nullptr};   // [0] forward kernels, [1] backward kernels
+struct WgTrace {
+    unsigned long long t0;
+    int which;
+    __device__ WgTrace(int w) : t0(__builtin_amdgcn_s_memrealtime()), which(w) {}
+    __device__ ~WgTrace() {
+        unsigned long long *b = g_wg_trace[which];
+        if (b && (threadIdx.x & 63) == 0) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+            const size_t i = ((size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 4;
+            b[i] = t0, b[i + 1] = t1, b[i + 2] = hw, b[i + 3] = xcc;
+        }
+    }
+};
+#define GSX_WG_TRACE_SCOPE(w) WgTrace _wg_trace(w);
+#else
+#define GSX_WG_TRACE_SCOPE(w)
+#endif
 #include "raster_v4.inc"
 
 }  // namespace
@@ -351,7 +374,7 @@ extern "C" int gsx_raster_fwd_track_loss(const float *rec, const float *backgrou
                                          const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W,
                                          int H, const float *gt, const float *exposure, float w_photo, float *render,
                                          float *alphas, int32_t *last_ids, float *v_render, float *loss_rows,
-                                         const int32_t *tile_order, void *stream) {
+                                         const int32_t *tile_order, int32_t *tile_work, void *stream) {
     GSX_CHECK_ARG(offsets && alphas && last_ids && gt && exposure && v_render && loss_rows && C >= 1 && W > 0 && H > 0);
     GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31) && (M == 0 || (rec && flatten_ids)));
     const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
@@ -359,6 +382,7 @@ extern "C" int gsx_raster_fwd_track_loss(const float *rec, const float *backgrou
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
     TrackLossArgs la;
     la.gt = gt; la.exposure = exposure; la.w_photo = w_photo; la.v_render = v_render; la.rows = loss_rows;
+    la.tile_work = tile_work;
     hipLaunchKernelGGL((raster_fwd_kernel4q<4, 12, false, true>), dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, rec,
                        backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, 0.5f, render, alphas,
                        last_ids, (int32_t *)nullptr, tile_order, la);
@@ -423,3 +447,29 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }
+
+#include "tile_balance.h"
+namespace {
+__global__ __launch_bounds__(gsx_bal::THREADS) void tile_balance_kernel(gsx_bal::Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_bal[gsx_bal::LDS_BYTES];
+    gsx_bal::run(a, s_bal);
+}
+}  // namespace
+
+extern "C" int gsx_tile_balance(const int32_t *tile_work, int64_t T, float chunk_cost, float light_rate, int n_cus,
+                                int32_t *tile_order, void *stream) {
+    GSX_CHECK_ARG(tile_work && tile_order && T >= 1 && T <= gsx_bal::MAX_TILES && n_cus >= 1 && n_cus <= gsx_bal::MAX_BINS);
+    GSX_CHECK_ARG(chunk_cost >= 0.f && chunk_cost < 1e6f && light_rate > 0.f && light_rate <= 1.f);
+    gsx_bal::Args a;
+    a.work = tile_work; a.order = tile_order; a.T = (int)T; a.G = n_cus; a.chunk_cost = chunk_cost; a.light_rate = light_rate;
+    hipLaunchKernelGGL(tile_balance_kernel, dim3(1), dim3(gsx_bal::THREADS), 0, (hipStream_t)stream, a);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+#ifdef GSX_WG_TRACE
+extern "C" int gsx_debug_wg_trace(int which, void *buffer) {   // diagnostic build only; not part of include/gsx.h
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace), &buffer, sizeof(buffer), (size_t)(which & 1) * sizeof(buffer)) ==
+                   hipSuccess ? 0 : 1;
+}
+#endif

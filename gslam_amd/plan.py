@@ -199,6 +199,11 @@ class RenderPlan:
             self.v_rec = torch.empty(n_slots, 12, dtype=f32, device=dev)
         self.capacity = 0
         self.flat = self.tile_order = self.isect_ws = None
+        # CU-balanced launch order (gsx_tile_balance): a render whose T workgroups are all resident at once (more than one
+        # and at most five per CU) runs as long as its most loaded CU; enable_balance() makes the rasteriser launches follow
+        # an order computed from the work the tiles took in an earlier closure
+        self.tile_work = self.balanced_order = None
+        self.n_cus = int(torch.cuda.get_device_properties(dev).multi_processor_count) if dev.type == 'cuda' else 0
         self.last_M = 0
         self.stale = False          # set when the buffers were re-allocated: graphs over the old ones must be re-captured
         if capacity is not None:
@@ -302,8 +307,31 @@ class RenderPlan:
                                 None if lean else _p(self.conics), None if self.compact else _p(self.tiles),
                                 _p(self.rec), _p(self.v_rec), None if self.compact else _p(self.vis_count),
                                 self.capacity, _p(self.offsets),
-                                _p(self.M_dev), _p(self.status), _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
-                                self.isect_ws.numel(), st), "gsx_front_fwd")
+                                _p(self.M_dev), _p(self.status), _p(self.flat), _p(self.tile_order),
+                                _p(self.tile_work), _p(self.balanced_order), self.CHUNK_COST, self.LIGHT_RATE, self.n_cus,
+                                _p(self.isect_ws), self.isect_ws.numel(), st), "gsx_front_fwd")
+
+    CHUNK_COST = 3.0        # weight of a 64-entry chunk (gather + cull) in compositing trips (tools/dbg/wg_trace.py)
+    LIGHT_RATE = 0.92       # a CU with 4 workgroups gets through 0.92 of the work of one with 5 in the same time (same trace)
+
+    def enable_balance(self) -> bool:
+        """-> whether this render's shape qualifies (all workgroups resident at once, several per CU)"""
+        if self.front and self.n_cus and self.n_cus < self.T <= min(5 * self.n_cus, 2048) and self.balanced_order is None:
+            self.balanced_order = torch.arange(self.T, dtype=torch.int32, device=self.dev)
+            self.tile_work = torch.zeros(self.T, 2, dtype=torch.int32, device=self.dev)
+        return self.balanced_order is not None
+
+    def rebalance(self, st: int):
+        """new launch order from the work counters the last track-loss forward left, as a launch of its own (the fused front
+        does the same inside its projection launch at every forward(): nothing to call in a loop of closures)"""
+        if self.balanced_order is not None:
+            check(lib.gsx_tile_balance(_p(self.tile_work), self.T, self.CHUNK_COST, self.LIGHT_RATE, self.n_cus,
+                                       _p(self.balanced_order), st),
+                  "gsx_tile_balance")
+
+    @property
+    def launch_order(self):
+        return self.balanced_order if self.balanced_order is not None else self.tile_order
 
     def forward(self, st: int, track_loss=None):
         """track_loss = (gt [C,H,W,3], exposure [C,2], w_photo, loss_rows [T,6]): the forward rasteriser evaluates the
@@ -325,7 +353,7 @@ class RenderPlan:
             check(lib.gsx_raster_fwd_track_loss(_p(self.rec), _p(self.backgrounds), _p(self.offsets), _p(self.flat),
                                                 self.capacity, 1, self.C, self.W, self.H, _p(gt), _p(exposure),
                                                 float(w_photo), None, _p(self.alphas), _p(self.last_ids),
-                                                _p(self.v_render), _p(rows), _p(self.tile_order), st),
+                                                _p(self.v_render), _p(rows), _p(self.launch_order), _p(self.tile_work), st),
                   "gsx_raster_fwd_track_loss")
             return
         if self.n_touched is not None:
@@ -341,7 +369,7 @@ class RenderPlan:
         assert self.grads != 'none'
         check(lib.gsx_raster_bwd(_p(self.rec), self.CH, _p(self.backgrounds), _p(self.offsets), _p(self.flat),
                                  self.capacity, 1, self.C, self.W, self.H, self.tile_w, self.tile_h, _p(self.alphas),
-                                 _p(self.last_ids), _p(self.v_render), None, _p(self.v_rec), None, _p(self.tile_order),
+                                 _p(self.last_ids), _p(self.v_render), None, _p(self.v_rec), None, _p(self.launch_order),
                                  1 if self.geom_only else 0, st), "gsx_raster_bwd")
         m = self.map
         vr = self.v_rec.data_ptr()
@@ -451,8 +479,14 @@ class TrackClosure:
         self.n_rows = (self.r.H * self.r.W + 255) // 256
         # fused tail: the loss is evaluated in the forward rasteriser's epilogue, one row of partials per tile
         self.loss_rows = torch.zeros(self.r.T, 6, device=dev)
+        if tail == 'fused':
+            self.r.enable_balance()       # the fused forward leaves the tiles' work counters: CU-balanced launch order
         self.stream = torch.cuda.Stream(device=dev)
         self.graph = HipGraph()
+
+    def rebalance(self):
+        """once per frame, before its closures: launch order of the rasteriser kernels from the last closure's tile work"""
+        self.r.rebalance(current_stream_ptr(self.dev))
 
     # convenient views of the slot
     @property

@@ -157,8 +157,11 @@ int gsx_front_fwd(const float *means, const float *quats, const float *scales, c
                   const float *logit_opacities, const float *logit_colors, const float *log_uncertainties,
                   int32_t *radii, float *means2d, float *depths, float *conics, int32_t *tiles_per_gauss, float *rec,
                   float *v_rec_clear, int32_t *vis_count, int64_t M_cap, int32_t *offsets, int64_t *M_dev,
-                  int32_t *status, int32_t *flatten_ids, int32_t *tile_order, void *workspace, int64_t workspace_bytes,
-                  void *stream);
+                  int32_t *status, int32_t *flatten_ids, int32_t *tile_order,
+                  /* balanced_order nullable.  If given (C * tile_w * tile_h <= 2048): one extra workgroup of the projection
+                   * launch does the work of gsx_tile_balance(tile_work, ...) -> balanced_order, hidden behind the projection */
+                  const int32_t *tile_work, int32_t *balanced_order, float chunk_cost, float light_rate, int n_cus,
+                  void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Pose gradient of a pose-only closure from the instance records gsx_front_fwd left in its workspace (same N, C, W, H,
  * M_cap): the pose part of gsx_project_bwd(v_means = NULL, flags | GSX_PROJ_VIEW_PARTIALS) over the visible instances
@@ -193,7 +196,15 @@ int gsx_raster_fwd_track_loss(const float *rec, const float *backgrounds, const 
                               const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
                               const float *gt, const float *exposure, float w_photo, float *render, float *alphas,
                               int32_t *last_ids, float *v_render, float *loss_rows, const int32_t *tile_order,
+                              int32_t *tile_work /*[T][2] nullable: (chunks, trips) per tile, the weights of gsx_tile_balance*/,
                               void *stream);
+/* Launch order for the rasteriser kernels of a render whose T workgroups are all resident at once (T <= 2048): deals the
+ * tiles into n_cus groups of near-equal weight (weight = trips + chunk_cost * chunks of tile_work, as measured by an earlier
+ * gsx_raster_fwd_track_loss of a nearby pose) and writes tile_order [T] so that the workgroups i, i + n_cus, i + 2 n_cus, ...
+ * - which an idle MI355X places on one CU - hold one group.  Always a permutation: the weights only matter for speed. */
+int gsx_tile_balance(const int32_t *tile_work, int64_t T, float chunk_cost,
+                     float light_rate /* (0,1]: throughput of a CU holding one workgroup less than the fullest, relative */,
+                     int n_cus, int32_t *tile_order, void *stream);
 
 /* ---- K9: rasterize_to_pixels bwd.  v_rec [C*N, stride] must be zeroed by the caller; gradients are accumulated
  * in record layout: v_xy(2) v_conic(3) v_opacity(1) v_colors(CH).  v_abs (nullable, [C*N,2], zeroed): absgrad.

@@ -298,3 +298,106 @@ def test_front_pose_backward_equals_projection_backward(dev, n, n_cams):
     a, b = sums
     assert float(a.abs().max()) > 0
     assert float((a - b).abs().max()) < 2e-4 * float(a.abs().max()), (a, b)
+
+
+@pytest.mark.parametrize("T,G", [(1200, 256), (300, 256), (2048, 256), (1024, 256), (200, 256), (1201, 304)])
+def test_tile_balance_order(dev, T, G):
+    """gsx_tile_balance: always a permutation; the groups {i, i + G, i + 2G, ...} of the launch order carry near-equal weight
+    (light_rate = 1), or the groups without a tile in the last round carry light_rate x the others' weight"""
+    import numpy as np
+    from gslam_amd._lib import check, lib, ptr
+    from gslam_amd.plan import current_stream_ptr
+    g = torch.Generator().manual_seed(T)
+    chunks = torch.randint(4, 20, (T,), generator=g)
+    trips = (torch.randn(T, generator=g).mul(0.35).exp() * 450).to(torch.int64)
+    work = torch.stack([chunks, trips], 1).to(torch.int32).to(dev).contiguous()
+    w = (trips.double() + 3.0 * chunks.double() + 1.0).numpy()
+    st = current_stream_ptr(dev)
+
+    def run(work_t, light_rate):
+        order = torch.full((T,), -1, dtype=torch.int32, device=dev)
+        check(lib.gsx_tile_balance(ptr(work_t), T, 3.0, light_rate, G, ptr(order), st), "gsx_tile_balance")
+        torch.cuda.synchronize()
+        o = order.cpu().numpy()
+        assert sorted(o.tolist()) == list(range(T))
+        return o
+
+    def sums(o):
+        s = np.zeros(G)
+        np.add.at(s, np.arange(T) % G, w[o])
+        return s
+
+    def emulate(light):
+        """the algorithm of csrc/tile_balance.h with exact sorts"""
+        srt = np.argsort(-w, kind="stable")
+        rounds, last = -(-T // G), T - (-(-T // G) - 1) * G
+        v, S = w[srt[T - last:]].mean(), w.sum() / (last + (G - last) * light)
+        s = np.where(np.arange(G) < last, max(0.0, v - (1 - light) * S) if last < G else 0.0, 0.0)
+        real = np.zeros(G)
+        for r in range(rounds):
+            nb = last if r == rounds - 1 else G
+            rank = np.argsort(np.argsort(s[:nb], kind="stable"), kind="stable")
+            for b in range(nb):
+                t = srt[r * G + rank[b]]
+                s[b] += w[t]
+                real[b] += w[t]
+        return real
+
+    o = run(work, 1.0)
+    run(torch.zeros_like(work), 0.92)                         # no measurements yet: still a permutation
+    if T <= G:
+        return
+    last = T - (-(-T // G) - 1) * G
+    for light in (1.0, 0.9):
+        s, e = sums(run(work, light)), emulate(light)
+        # the kernel sorts the tiles on 1024 weight levels: the group sums follow the exact algorithm closely, not exactly
+        assert abs(s.max() - e.max()) < 0.02 * e.mean() and abs(s.min() - e.min()) < 0.02 * e.mean(), (light, s.max(), e.max())
+        if last < G:
+            assert abs(s[last:].mean() / s[:last].mean() - e[last:].mean() / e[:last].mean()) < 0.01
+    s, ident = sums(o), sums(np.arange(T))
+    if T >= 4 * G:
+        assert s.std() < 0.5 * ident.std()                    # and that is a balance: spread of the group sums halved at least
+    else:
+        assert s.max() <= ident.max()
+
+
+def test_balanced_track_closure_equals_identity_order(dev):
+    """the CU-balanced launch order changes which workgroup renders which tile, nothing else: loss and pose gradient of a
+    tracking closure agree with the identity order to float-atomic reordering"""
+    from gslam_amd.plan import TrackClosure, current_stream_ptr
+    from gslam_amd.primitives import Camera
+    from gslam_amd.synthetic import make_intrinsics, make_scene, make_viewmat
+    from gslam_amd.map import GaussianSplattingData
+    W, H = 640, 480
+    sc = make_scene(60000, 5)
+    sc["scales"] = sc["scales"] + 0.4
+    splats = GaussianSplattingData.from_dict(sc, dev)
+    cam = Camera(make_intrinsics(W, H).to(dev), H, W)
+    c = TrackClosure(splats, cam)
+    assert c.r.balanced_order is not None and c.r.T == 1200
+    img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    c.load(make_viewmat(1.0).to(dev), img, torch.tensor([0.01, -0.02], device=dev))
+    c.r.probe()
+    st = current_stream_ptr(dev)
+
+    denom = H * W
+
+    def once():
+        c.r.forward(st, track_loss=(c.img, c.exposure, 1.0 / denom, c.loss_rows))
+        c.r.backward(st)
+        torch.cuda.synchronize()
+        return (c.loss_rows.sum(0).clone(), c.r.v_render.clone(), c.r.v_rec.clone(),
+                c.r.pose_ws.view(torch.float32)[:c.r.pose_blocks * 12].clone())
+
+    a = once()
+    assert c.r.check_capacity() and int(c.r.tile_work[:, 0].sum()) > 0 and int(c.r.tile_work[:, 1].sum()) > 0
+    c.rebalance()
+    torch.cuda.synchronize()
+    o = c.r.balanced_order.cpu()
+    assert sorted(o.tolist()) == list(range(1200)) and not torch.equal(o, torch.arange(1200, dtype=torch.int32))
+    b = once()
+    assert torch.equal(a[1], b[1])                                        # per-pixel results do not depend on the order
+    torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=1e-6)
+    scale = float(a[2].abs().max())
+    assert float((a[2] - b[2]).abs().max()) < 1e-4 * scale                # float atomics in another order
+    assert float((a[3] - b[3]).abs().max()) < 1e-4 * float(a[3].abs().max()) + 1e-12

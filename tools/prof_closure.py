@@ -20,8 +20,12 @@ def main():
     ap.add_argument("--eager", action="store_true", help="issue the launches eagerly (counter passes cannot attribute graph nodes)")
     ap.add_argument("--front", type=int, default=-1, help="1 / 0 force the fused front on / off")
     ap.add_argument("--ba-front", type=int, default=-1, help="1 / 0 force the fused front of the BA plan on / off")
+    ap.add_argument("--no-balance", action="store_true", help="identity launch order of the rasteriser kernels (A/B)")
     args = ap.parse_args()
     import bench
+    if args.no_balance:
+        import gslam_amd.plan as P0
+        P0.RenderPlan.enable_balance = lambda self: False
     from gslam_amd.map import GaussianSplattingData
     from gslam_amd.mapping import BundleAdjuster, MapConfig
     from gslam_amd.plan import current_stream_ptr
