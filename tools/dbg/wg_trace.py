@@ -138,6 +138,31 @@ def main():
                 o = order.cpu().numpy() if order is not None else np.arange(T)
                 np.save(f"gpurun_out/wg_{tag}_{name}.npy", np.stack([o, dur, tw.cpu().numpy()[o, 0], tw.cpu().numpy()[o, 1]], 1))
 
+    if "--b2b" in sys.argv:
+        # the same backward launch repeated back to back on one stream: do consecutive launches overlap?
+        last = {}
+        orig_bwd = lib.gsx_raster_bwd
+
+        def grab(*a):
+            last["a"] = a
+            return orig_bwd(*a)
+        lib.gsx_raster_bwd = grab
+        tr.plan.enqueue(st)
+        lib.gsx_raster_bwd = orig_bwd
+        torch.cuda.synchronize()
+        for k in bufs:
+            bufs[k].zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(300):
+            orig_bwd(*last["a"])
+        e0.record()
+        for _ in range(100):
+            orig_bwd(*last["a"])
+        e1.record()
+        torch.cuda.synchronize()
+        print("back to back: %.1f us per launch by events" % (e0.elapsed_time(e1) * 10.0))
+        analyse("back-to-back raster backward (last launch)", bufs["gsx_raster_bwd"], 4, None)
+        return
     if "--lag" in sys.argv:
         # how fast the tiles' work decorrelates along the closures of a frame
         frames2, _ = bench.make_frames([sequence_param(i) for i in range(3, 6)], W, H, dev,
