@@ -240,6 +240,10 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 // 21 us for the 1.5 M parameters of a 100 k map, 2 TB/s.)
 // (Tried and rejected: ADAM_UNITS = 256 (slower), and issuing both of a lane's 4 x 16-byte loads ahead of the step-counter
 // read and the bias corrections - 14.1 us against 12.4 us for the 1.5 M parameters.)
+#ifndef GSX_ADAM_NT
+#define GSX_ADAM_NT 1
+#endif
+typedef float gsx_f4v __attribute__((ext_vector_type(4)));
 constexpr int ADAM_UNITS = 512;
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
@@ -266,9 +270,21 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
         for (int64_t u = u0 + threadIdx.x; u < seg_end; u += 256) {
             const int64_t j = (u - a.start[k]) * 4;
             if (vec && j + 4 <= numel) {
+#if GSX_ADAM_NT
+                // the moments are touched by this kernel alone, once per iteration: streamed past the caches, so that the
+                // 8 bytes per parameter they move in each direction do not evict the map and the records the next
+                // iteration's projection and rasteriser read
+                float4 pp = *reinterpret_cast<float4 *>(p + j);
+                const gsx_f4v mn = __builtin_nontemporal_load(reinterpret_cast<gsx_f4v *>(m + j));
+                const gsx_f4v vn = __builtin_nontemporal_load(reinterpret_cast<gsx_f4v *>(v + j));
+                const gsx_f4v gn = __builtin_nontemporal_load(reinterpret_cast<const gsx_f4v *>(g + j));
+                float4 mm = make_float4(mn.x, mn.y, mn.z, mn.w), vv = make_float4(vn.x, vn.y, vn.z, vn.w);
+                const float4 gg = make_float4(gn.x, gn.y, gn.z, gn.w);
+#else
                 float4 pp = *reinterpret_cast<float4 *>(p + j), mm = *reinterpret_cast<float4 *>(m + j),
                        vv = *reinterpret_cast<float4 *>(v + j);
                 const float4 gg = *reinterpret_cast<const float4 *>(g + j);
+#endif
                 adam_one(pp.x, gg.x, mm.x, vv.x, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
                 adam_one(pp.y, gg.y, mm.y, vv.y, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
                 adam_one(pp.z, gg.z, mm.z, vv.z, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
@@ -281,8 +297,13 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
                     if (mk.w > a.decay_min) pp.w *= a.decay;
                 }
                 *reinterpret_cast<float4 *>(p + j) = pp;
+#if GSX_ADAM_NT
+                __builtin_nontemporal_store(gsx_f4v{mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<gsx_f4v *>(m + j));
+                __builtin_nontemporal_store(gsx_f4v{vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<gsx_f4v *>(v + j));
+#else
                 *reinterpret_cast<float4 *>(m + j) = mm;
                 *reinterpret_cast<float4 *>(v + j) = vv;
+#endif
             } else {
                 for (int64_t e = j; e < min(numel, j + 4); ++e) {
                     float pe = p[e], me = m[e], ve = v[e];
