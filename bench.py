@@ -180,7 +180,10 @@ def in_graph_launch_us(plan, stage, reset, n_closures, frames=6):
         reset()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        (g2 if which else plan.graph).launch(count=n_closures)
+        if which:
+            g2.launch(count=n_closures)
+        else:
+            plan.graph.launch(count=n_closures)
         e1.record()
         torch.cuda.synchronize()
         if i >= 2:

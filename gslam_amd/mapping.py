@@ -338,7 +338,7 @@ class GraphedPoseRefiner:
 
     def _issue(self):
         self.plan.init_optimizer(self.max_eval)
-        self.plan.graph.launch(count=self.max_eval + 1)
+        self.plan.launch(self.max_eval + 1)
 
     def run_async(self, window: Optional[List[Frame]] = None):
         """one refinement without any read-back (the caller polls ``capacity_ok()`` later): the graph must have been

@@ -98,6 +98,34 @@ class HipGraph:
             pass
 
 
+def _launch_chain(plan, count: int, stream_ptr: Optional[int] = None):
+    """``count`` evaluations of ``plan``'s closure as ONE graph launch: consecutive launches of a graph sit ~9 us apart on the
+    device (traced), nodes inside one ~1.5 us - a frame of 36 closures loses a third of a millisecond between launches of the
+    one-closure graph.  The chain of ``count`` closures is captured on first use and kept until the closure is re-captured."""
+    if count <= 1:
+        return plan.graph.launch(stream_ptr, count)
+    g = plan._chains.get(count)
+    if g is None:
+        from ._sync import capture_lock
+        g = HipGraph()
+
+        def enqueue(st):
+            for _ in range(count):
+                plan.enqueue(st)
+        with capture_lock:
+            plan.stream.wait_stream(torch.cuda.current_stream(plan.dev))
+            g.capture(plan.stream, enqueue)
+            torch.cuda.current_stream(plan.dev).wait_stream(plan.stream)
+        plan._chains[count] = g
+    g.launch(stream_ptr)
+
+
+def _drop_chains(plan):
+    for g in plan._chains.values():
+        g.destroy()
+    plan._chains.clear()
+
+
 def _map_tensors(splats):
     ts = [splats.means, splats.quats, splats.scales, splats.opacities, splats.colors, splats.log_uncertainties]
     out = []
@@ -490,6 +518,11 @@ class TrackClosure:
             self.r.enable_balance()       # the fused forward leaves the tiles' work counters: CU-balanced launch order
         self.stream = torch.cuda.Stream(device=dev)
         self.graph = HipGraph()
+        self._chains: Dict[int, HipGraph] = {}
+
+    def launch(self, count: int, stream_ptr: Optional[int] = None):
+        """``count`` closures, one graph launch"""
+        _launch_chain(self, count, stream_ptr)
 
     def rebalance(self):
         """once per frame, before its closures: launch order of the rasteriser kernels from the last closure's tile work"""
@@ -570,6 +603,7 @@ class TrackClosure:
                 break
         else:
             raise RuntimeError("tile-list capacity keeps overflowing during warm-up")
+        _drop_chains(self)
         self.graph.capture(self.stream, self.enqueue)
         self.r.stale = False
         self.stream.synchronize()
@@ -619,6 +653,7 @@ class WindowClosure:
         self._ns = (C.c_int * len(ns))(*ns)
         self.stream = torch.cuda.Stream(device=dev)
         self.graph = HipGraph()
+        self._chains: Dict[int, HipGraph] = {}
 
     @torch.no_grad()
     def load(self, window):
@@ -657,6 +692,10 @@ class WindowClosure:
                                         current_stream_ptr(self.dev) if st is None else st), "gsx_window_opt_report")
         return self.report
 
+    def launch(self, count: int, stream_ptr: Optional[int] = None):
+        """``count`` closures, one graph launch"""
+        _launch_chain(self, count, stream_ptr)
+
     def prepare(self):
         saved = [t.clone() for t in (self.slots.dR, self.slots.dt)]
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
@@ -671,6 +710,7 @@ class WindowClosure:
                 break
         else:
             raise RuntimeError("tile-list capacity keeps overflowing during warm-up")
+        _drop_chains(self)
         self.graph.capture(self.stream, self.enqueue)
         self.r.stale = False
         self.stream.synchronize()

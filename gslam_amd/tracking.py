@@ -214,7 +214,7 @@ class GraphedTracker:
             me = self.max_eval if max_eval is None else int(max_eval)
             self.plan.init_optimizer(conf.n_adam_warmup, conf.pose_optim_lr, conf.lbfgs_history, me)
             # a line search may overshoot max_eval by one evaluation
-            self.plan.graph.launch(count=conf.n_adam_warmup + me + 1)
+            self.plan.launch(conf.n_adam_warmup + me + 1)
             rep = self.plan.read_report()
             if not sync:
                 self._write_back(frame)
