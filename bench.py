@@ -141,7 +141,7 @@ class StageTimer:
         return out
 
 
-def in_graph_launch_us(plan, stage, reset, n_closures, frames=6):
+def in_graph_launch_us(plan, stage, resets, n_closures, frames=3):
     """Average duration of one C-ABI launch (``stage``) INSIDE the replayed HIP graph of the closure, HIP events on the launch
     stream: a second graph is captured in which the stage's launch is issued twice in a row - the second time with its
     output redirected where that is an accumulator (the rasteriser backward's gradient records go to a scratch buffer), so the
@@ -150,7 +150,9 @@ def in_graph_launch_us(plan, stage, reset, n_closures, frames=6):
     ``n_closures`` replays are timed with either graph in turn, one event pair around a frame, and the difference per closure
     is the launch: started on a drained chip like every node of the chain - the condition the CU-balanced launch order relies
     on - with the state of each of the frame's closures, at the clocks of the benchmark.  rocprofv3's per-kernel average over
-    the bench is the number this has to agree with."""
+    the bench is the number this has to agree with.  ``resets``: one callable per sample frame of the sequence (the tile lists,
+    and with them the launch's duration, vary by +-10 % along the camera sweep); returns the averages over the samples and the
+    intersection count of each."""
     from gslam_amd import _lib
     from gslam_amd.plan import HipGraph
     lib = _lib.lib
@@ -174,23 +176,28 @@ def in_graph_launch_us(plan, stage, reset, n_closures, frames=6):
     finally:
         setattr(lib, stage, fn)
     assert g2.nodes == plan.graph.nodes + 1, (g2.nodes, plan.graph.nodes)
-    totals = {0: [], 1: []}
-    for i in range(2 * frames + 2):
-        which = i & 1
-        reset()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        if which:
-            g2.launch(count=n_closures)
-        else:
-            plan.graph.launch(count=n_closures)
-        e1.record()
-        torch.cuda.synchronize()
-        if i >= 2:
-            totals[which].append(e0.elapsed_time(e1) * 1e3)
+    per_launch, per_closure, Ms = [], [], []
+    for reset in resets:
+        totals = {0: [], 1: []}
+        for i in range(2 * frames + 2):
+            which = i & 1
+            reset()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if which:
+                g2.launch(count=n_closures)
+            else:
+                plan.graph.launch(count=n_closures)
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                totals[which].append(e0.elapsed_time(e1) * 1e3)
+        plain, extra = sum(totals[0]) / len(totals[0]), sum(totals[1]) / len(totals[1])
+        per_launch.append((extra - plain) / n_closures)
+        per_closure.append(plain / n_closures)
+        Ms.append(int(plan.r.M_dev.item()))
     g2.destroy()
-    plain, extra = sum(totals[0]) / len(totals[0]), sum(totals[1]) / len(totals[1])
-    return (extra - plain) / n_closures, plain / n_closures
+    return sum(per_launch) / len(per_launch), sum(per_closure) / len(per_closure), Ms, per_launch
 
 
 def algorithmic_bytes(N, C, M, P, CH, T):
@@ -397,10 +404,17 @@ def run_headline(args, dev):
         algo = algorithmic_bytes(N, 1, M1, P, 4, T)
         dom = max((s for s in stages if s in algo and s != "gsx_front_fwd"), key=lambda s: stages[s])
 
-        def reset():
-            c.load(f.pose().detach(), f.img, f.exposure_params)
-            c.init_optimizer(N_ADAM, conf.pose_optim_lr, conf.lbfgs_history, MAX_EVAL)
-        dom_us, closure_graph_us = in_graph_launch_us(c, dom, reset, closures_per_frame)
+        def reset_to(fr):
+            def reset():
+                c.load(fr.pose().detach(), fr.img, fr.exposure_params)
+                c.init_optimizer(N_ADAM, conf.pose_optim_lr, conf.lbfgs_history, MAX_EVAL)
+            return reset
+        # sample frames spread over the camera sweep of the timed sequence
+        samples = [frames[WINDOW + min(n_frames - 1, i)] for i in (1, 16, 31, 46, 61, 76, 91, 106)]
+        dom_us, closure_graph_us, Ms, per_sample = in_graph_launch_us(c, dom, [reset_to(fr) for fr in samples],
+                                                                       closures_per_frame)
+        M1 = int(sum(Ms) / len(Ms))
+        algo = algorithmic_bytes(N, 1, M1, P, 4, T)
         achieved = algo[dom] / (dom_us * 1e-6) / 1e9
         line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for(dom, N),
@@ -408,6 +422,8 @@ def run_headline(args, dev):
                             "timing": "HIP events on the launch stream around frames of 36 graph replays, with and without "
                                       "the launch duplicated in the captured closure; difference per closure",
                             "closure_us_in_graph": round(closure_graph_us, 2),
+                            "samples": {"frames_of_the_sequence": [1, 16, 31, 46, 61, 76, 91, 106], "n_isects": Ms,
+                                        "launch_us": [round(x, 2) for x in per_sample]},
                             "avg_launch_us_eager": round(stages[dom], 2),
                             "whole_closure_frac": line["closure"]["frac_of_hbm_peak"]}
         line["stage_us_eager"] = {k: round(v, 2) for k, v in stages.items()}
