@@ -92,14 +92,11 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         }
         radii[idx] = radius_i;
         n_vis += radius_i > 0 ? 1 : 0;
-        if (tiles_per_gauss) tiles_per_gauss[idx] = radius_i > 0 ? tile_count(mx, my, radius_i, tile_w, tile_h) : 0;
-        // GSX_PROJ_SKIP_CULLED (launch plans): a culled pair leaves radii = 0 and tiles = 0 and nothing else - 124 of the
-        // 132 bytes a pair's row takes up; no kernel reads the other columns of a row whose radius is 0
-        if (radius_i == 0 && (flags & GSX_PROJ_SKIP_CULLED)) continue;
         means2d[2 * idx] = mx; means2d[2 * idx + 1] = my;
         depths[idx] = depth;
         conics[3 * idx] = con0; conics[3 * idx + 1] = con1; conics[3 * idx + 2] = con2;
         if (comps) comps[idx] = comp;
+        if (tiles_per_gauss) tiles_per_gauss[idx] = radius_i > 0 ? tile_count(mx, my, radius_i, tile_w, tile_h) : 0;
         if (RS > 0) {
             float *r = rec + idx * RS;
             float ch[6] = {col[0], col[1], col[2], 0.f, 0.f, 0.f};

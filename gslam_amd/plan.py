@@ -291,26 +291,21 @@ class RenderPlan:
         return recs[:, 3].long() & 0xFFFFFFFF
 
     def as_output(self):
-        """the plan's buffers seen as the reference's RasterizationOutput (render / radii / counters as views, the per-pair
-        arrays as copies with the rows of culled pairs zeroed): what pruning, insertion and the SYNC payload read after a
-        render (gslam/rasterization.py:17-41).  ``means2d.grad`` is the view of the
+        """the plan's buffers seen as the reference's RasterizationOutput (views, no copies): what pruning, insertion and
+        the SYNC payload read after a render (gslam/rasterization.py:17-41).  ``means2d.grad`` is the view of the
         gradient records that ``means2d.retain_grad()`` would have produced (backend.py:326)."""
         from .rasterization import RasterizationOutput
         if self.compact:
             raise RuntimeError("a pose-only plan keeps its records per visible instance: no RasterizationOutput view")
-        # rows of culled pairs are not written by the projection (GSX_PROJ_SKIP_CULLED): hand out masked copies
-        vis = (self.radii > 0).view(self.C, self.N)
-        zero = lambda t: torch.where(vis.view(self.C, self.N, *([1] * (t.dim() - 2))), t, torch.zeros((), device=self.dev))
-        means2d = zero(self.means2d.view(self.C, self.N, 2))
-        depths, conics = zero(self.depths.view(self.C, self.N)), zero(self.conics.view(self.C, self.N, 3))
-        opac = zero(self.rec.view(self.C, self.N, -1)[..., 5])
+        means2d = self.means2d
         if self.v_rec is not None:
-            means2d.grad = zero(self.v_rec.view(self.C, self.N, -1)[..., 0:2])
+            means2d = self.means2d.view(self.C, self.N, 2)
+            means2d.grad = self.v_rec[..., 0:2]
         out = RasterizationOutput(
             rgbs=self.render[..., :3], alphas=self.alphas, tile_width=self.tile_w, tile_height=self.tile_h,
             tiles_per_gauss=self.tiles, isect_offsets=self.offsets[:-1].view(self.C, self.tile_h, self.tile_w),
             width=self.W, height=self.H, tile_size=TILE, n_cameras=self.C, camera_ids=None, gaussian_ids=None,
-            radii=self.radii, means2d=means2d, depths=depths, conics=conics, opacities=opac,
+            radii=self.radii, means2d=means2d, depths=self.depths, conics=self.conics, opacities=self.rec[..., 5],
             n_touched=self.n_touched)
         if self.depth_index >= 0:
             out.depthmaps = self.render[..., self.depth_index]
@@ -323,10 +318,8 @@ class RenderPlan:
     # ---- launches ----------------------------------------------------------------------------------------------------
     def _project(self, st: int):
         m = self.map
-        # culled (camera, Gaussian) pairs leave radii = 0 and nothing else (two thirds of the rows of a window render):
-        # as_output() masks what it hands out
         check(lib.gsx_project_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
-                                  self.H, self.eps2d, self.near, self.far, 0.0, self.flags | _SKIP_CULLED, _p(self.radii),
+                                  self.H, self.eps2d, self.near, self.far, 0.0, self.flags, _p(self.radii),
                                   _p(self.means2d), _p(self.depths), _p(self.conics), None, _p(self.tiles), self.tile_w,
                                   self.tile_h, _p(m[3]), _p(m[4]), _p(m[5]), _p(self.rec), _p(self.vis_count),
                                   _p(self.v_rec), st), "gsx_project_fwd")
@@ -334,7 +327,7 @@ class RenderPlan:
     def _front(self, st: int):
         m = self.map
         lean = self.lean
-        flags = self.flags | _SKIP_CULLED | (_COMPACT if self.compact else 0)
+        flags = self.flags | (_SKIP_CULLED if lean else 0) | (_COMPACT if self.compact else 0)
         check(lib.gsx_front_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                 self.H, self.eps2d, self.near, self.far, flags,
                                 _p(m[3]), _p(m[4]), _p(m[5]), None if self.compact else _p(self.radii),

@@ -48,10 +48,8 @@ extern "C" {
 #define GSX_PROJ_VIEW_PARTIALS 8  /* gsx_project_bwd only: leave the per-workgroup pose-gradient partials
                                      ([gsx_project_bwd_blocks(N)][C][12] floats at the start of the workspace) for a fused
                                      consumer (gsx_track_opt_tail) and skip the finishing launch; v_viewmats is ignored */
-#define GSX_PROJ_SKIP_CULLED 16   /* gsx_project_fwd / gsx_front_fwd: rows of culled (camera, Gaussian) pairs get radii = 0 and
-                                     tiles_per_gauss = 0 and nothing else - neither the other per-pair arrays nor the record
-                                     nor the cleared gradient record (no kernel reads a row whose radius is 0; a host-side
-                                     reader has to mask by radii > 0) */
+#define GSX_PROJ_SKIP_CULLED 16   /* gsx_front_fwd only: rows of culled (camera, Gaussian) pairs get radii = 0 and
+                                     tiles_per_gauss = 0 and nothing else (nobody reads them in a pose-only closure) */
 #define GSX_PROJ_COMPACT 32       /* gsx_front_fwd / gsx_front_pose_bwd: rec and v_rec hold one row per visible INSTANCE, indexed
                                      by its slot ((c * R + row) * slots_per_segment + position, gsx_front_layout) instead of one
                                      row per flatten id, and flatten_ids carries slots.  Slots are assigned in flatten-id order,

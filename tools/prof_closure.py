@@ -21,12 +21,8 @@ def main():
     ap.add_argument("--front", type=int, default=-1, help="1 / 0 force the fused front on / off")
     ap.add_argument("--ba-front", type=int, default=-1, help="1 / 0 force the fused front of the BA plan on / off")
     ap.add_argument("--no-balance", action="store_true", help="identity launch order of the rasteriser kernels (A/B)")
-    ap.add_argument("--no-skip", action="store_true", help="projection writes the rows of culled pairs too (A/B)")
     args = ap.parse_args()
     import bench
-    if args.no_skip:
-        import gslam_amd.plan as P1
-        P1._SKIP_CULLED = 0
     if args.no_balance:
         import gslam_amd.plan as P0
         P0.RenderPlan.enable_balance = lambda self: False
