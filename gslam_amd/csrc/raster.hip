@@ -410,6 +410,9 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
     //                                    round: 86.9 -> 80.9 us at 500 k)
     //   full chip (>= 4096 tiles)      : two pixels per lane, two wavefronts per tile, batches of 128
     //   one camera                     : quadrant kernel; batches of 128 with deep tile lists, 64 otherwise
+#ifndef GSX_BWD_FULLCHIP_TILES
+#define GSX_BWD_FULLCHIP_TILES 4096
+#endif
     const bool geom_only = geometry_only != 0 && !v_abs;
     const int64_t per_tile = M / (T > 0 ? T : 1);
 #define LAUNCH(ch, rs)                                                                                               \
@@ -422,7 +425,7 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
             hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, true>), dim3((unsigned)T), dim3(256), 0, st, rec,    \
                                backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas,  \
                                last_ids, v_render, v_alphas, v_rec, tile_order);                                     \
-        else if (T >= 4096)                                                                                          \
+        else if (T >= GSX_BWD_FULLCHIP_TILES)                                                                        \
             hipLaunchKernelGGL((raster_bwd_kernel4<ch, rs, 128>), dim3((unsigned)T), dim3(128), 0, st, rec,          \
                                backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas,  \
                                last_ids, v_render, v_alphas, v_rec, tile_order);                                     \
