@@ -434,7 +434,7 @@ def run_headline(args, dev):
 # ------------------------------------------------------------------------------------------------------------------------
 # keyframe bundle adjustment (configs[3] strong scaling; configs[1] as an extra)
 # ------------------------------------------------------------------------------------------------------------------------
-def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=False):
+def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=False, unsharded=False):
     import torch.distributed as td
     from gslam_amd.map import GaussianSplattingData
     from gslam_amd.mapping import BundleAdjuster, MapConfig
@@ -445,7 +445,13 @@ def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=F
     del gt_scene
     torch.cuda.empty_cache()
     ba = BundleAdjuster(splats, MapConfig(), capturable=True)
-    plan = ba.plan(window)
+    if unsharded:
+        # the whole window on this rank although a process group exists: the 1-GPU point of the scaling curve, measured on
+        # the same node right before the sharded run
+        from gslam_amd.plan import MappingStep
+        plan = MappingStep(splats, ba.optimizers, window, ba.conf, shard=None)
+    else:
+        plan = ba.plan(window)
     plan.prepare()
 
     def barrier():
@@ -588,15 +594,25 @@ def main():
     W, H = args.width, args.height
     steps = args.steps or 60
     warmup = 10 if args.warmup is None else args.warmup
+    one_gpu = None
+    if world > 1:
+        if rank == 0:
+            r1 = run_ba(dev, 0, 1, N, W, H, WINDOW, max(10, steps // 2), warmup, unsharded=True)
+            one_gpu = {"keyframes_per_s": round(r1["keyframes_per_s"], 3), "ms_per_ba_iteration": round(r1["ms_per_iter"], 4),
+                       "note": "the same workload with the whole 8-keyframe window on rank 0 alone (no collective), measured "
+                               "right before the sharded run while the other ranks wait"}
+            torch.cuda.empty_cache()
+        td.barrier()
     r = run_ba(dev, rank, world, N, W, H, WINDOW, steps, warmup, stage_timing=not args.no_stage_timing)
     if rank == 0:
         line = {
-            "metric": "keyframe-BA throughput: keyframe renders fwd+bwd per second @640x480 / 2M Gaussians, 8-keyframe window",
+            "metric": f"keyframe-BA throughput: keyframe renders fwd+bwd per second @{W}x{H} / {N / 1e6:g}M Gaussians, "
+                      f"{WINDOW}-keyframe window",
             "value": round(r["keyframes_per_s"], 3), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(r["ms_per_iter"], 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[3]: 2M Gaussians, 640x480, keyframe bundle adjustment over a fixed 8-keyframe "
+                "workload": f"BASELINE.json configs[3]: {N / 1e6:g}M Gaussians, {W}x{H}, keyframe bundle adjustment over a fixed 8-keyframe "
                             "window sharded across the GPUs (step = one BA iteration: render fwd+bwd CH=5 + full mapping loss + "
                             "fused Adam)",
                 "gaussians": N, "width": W, "height": H, "window": WINDOW, "cameras_on_rank0": r["local_cameras"],
@@ -605,6 +621,7 @@ def main():
                 "launch": "hip-graph replay (render+loss+backward | isotropic+Adam) around one eager all-reduce"
                           if world > 1 else "hip-graph replay of the whole step",
             },
+            "one_gpu_reference": one_gpu,
             "all_reduce_us": None if r["reduce_us"] is None else round(r["reduce_us"], 1),
             "all_reduce_algbw_gbs": None if not r["reduce_us"] else round(r["bucket_bytes"] / r["reduce_us"] * 1e-3, 1),
             "rccl": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "RCCL_MSCCL_ENABLE") if os.environ.get(k)},
