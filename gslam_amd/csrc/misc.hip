@@ -240,11 +240,14 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 // 21 us for the 1.5 M parameters of a 100 k map, 2 TB/s.)
 // (Tried and rejected: ADAM_UNITS = 256 (slower), and issuing both of a lane's 4 x 16-byte loads ahead of the step-counter
 // read and the bias corrections - 14.1 us against 12.4 us for the 1.5 M parameters.)
-#ifndef GSX_ADAM_NT
-#define GSX_ADAM_NT 1
+#ifndef GSX_ADAM_ILP
+#define GSX_ADAM_ILP 1      /* 2 and 4 units in flight per thread measured slower (76 / 88 us against 71 at 7.5 M parameters) */
+#endif
+#ifndef GSX_ADAM_UNITS
+#define GSX_ADAM_UNITS 512
 #endif
 typedef float gsx_f4v __attribute__((ext_vector_type(4)));
-constexpr int ADAM_UNITS = 512;
+constexpr int ADAM_UNITS = GSX_ADAM_UNITS, ADAM_ILP = GSX_ADAM_ILP;
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
     int64_t u0 = (int64_t)blockIdx.x * ADAM_UNITS;
@@ -267,49 +270,66 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
         const bool decays = (k == a.decay_k);
         const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) &&
                          (!decays || (((uintptr_t)a.decay_mask & 15) == 0));
-        for (int64_t u = u0 + threadIdx.x; u < seg_end; u += 256) {
-            const int64_t j = (u - a.start[k]) * 4;
-            if (vec && j + 4 <= numel) {
-#if GSX_ADAM_NT
-                // the moments are touched by this kernel alone, once per iteration: streamed past the caches, so that the
-                // 8 bytes per parameter they move in each direction do not evict the map and the records the next
-                // iteration's projection and rasteriser read
-                float4 pp = *reinterpret_cast<float4 *>(p + j);
-                const gsx_f4v mn = __builtin_nontemporal_load(reinterpret_cast<gsx_f4v *>(m + j));
-                const gsx_f4v vn = __builtin_nontemporal_load(reinterpret_cast<gsx_f4v *>(v + j));
-                const gsx_f4v gn = __builtin_nontemporal_load(reinterpret_cast<const gsx_f4v *>(g + j));
-                float4 mm = make_float4(mn.x, mn.y, mn.z, mn.w), vv = make_float4(vn.x, vn.y, vn.z, vn.w);
-                const float4 gg = make_float4(gn.x, gn.y, gn.z, gn.w);
-#else
-                float4 pp = *reinterpret_cast<float4 *>(p + j), mm = *reinterpret_cast<float4 *>(m + j),
-                       vv = *reinterpret_cast<float4 *>(v + j);
-                const float4 gg = *reinterpret_cast<const float4 *>(g + j);
-#endif
-                adam_one(pp.x, gg.x, mm.x, vv.x, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
-                adam_one(pp.y, gg.y, mm.y, vv.y, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
-                adam_one(pp.z, gg.z, mm.z, vv.z, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
-                adam_one(pp.w, gg.w, mm.w, vv.w, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
-                if (decays) {
-                    const int4 mk = *reinterpret_cast<const int4 *>(a.decay_mask + j);
-                    if (mk.x > a.decay_min) pp.x *= a.decay;
-                    if (mk.y > a.decay_min) pp.y *= a.decay;
-                    if (mk.z > a.decay_min) pp.z *= a.decay;
-                    if (mk.w > a.decay_min) pp.w *= a.decay;
+        // ADAM_ILP units per thread and trip: all their loads are issued before the first result is needed
+        for (int64_t ub = u0 + threadIdx.x; ub < seg_end; ub += 256 * ADAM_ILP) {
+            float4 pp[ADAM_ILP], mm[ADAM_ILP], vv[ADAM_ILP], gg[ADAM_ILP];
+            int4 mk[ADAM_ILP];
+            bool fast[ADAM_ILP];
+#pragma unroll
+            for (int q = 0; q < ADAM_ILP; ++q) {
+                const int64_t u = ub + 256 * q;
+                const int64_t j = (u - a.start[k]) * 4;
+                fast[q] = u < seg_end && vec && j + 4 <= numel;
+                if (fast[q]) {
+                    // the moments and the gradient are touched by this kernel alone, once per iteration: streamed past the
+                    // caches, so that they do not evict the map and the records the next iteration reads
+                    pp[q] = *reinterpret_cast<float4 *>(p + j);
+                    const gsx_f4v mn = __builtin_nontemporal_load(reinterpret_cast<gsx_f4v *>(m + j));
+                    const gsx_f4v vn = __builtin_nontemporal_load(reinterpret_cast<gsx_f4v *>(v + j));
+                    const gsx_f4v gn = __builtin_nontemporal_load(reinterpret_cast<const gsx_f4v *>(g + j));
+                    mm[q] = make_float4(mn.x, mn.y, mn.z, mn.w); vv[q] = make_float4(vn.x, vn.y, vn.z, vn.w);
+                    gg[q] = make_float4(gn.x, gn.y, gn.z, gn.w);
+                    if (decays) mk[q] = *reinterpret_cast<const int4 *>(a.decay_mask + j);
                 }
-                *reinterpret_cast<float4 *>(p + j) = pp;
-#if GSX_ADAM_NT
-                __builtin_nontemporal_store(gsx_f4v{mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<gsx_f4v *>(m + j));
-                __builtin_nontemporal_store(gsx_f4v{vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<gsx_f4v *>(v + j));
-#else
-                *reinterpret_cast<float4 *>(m + j) = mm;
-                *reinterpret_cast<float4 *>(v + j) = vv;
-#endif
-            } else {
-                for (int64_t e = j; e < min(numel, j + 4); ++e) {
-                    float pe = p[e], me = m[e], ve = v[e];
-                    adam_one(pe, g[e], me, ve, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
-                    if (decays && a.decay_mask[e] > a.decay_min) pe *= a.decay;
-                    p[e] = pe; m[e] = me; v[e] = ve;
+            }
+#pragma unroll
+            for (int q = 0; q < ADAM_ILP; ++q) {
+                const int64_t u = ub + 256 * q;
+                const int64_t j = (u - a.start[k]) * 4;
+                // A unit whose gradient and moments are all zero - a Gaussian no camera of any window has seen yet, most of
+                // a large map - comes out of the update exactly as it went in (p - 0 / eps, m = 0, v = 0): its 12 bytes
+                // per parameter of stores are skipped.  Bit-identical by construction.
+                bool idle = false;
+                if (fast[q]) {
+                    const float any = (fabsf(gg[q].x) + fabsf(gg[q].y)) + (fabsf(gg[q].z) + fabsf(gg[q].w)) +
+                                      (fabsf(mm[q].x) + fabsf(mm[q].y)) + (fabsf(mm[q].z) + fabsf(mm[q].w)) +
+                                      (vv[q].x + vv[q].y) + (vv[q].z + vv[q].w);
+                    idle = any == 0.0f;
+                    if (idle && decays)
+                        idle = !(mk[q].x > a.decay_min || mk[q].y > a.decay_min || mk[q].z > a.decay_min || mk[q].w > a.decay_min);
+                }
+                if (idle) continue;
+                if (fast[q]) {
+                    adam_one(pp[q].x, gg[q].x, mm[q].x, vv[q].x, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
+                    adam_one(pp[q].y, gg[q].y, mm[q].y, vv[q].y, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
+                    adam_one(pp[q].z, gg[q].z, mm[q].z, vv[q].z, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
+                    adam_one(pp[q].w, gg[q].w, mm[q].w, vv[q].w, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
+                    if (decays) {
+                        if (mk[q].x > a.decay_min) pp[q].x *= a.decay;
+                        if (mk[q].y > a.decay_min) pp[q].y *= a.decay;
+                        if (mk[q].z > a.decay_min) pp[q].z *= a.decay;
+                        if (mk[q].w > a.decay_min) pp[q].w *= a.decay;
+                    }
+                    *reinterpret_cast<float4 *>(p + j) = pp[q];
+                    __builtin_nontemporal_store(gsx_f4v{mm[q].x, mm[q].y, mm[q].z, mm[q].w}, reinterpret_cast<gsx_f4v *>(m + j));
+                    __builtin_nontemporal_store(gsx_f4v{vv[q].x, vv[q].y, vv[q].z, vv[q].w}, reinterpret_cast<gsx_f4v *>(v + j));
+                } else if (u < seg_end) {
+                    for (int64_t e = j; e < min(numel, j + 4); ++e) {
+                        float pe = p[e], me = m[e], ve = v[e];
+                        adam_one(pe, g[e], me, ve, a.beta1, a.beta2, a.eps, step_size, bc2_sqrt);
+                        if (decays && a.decay_mask[e] > a.decay_min) pe *= a.decay;
+                        p[e] = pe; m[e] = me; v[e] = ve;
+                    }
                 }
             }
         }
