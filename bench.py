@@ -268,6 +268,10 @@ def run_headline(args, dev):
     mailbox = MapMailbox()
     frontend_map, _ = receive(None, mailbox.publish(backend_map))      # what SYNC ships (backend.py:508-519)
     conf = TrackingConfig()
+    for x in args.diag.split(","):
+        if x.startswith("balance:"):                        # balance:<light_rate>:<chunk_cost> (tuning runs)
+            from gslam_amd.plan import RenderPlan as _RP
+            _RP.LIGHT_RATE, _RP.CHUNK_COST = float(x.split(":")[1]), float(x.split(":")[2])
     tracker = GraphedTracker(frontend_map, cam, conf, device_optimizer=True, max_eval=MAX_EVAL)
     ba = BundleAdjuster(backend_map, MapConfig(), capturable=True)
     plan = ba.plan(keyframes)
