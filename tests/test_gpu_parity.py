@@ -425,6 +425,34 @@ def test_adam_matches_torch_and_oracle(dev, oracle32):
         assert np.abs(_np(p) - cp).max() < 1e-6
 
 
+def test_adam_untouched_rows_stay_bit_identical(dev):
+    """Gaussians no camera has seen yet have zero gradient and zero moments: the kernel skips their stores, torch.optim.Adam
+    rewrites them with the same values - parameters and moments agree bit for bit, before and after such rows wake up"""
+    from gslam_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(3000, 3), (3000, 4), (3000,)]
+    p0 = [torch.randn(s, generator=g) for s in shapes]
+    ours = [p.clone().to(dev).requires_grad_(True) for p in p0]
+    ref = [p.clone().to(dev).requires_grad_(True) for p in p0]
+    opt = FusedAdam([{"params": [p], "lr": 1e-2} for p in ours])
+    ropts = [torch.optim.Adam([p], lr=1e-2) for p in ref]
+    seen = torch.zeros(3000, dtype=torch.bool)
+    for step in range(1, 7):
+        seen |= torch.rand(3000, generator=g) < 0.25            # a quarter more of the rows gets a gradient each step
+        for p, q, shp in zip(ours, ref, shapes):
+            gr = torch.randn(shp, generator=g)
+            gr[~seen] = 0.0
+            p.grad = gr.clone().to(dev)
+            q.grad = gr.clone().to(dev)
+        opt.step()
+        for ro in ropts:
+            ro.step()
+        for p, q, p_init in zip(ours, ref, p0):
+            assert torch.equal(p.detach()[~seen.to(dev)], p_init.to(dev)[~seen.to(dev)])       # untouched rows: untouched
+            assert (p - q).abs().max() < 1e-6
+    assert int((~seen).sum()) > 100
+
+
 @pytest.mark.parametrize("regularize,c", [(True, 2), (False, 2), (True, 17)])
 def test_fused_mapping_loss_matches_reference_formulation(dev, regularize, c):
     """csrc/loss.hip (one pass, analytic gradient) vs the reference's own torch formulation of
