@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         n_vis += radius_i > 0 ? 1 : 0;
         means2d[2 * idx] = mx; means2d[2 * idx + 1] = my;
         depths[idx] = depth;
-        conics[3 * idx] = con0; conics[3 * idx + 1] = con1; conics[3 * idx + 2] = con2;
+        if (conics) { conics[3 * idx] = con0; conics[3 * idx + 1] = con1; conics[3 * idx + 2] = con2; }
         if (comps) comps[idx] = comp;
         if (tiles_per_gauss) tiles_per_gauss[idx] = radius_i > 0 ? tile_count(mx, my, radius_i, tile_w, tile_h) : 0;
         if (RS > 0) {
@@ -419,7 +419,8 @@ extern "C" int gsx_project_fwd(const float *means, const float *quats, const flo
                                void *stream) {
     GSX_CHECK_ARG(N >= 0 && C >= 1 && W > 0 && H > 0);
     GSX_CHECK_ARG(!v_rec_clear || rec);
-    GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && radii && means2d && depths && conics);
+    GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && radii && means2d && depths);
+    GSX_CHECK_ARG(conics || rec);                             // the conic is in the record as well (columns 2..4)
     if (rec) {
         GSX_CHECK_ARG(logit_opacities && logit_colors);
         GSX_CHECK_ARG(!(flags & GSX_PROJ_BETAS) || log_uncertainties);

@@ -178,7 +178,7 @@ class RenderPlan:
         if Ks is not None:
             self.Ks.copy_(Ks.reshape(-1, 3, 3).expand(Cn, 3, 3))
         self.radii, self.tiles = e(Cn, N, dtype=i32), e(Cn, N, dtype=i32)
-        self.means2d, self.depths, self.conics = e(Cn, N, 2), e(Cn, N), e(Cn, N, 3)
+        self.means2d, self.depths = e(Cn, N, 2), e(Cn, N)        # (the conics are columns 2..4 of the record: no array of their own)
         self.vis_count = e(N, dtype=i32)
         self.rec = e(Cn, N, 12)
         self.v_rec = e(Cn, N, 12) if grads != 'none' else None
@@ -305,7 +305,7 @@ class RenderPlan:
             rgbs=self.render[..., :3], alphas=self.alphas, tile_width=self.tile_w, tile_height=self.tile_h,
             tiles_per_gauss=self.tiles, isect_offsets=self.offsets[:-1].view(self.C, self.tile_h, self.tile_w),
             width=self.W, height=self.H, tile_size=TILE, n_cameras=self.C, camera_ids=None, gaussian_ids=None,
-            radii=self.radii, means2d=means2d, depths=self.depths, conics=self.conics, opacities=self.rec[..., 5],
+            radii=self.radii, means2d=means2d, depths=self.depths, conics=self.rec[..., 2:5], opacities=self.rec[..., 5],
             n_touched=self.n_touched)
         if self.depth_index >= 0:
             out.depthmaps = self.render[..., self.depth_index]
@@ -320,7 +320,7 @@ class RenderPlan:
         m = self.map
         check(lib.gsx_project_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                   self.H, self.eps2d, self.near, self.far, 0.0, self.flags, _p(self.radii),
-                                  _p(self.means2d), _p(self.depths), _p(self.conics), None, _p(self.tiles), self.tile_w,
+                                  _p(self.means2d), _p(self.depths), None, None, _p(self.tiles), self.tile_w,
                                   self.tile_h, _p(m[3]), _p(m[4]), _p(m[5]), _p(self.rec), _p(self.vis_count),
                                   _p(self.v_rec), st), "gsx_project_fwd")
 
@@ -332,7 +332,7 @@ class RenderPlan:
                                 self.H, self.eps2d, self.near, self.far, flags,
                                 _p(m[3]), _p(m[4]), _p(m[5]), None if self.compact else _p(self.radii),
                                 None if lean else _p(self.means2d), None if lean else _p(self.depths),
-                                None if lean else _p(self.conics), None if self.compact else _p(self.tiles),
+                                None, None if self.compact else _p(self.tiles),
                                 _p(self.rec), _p(self.v_rec), None if self.compact else _p(self.vis_count),
                                 self.capacity, _p(self.offsets),
                                 _p(self.M_dev), _p(self.status), _p(self.flat), _p(self.tile_order),

@@ -65,7 +65,8 @@ int gsx_record_stride(int CH);
 int gsx_read_i64(const int64_t *dev_ptr, int64_t *host_out, void *stream);
 
 /* ---- K1: gsplat fully_fused_projection fwd  (gslam/rasterization.py:153-170, :390-407) -------------------------
- * outputs [C,N]: radii i32, means2d [.,2], depths, conics [.,3], comps (nullable; 'antialiased' compensation).
+ * outputs [C,N]: radii i32, means2d [.,2], depths, conics [.,3] (nullable when `rec` is given: columns 2..4 of the record
+ * hold the same values), comps (nullable; 'antialiased' compensation).
  * Culled rows are written as zeros.  tiles_per_gauss (nullable) = K3 count for tile 16 (rasterization.py:259-272).
  * Optional fused gslam front-end (rasterization.py:145-149,183-256): when `rec` != NULL a splat record
  * [xy, conic, opacity, colors...] of gsx_record_stride(CH) floats is written per (c,g) with
