@@ -1315,6 +1315,10 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
         const int64_t vrow = compact ? (((int64_t)c * R + row) * seg_cap + i) : idx;
         const float4 *r4 = reinterpret_cast<const float4 *>(v_rec + vrow * 12);
         const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2];
+        if (flags & GSX_PROJ_RESET_V_REC) {                  // consumed: the row goes back to zero for the next backward
+            float4 *w4 = const_cast<float4 *>(r4);
+            w4[0] = w4[1] = w4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         QuatRot qr;
         quat_to_rotmat(q, qr);
         float M[9];

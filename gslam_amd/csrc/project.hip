@@ -182,6 +182,10 @@ __global__ __launch_bounds__(PBWD_THREADS) void project_bwd_kernel(
             if (fused_row) {
                 const float4 *r4 = reinterpret_cast<const float4 *>(v_rec + idx * 12);
                 const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2];
+                if (flags & GSX_PROJ_RESET_V_REC) {             // consumed: the row goes back to zero for the next backward
+                    float4 *w4 = const_cast<float4 *>(r4);
+                    w4[0] = w4[1] = w4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
                 row[0] = q0.x; row[1] = q0.y; row[2] = q0.z; row[3] = q0.w; row[4] = q1.x; row[5] = q1.y; row[6] = q1.z;
                 row[7] = q1.w; row[8] = q2.x; row[9] = q2.y; row[10] = q2.z; row[11] = q2.w;
             } else {
@@ -466,6 +470,8 @@ extern "C" int gsx_project_bwd(const float *means, const float *quats, const flo
     const bool partials_only = (flags & GSX_PROJ_VIEW_PARTIALS) != 0;   // leave the pose partials for a fused consumer
     GSX_CHECK_ARG(pose_only ? (v_viewmats != nullptr || partials_only) : (v_means && v_quats && v_scales));
     GSX_CHECK_ARG(v_means2d_stride >= 2 && v_conics_stride >= 3);
+    GSX_CHECK_ARG(!(flags & GSX_PROJ_RESET_V_REC) || (v_rec && v_means2d == v_rec && v_means2d_stride == 12 &&
+                                                      v_conics == v_rec + 2 && v_conics_stride == 12));
     if (v_rec && !pose_only) GSX_CHECK_ARG(logit_opacities && logit_colors && v_logit_opacities && v_logit_colors);
     if (v_rec && !pose_only && (flags & GSX_PROJ_BETAS)) GSX_CHECK_ARG(log_uncertainties && v_log_unc);
     hipStream_t st = (hipStream_t)stream;

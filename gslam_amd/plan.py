@@ -30,6 +30,7 @@ from .ops import PROJ_BETAS, PROJ_LOG_SCALES, PROJ_RENDER_DEPTH
 
 TILE = 16
 _VIEW_PARTIALS = 8      # GSX_PROJ_VIEW_PARTIALS
+_RESET_V_REC = 64       # GSX_PROJ_RESET_V_REC
 _SKIP_CULLED = 16       # GSX_PROJ_SKIP_CULLED
 _COMPACT = 32           # GSX_PROJ_COMPACT
 
@@ -181,7 +182,11 @@ class RenderPlan:
         self.means2d, self.depths = e(Cn, N, 2), e(Cn, N)        # (the conics are columns 2..4 of the record: no array of their own)
         self.vis_count = e(N, dtype=i32)
         self.rec = e(Cn, N, 12)
-        self.v_rec = e(Cn, N, 12) if grads != 'none' else None
+        # gradient records [C,N,12]: all zeros between backward passes - the projection backward zeroes every row it has
+        # read (GSX_PROJ_RESET_V_REC), so no forward clears them (192 of the 416 MB the projection of a 500 k x 8 window
+        # wrote: 86 -> 51 us, the backward pays 18 us of it back)
+        self.v_rec = torch.zeros(Cn, N, 12, dtype=f32, device=dev) if grads != 'none' else None
+        self._v_rec_dirty = False      # a backward(keep=True) left its gradients in v_rec
         self.offsets = torch.zeros(self.T + 1, dtype=i32, device=dev)
         self.M_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.status = torch.zeros(1, dtype=i32, device=dev)
@@ -224,7 +229,7 @@ class RenderPlan:
             self.front_rows, self.front_seg = int(lay[0]), int(lay[1])
             n_slots = Cn * self.front_rows * self.front_seg
             self.rec = torch.empty(n_slots, 12, dtype=f32, device=dev)
-            self.v_rec = torch.empty(n_slots, 12, dtype=f32, device=dev)
+            self.v_rec = torch.zeros(n_slots, 12, dtype=f32, device=dev)
         self.capacity = 0
         self.flat = self.tile_order = self.isect_ws = None
         # CU-balanced launch order (gsx_tile_balance): a render whose T workgroups are all resident at once (more than one
@@ -316,13 +321,35 @@ class RenderPlan:
         return out
 
     # ---- launches ----------------------------------------------------------------------------------------------------
+    def _clear_ptr(self):
+        """the gradient records as the forward's clear target - only when an earlier backward(keep=True) left them dirty (an
+        eager call decides this when it is issued; owners of captured graphs call clean() before a replay)"""
+        if self.v_rec is None:
+            return None
+        if self.compact:
+            # records per visible instance (pose-only plans): 48 dense bytes per instance, cleared on the way by the
+            # projection - cheaper there than zeroing them from the pose backward (measured: 12.2 against 11.1 us)
+            return self.v_rec.data_ptr()
+        if self._v_rec_dirty:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("capture with clean gradient records (RenderPlan.clean())")
+            self._v_rec_dirty = False
+            return self.v_rec.data_ptr()
+        return None
+
+    def clean(self, st: int):
+        """zeroes the gradient records if a backward(keep=True) left them behind; call before replaying a captured forward"""
+        if self.v_rec is not None and self._v_rec_dirty:
+            check(lib.gsx_zero_words(_p(self.v_rec), self.v_rec.numel(), st), "gsx_zero_words")
+            self._v_rec_dirty = False
+
     def _project(self, st: int):
         m = self.map
         check(lib.gsx_project_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                   self.H, self.eps2d, self.near, self.far, 0.0, self.flags, _p(self.radii),
                                   _p(self.means2d), _p(self.depths), None, None, _p(self.tiles), self.tile_w,
                                   self.tile_h, _p(m[3]), _p(m[4]), _p(m[5]), _p(self.rec), _p(self.vis_count),
-                                  _p(self.v_rec), st), "gsx_project_fwd")
+                                  self._clear_ptr(), st), "gsx_project_fwd")
 
     def _front(self, st: int):
         m = self.map
@@ -333,7 +360,7 @@ class RenderPlan:
                                 _p(m[3]), _p(m[4]), _p(m[5]), None if self.compact else _p(self.radii),
                                 None if lean else _p(self.means2d), None if lean else _p(self.depths),
                                 None, None if self.compact else _p(self.tiles),
-                                _p(self.rec), _p(self.v_rec), None if self.compact else _p(self.vis_count),
+                                _p(self.rec), self._clear_ptr(), None if self.compact else _p(self.vis_count),
                                 self.capacity, _p(self.offsets),
                                 _p(self.M_dev), _p(self.status), _p(self.flat), _p(self.tile_order),
                                 _p(self.tile_work), _p(self.balanced_order), self.CHUNK_COST, self.LIGHT_RATE, self.n_cus,
@@ -391,10 +418,14 @@ class RenderPlan:
                                  _p(self.render), _p(self.alphas), _p(self.last_ids), _p(self.n_touched),
                                  _p(self.tile_order), st), "gsx_raster_fwd")
 
-    def backward(self, st: int):
+    def backward(self, st: int, keep: bool = False):
         """from ``self.v_render`` (filled by the loss launch) to the pose partials in ``self.pose_ws`` and, for 'full', the
-        six map gradients (overwritten, summed over cameras inside)"""
+        six map gradients (overwritten, summed over cameras inside).  keep: leave the gradient records as accumulated
+        (``as_output().means2d.grad`` reads them: densification) instead of zeroing each row once it has been consumed"""
         assert self.grads != 'none'
+        reset = 0 if (keep or self.compact) else _RESET_V_REC
+        if keep and not self.compact:
+            self._v_rec_dirty = True
         check(lib.gsx_raster_bwd(_p(self.rec), self.CH, _p(self.backgrounds), _p(self.offsets), _p(self.flat),
                                  self.capacity, 1, self.C, self.W, self.H, self.tile_w, self.tile_h, _p(self.alphas),
                                  _p(self.last_ids), _p(self.v_render), None, _p(self.v_rec), None, _p(self.launch_order),
@@ -404,7 +435,7 @@ class RenderPlan:
         if self.grads == 'pose' and self.front:
             check(lib.gsx_front_pose_bwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C,
                                          self.W, self.H, self.eps2d, self.near, self.far,
-                                         self.flags | (_COMPACT if self.compact else 0), vr, self.capacity,
+                                         self.flags | reset | (_COMPACT if self.compact else 0), vr, self.capacity,
                                          _p(self.isect_ws), self.isect_ws.numel(), _p(self.pose_ws), st),
                   "gsx_front_pose_bwd")
             return
@@ -414,7 +445,7 @@ class RenderPlan:
             v = self.v_map
             outs = (_p(v[0]), _p(v[1]), _p(v[2]), None, _p(v[3]), _p(v[4]), _p(v[5]))
         check(lib.gsx_project_bwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
-                                  self.H, self.eps2d, self.near, self.far, self.flags | _VIEW_PARTIALS, _p(self.radii),
+                                  self.H, self.eps2d, self.near, self.far, self.flags | _VIEW_PARTIALS | reset, _p(self.radii),
                                   vr, 12, None, vr + 8, 12, None, _p(m[3]), _p(m[4]), _p(m[5]), vr, *outs,
                                   _p(self.pose_ws), self.pose_ws.numel(), st), "gsx_project_bwd")
 
@@ -829,7 +860,7 @@ class MappingStep:
         return (self.r is None or self.r.matches(splats)) and len(window) == self.Cw and \
             all(a is b for a, b in zip(window, self.window)) and int(splats.means.shape[0]) == self.N
 
-    def enqueue_render_backward(self, st: int):
+    def enqueue_render_backward(self, st: int, keep: bool = False):
         """render + loss + backward of this rank's cameras: fills the bucket (map gradients, counts source, pose rows)"""
         conf = self.conf
         if self.world > 1:
@@ -865,7 +896,7 @@ class MappingStep:
         check(lib.gsx_map_loss(_p(r.render), _p(r.alphas), _p(self.gt), _p(self.exposure), Cl, H, W, r.CH, r.depth_index,
                                r.betas_index, mode, w_photo / denom, w_tv, 0.4, _p(ssim_grad), None, _p(r.v_render),
                                None, _p(self.map_ws), self.map_ws.numel(), st), "gsx_map_loss")
-        r.backward(st)
+        r.backward(st, keep)
         if any(self.learnable[i] for i in self.mine):
             check(lib.gsx_pose_zhou_bwd_partials(Cl, self._Rt, self._dR, self._dt, self._flags, _p(r.pose_ws),
                                                  r.pose_blocks, None, self._vdR, self._vdt, st),
@@ -935,6 +966,8 @@ class MappingStep:
         if graphed and (not self.graph.captured or (self.r is not None and self.r.stale)):
             self.prepare()
         st = current_stream_ptr(self.dev)
+        if self.r is not None:
+            self.r.clean(st)                                 # (only after a render_backward(): its gradient records)
         if self.world == 1:
             if graphed:
                 self.graph.launch(st)
@@ -971,7 +1004,8 @@ class MappingStep:
             check(lib.gsx_pose_zhou_fwd(self.r.C, self._Rt, self._dR, self._dt, self._flags, _p(self.r.viewmats), st),
                   "gsx_pose_zhou_fwd")
             self.r.probe()
-        self.enqueue_render_backward(st)
+        # the gradient records stay as accumulated (densification reads means2d.grad out of them); the next step() cleans up
+        self.enqueue_render_backward(st, keep=True)
         self.reduce()
         return self.out2[0], self.out2[1]
 

@@ -50,6 +50,9 @@ extern "C" {
                                      consumer (gsx_track_opt_tail) and skip the finishing launch; v_viewmats is ignored */
 #define GSX_PROJ_SKIP_CULLED 16   /* gsx_front_fwd only: rows of culled (camera, Gaussian) pairs get radii = 0 and
                                      tiles_per_gauss = 0 and nothing else (nobody reads them in a pose-only closure) */
+#define GSX_PROJ_RESET_V_REC 64   /* gsx_project_bwd / gsx_front_pose_bwd: every gradient-record row is zeroed right after it has
+                                     been read, so the buffer is all zeros again when the launch ends and the next forward need
+                                     not clear it (a third of what the projection writes); needs the 12-float record rows */
 #define GSX_PROJ_COMPACT 32       /* gsx_front_fwd / gsx_front_pose_bwd: rec and v_rec hold one row per visible INSTANCE, indexed
                                      by its slot ((c * R + row) * slots_per_segment + position, gsx_front_layout) instead of one
                                      row per flatten id, and flatten_ids carries slots.  Slots are assigned in flatten-id order,

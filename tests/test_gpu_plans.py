@@ -165,9 +165,14 @@ def test_mapping_step_plan_matches_autograd_step(dev):
     out = plan.as_output()
     assert out.means2d.grad.shape == (3, n, 2) and out.depthmaps.shape == (3, H, W) and out.radii.shape == (3, n)
     assert torch.equal(out.radii, ba.last_outputs.radii)
+    # render_backward() keeps the gradient records for the densification to read ...
+    ref_g = ba.last_outputs.means2d.grad
+    assert float((out.means2d.grad - ref_g).abs().max()) < 2e-3 * float(ref_g.abs().max())
     # the update: one graph replay from the same start (the eager render_backward above did not touch the parameters)
     plan.step()
     torch.cuda.synchronize()
+    # ... a step() consumes them: every row the projection backward read is zero again (no forward clears them)
+    assert float(plan.r.v_rec.abs().max()) == 0.0
     assert plan.graph.captured and plan.capacity_ok()
     for k in grads_a:
         a, b = getattr(sa, k), getattr(sb, k)
@@ -242,7 +247,8 @@ def test_fused_front_equals_projection_plus_bin_sort(dev, n, n_cams, grads):
         r.viewmats.copy_(viewmats.to(dev))
         r.probe()
         if r.v_rec is not None:
-            r.v_rec.fill_(7.0)                              # the forward must clear the rows it will accumulate into
+            r.v_rec.fill_(7.0)                              # left behind by a backward(keep=True): the forward must clear
+            r._v_rec_dirty = True                           # the rows it will accumulate into
         r.forward(current_stream_ptr(dev))
         torch.cuda.synchronize()
         assert r.check_capacity()
@@ -387,7 +393,7 @@ def test_balanced_track_closure_equals_identity_order(dev):
         c.r.forward(st, track_loss=(c.img, c.exposure, 1.0 / denom, c.loss_rows))
         c.r.backward(st)
         torch.cuda.synchronize()
-        return (c.loss_rows.sum(0).clone(), c.r.v_render.clone(), c.r.v_rec.clone(),
+        return (c.loss_rows.sum(0).clone(), c.r.v_render.clone(), None,
                 c.r.pose_ws.view(torch.float32)[:c.r.pose_blocks * 12].clone())
 
     a = once()
@@ -399,6 +405,4 @@ def test_balanced_track_closure_equals_identity_order(dev):
     b = once()
     assert torch.equal(a[1], b[1])                                        # per-pixel results do not depend on the order
     torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=1e-6)
-    scale = float(a[2].abs().max())
-    assert float((a[2] - b[2]).abs().max()) < 1e-4 * scale                # float atomics in another order
     assert float((a[3] - b[3]).abs().max()) < 1e-4 * float(a[3].abs().max()) + 1e-12
