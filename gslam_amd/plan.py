@@ -260,7 +260,7 @@ class RenderPlan:
         """sizes the tile lists from the current map and poses with ONE synchronous read of sum(tiles_per_gauss) (an upper
         bound of M that the projection produces anyway); later drift is caught by check_capacity()"""
         st = current_stream_ptr(self.dev) if stream_ptr is None else stream_ptr
-        self._project(st)
+        self._project(st, tiles=True)
         if stream_ptr is not None:
             check(lib.gsx_stream_synchronize(st), "gsx_stream_synchronize")
         m = int(self.tiles.sum().item())
@@ -306,6 +306,10 @@ class RenderPlan:
         if self.v_rec is not None:
             means2d = self.means2d.view(self.C, self.N, 2)
             means2d.grad = self.v_rec[..., 0:2]
+        if not self.front:
+            # the projection of a render leaves tiles_per_gauss out (16 MB at 500 k x 8 that only this view reads)
+            check(lib.gsx_isect_count(_p(self.means2d), _p(self.radii), self.C * self.N, self.tile_w, self.tile_h,
+                                      _p(self.tiles), current_stream_ptr(self.dev)), "gsx_isect_count")
         out = RasterizationOutput(
             rgbs=self.render[..., :3], alphas=self.alphas, tile_width=self.tile_w, tile_height=self.tile_h,
             tiles_per_gauss=self.tiles, isect_offsets=self.offsets[:-1].view(self.C, self.tile_h, self.tile_w),
@@ -343,11 +347,12 @@ class RenderPlan:
             check(lib.gsx_zero_words(_p(self.v_rec), self.v_rec.numel(), st), "gsx_zero_words")
             self._v_rec_dirty = False
 
-    def _project(self, st: int):
+    def _project(self, st: int, tiles: bool = False):
+        """tiles: also write tiles_per_gauss [C,N] (the capacity probe sums it; a render does not need it)"""
         m = self.map
         check(lib.gsx_project_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                   self.H, self.eps2d, self.near, self.far, 0.0, self.flags, _p(self.radii),
-                                  _p(self.means2d), _p(self.depths), None, None, _p(self.tiles), self.tile_w,
+                                  _p(self.means2d), _p(self.depths), None, None, _p(self.tiles) if tiles else None, self.tile_w,
                                   self.tile_h, _p(m[3]), _p(m[4]), _p(m[5]), _p(self.rec), _p(self.vis_count),
                                   self._clear_ptr(), st), "gsx_project_fwd")
 
