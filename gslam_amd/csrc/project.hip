@@ -183,8 +183,14 @@ __global__ __launch_bounds__(PBWD_THREADS) void project_bwd_kernel(
                 const float4 *r4 = reinterpret_cast<const float4 *>(v_rec + idx * 12);
                 const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2];
                 if (flags & GSX_PROJ_RESET_V_REC) {             // consumed: the row goes back to zero for the next backward
-                    float4 *w4 = const_cast<float4 *>(r4);
-                    w4[0] = w4[1] = w4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    // (a visible pair the rasteriser never reached - every pixel under it saturated before - is zero already)
+                    const unsigned any = (__float_as_uint(q0.x) | __float_as_uint(q0.y) | __float_as_uint(q0.z) | __float_as_uint(q0.w)) |
+                                         (__float_as_uint(q1.x) | __float_as_uint(q1.y) | __float_as_uint(q1.z) | __float_as_uint(q1.w)) |
+                                         (__float_as_uint(q2.x) | __float_as_uint(q2.y) | __float_as_uint(q2.z) | __float_as_uint(q2.w));
+                    if (any << 1) {
+                        float4 *w4 = const_cast<float4 *>(r4);
+                        w4[0] = w4[1] = w4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
                 row[0] = q0.x; row[1] = q0.y; row[2] = q0.z; row[3] = q0.w; row[4] = q1.x; row[5] = q1.y; row[6] = q1.z;
                 row[7] = q1.w; row[8] = q2.x; row[9] = q2.y; row[10] = q2.z; row[11] = q2.w;
