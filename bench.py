@@ -82,7 +82,7 @@ class StageTimer:
     """Times every C-ABI launch with HIP events on the stream the kernels are launched on (torch's current stream: the
     instrumented passes issue their plans' launches there)."""
     STAGES = ("gsx_pose_zhou_fwd", "gsx_project_fwd", "gsx_isect_bin_sort", "gsx_front_fwd", "gsx_front_pose_bwd",
-              "gsx_raster_fwd", "gsx_raster_fwd_track_loss", "gsx_ssim_fwd",
+              "gsx_raster_fwd", "gsx_raster_fwd_track_loss", "gsx_raster_track_fused", "gsx_ssim_fwd",
               "gsx_ssim_bwd", "gsx_map_loss", "gsx_raster_bwd", "gsx_project_bwd", "gsx_pose_zhou_bwd_partials",
               "gsx_isotropic_loss_acc", "gsx_loss_finish", "gsx_counters_add", "gsx_adam_multi_steps",
               "gsx_adam_multi_steps_decay", "gsx_track_opt_tail")
@@ -157,7 +157,7 @@ def in_graph_launch_us(plan, stage, resets, n_closures, frames=3):
     from gslam_amd.plan import HipGraph
     lib = _lib.lib
     fn = getattr(lib, stage)
-    scratch = torch.zeros_like(plan.r.v_rec) if stage == "gsx_raster_bwd" else None
+    scratch = torch.zeros_like(plan.r.v_rec) if stage in ("gsx_raster_bwd", "gsx_raster_track_fused") else None
     torch.cuda.synchronize()
 
     def twice(*a):
@@ -212,6 +212,8 @@ def algorithmic_bytes(N, C, M, P, CH, T):
         # forward + tracking loss in its epilogue: reads the frame (12 B/px), writes v_render instead of the render
         "gsx_raster_fwd_track_loss": M * (28 + 4 * CH) + P * (4 * CH + 8 + 12) + C * N * 4,
         "gsx_raster_bwd": P * (4 * CH + 12) + M * (28 + 4 * CH) + C * N * (24 + 4 * CH),
+        # forward + tracking loss + backward of a tile in one launch: the images between them stay in registers
+        "gsx_raster_track_fused": 2 * M * (28 + 4 * CH) + P * 12 + C * N * 4 + C * N * (24 + 4 * CH),
         "gsx_project_bwd": C * N * (40 + 28 + 24) + N * 40 + C * 64,
         "gsx_ssim_fwd": 72 * P,
         "gsx_ssim_bwd": 72 * P,

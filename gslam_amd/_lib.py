@@ -98,6 +98,7 @@ PROTOTYPES = {
     "gsx_zero_words": (i32, [vp, i64, vp]),
     "gsx_raster_fwd_track_loss": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gsx_tile_balance": (i32, [vp, i64, f32, f32, i32, vp, vp]),
+    "gsx_raster_track_fused": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gsx_front_workspace_bytes": (i64, [i64, i64, i32, i32, i64]),
     "gsx_front_rows": (i64, [i64, i64, i32, i32]),
     "gsx_front_layout": (i32, [i64, i64, i32, i32, i64, C.POINTER(i64)]),

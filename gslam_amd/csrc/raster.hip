@@ -390,6 +390,25 @@ extern "C" int gsx_raster_fwd_track_loss(const float *rec, const float *backgrou
     return GSX_OK;
 }
 
+extern "C" int gsx_raster_track_fused(const float *rec, const float *backgrounds, const int32_t *offsets,
+                                      const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
+                                      const float *gt, const float *exposure, float w_photo, float *alphas,
+                                      int32_t *last_ids, float *v_render, float *loss_rows, float *v_rec,
+                                      const int32_t *tile_order, int32_t *tile_work, void *stream) {
+    GSX_CHECK_ARG(offsets && gt && exposure && loss_rows && v_rec && C >= 1 && W > 0 && H > 0);
+    GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31) && (M == 0 || (rec && flatten_ids)));
+    const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
+    const int64_t T = C * tile_w * tile_h;
+    GSX_CHECK_ARG(T < ((int64_t)1 << 31));
+    TrackLossArgs la;
+    la.gt = gt; la.exposure = exposure; la.w_photo = w_photo; la.v_render = v_render; la.rows = loss_rows;
+    la.tile_work = tile_work;
+    hipLaunchKernelGGL((raster_track_fused_kernel<12>), dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, rec, backgrounds,
+                       offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas, last_ids, v_rec, tile_order, la);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
 extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
                               const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
                               int tile_w, int tile_h, const float *alphas, const int32_t *last_ids,

@@ -393,6 +393,24 @@ class RenderPlan:
     def launch_order(self):
         return self.balanced_order if self.balanced_order is not None else self.tile_order
 
+    def forward_track_fused(self, st: int, track_loss):
+        """front + gsx_raster_track_fused: the forward rasteriser, the tracking loss and the geometry-only rasteriser backward
+        of every tile in one launch (pose-only CH = 4 plans); follow with backward(st, rasterised=True)"""
+        assert self.CH == 4 and self.geom_only and self.n_touched is None and self.capacity > 0
+        if self.front:
+            self._front(st)
+        else:
+            self._project(st)
+            check(lib.gsx_isect_bin_sort(_p(self.means2d), _p(self.radii), _p(self.depths), self.N, self.C, self.tile_w,
+                                         self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status),
+                                         None, _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
+                                         self.isect_ws.numel(), st), "gsx_isect_bin_sort")
+        gt, exposure, w_photo, rows = track_loss
+        check(lib.gsx_raster_track_fused(_p(self.rec), _p(self.backgrounds), _p(self.offsets), _p(self.flat), self.capacity,
+                                         1, self.C, self.W, self.H, _p(gt), _p(exposure), float(w_photo), None, None, None,
+                                         _p(rows), _p(self.v_rec), _p(self.launch_order), _p(self.tile_work), st),
+              "gsx_raster_track_fused")
+
     def forward(self, st: int, track_loss=None):
         """track_loss = (gt [C,H,W,3], exposure [C,2], w_photo, loss_rows [T,6]): the forward rasteriser evaluates the
         active-nerf tracking loss in its epilogue (CH = 4 plans): self.v_render and the loss rows come out of the same
@@ -423,18 +441,20 @@ class RenderPlan:
                                  _p(self.render), _p(self.alphas), _p(self.last_ids), _p(self.n_touched),
                                  _p(self.tile_order), st), "gsx_raster_fwd")
 
-    def backward(self, st: int, keep: bool = False):
+    def backward(self, st: int, keep: bool = False, rasterised: bool = False):
         """from ``self.v_render`` (filled by the loss launch) to the pose partials in ``self.pose_ws`` and, for 'full', the
         six map gradients (overwritten, summed over cameras inside).  keep: leave the gradient records as accumulated
-        (``as_output().means2d.grad`` reads them: densification) instead of zeroing each row once it has been consumed"""
+        (``as_output().means2d.grad`` reads them: densification) instead of zeroing each row once it has been consumed.
+        rasterised: the gradient records are complete already (forward_track_fused ran the rasteriser's backward)"""
         assert self.grads != 'none'
         reset = 0 if (keep or self.compact) else _RESET_V_REC
         if keep and not self.compact:
             self._v_rec_dirty = True
-        check(lib.gsx_raster_bwd(_p(self.rec), self.CH, _p(self.backgrounds), _p(self.offsets), _p(self.flat),
-                                 self.capacity, 1, self.C, self.W, self.H, self.tile_w, self.tile_h, _p(self.alphas),
-                                 _p(self.last_ids), _p(self.v_render), None, _p(self.v_rec), None, _p(self.launch_order),
-                                 1 if self.geom_only else 0, st), "gsx_raster_bwd")
+        if not rasterised:
+            check(lib.gsx_raster_bwd(_p(self.rec), self.CH, _p(self.backgrounds), _p(self.offsets), _p(self.flat),
+                                     self.capacity, 1, self.C, self.W, self.H, self.tile_w, self.tile_h, _p(self.alphas),
+                                     _p(self.last_ids), _p(self.v_render), None, _p(self.v_rec), None,
+                                     _p(self.launch_order), 1 if self.geom_only else 0, st), "gsx_raster_bwd")
         m = self.map
         vr = self.v_rec.data_ptr()
         if self.grads == 'pose' and self.front:
@@ -523,9 +543,12 @@ class TrackClosure:
     PoseZhou backward, loss finish, optimiser advance).  'host': stops at the gradients (``g_dt, g_dR, g_exposure``,
     ``loss``) for an optimiser on the host."""
 
-    def __init__(self, splats, camera, tail: str = 'fused'):
+    def __init__(self, splats, camera, tail: str = 'fused', fuse_raster: bool = True):
+        """fuse_raster (fused tail only): forward rasteriser, loss and rasteriser backward as ONE launch
+        (gsx_raster_track_fused); False keeps them as two (the independent path the tests compare against)"""
         assert tail in ('fused', 'split', 'host')
         self.tail = tail
+        self.fuse_raster = bool(fuse_raster) and tail == 'fused'
         self.camera = camera
         self.r = RenderPlan(splats, 1, camera.width, camera.height, render_depth=False, grads='pose',
                             Ks=camera.intrinsics)
@@ -584,8 +607,12 @@ class TrackClosure:
         r = self.r
         if self.tail == 'fused':
             denom = r.C * r.H * r.W
-            r.forward(st, track_loss=(self.img, self.exposure, 1.0 / denom, self.loss_rows))
-            r.backward(st)
+            if self.fuse_raster:
+                r.forward_track_fused(st, (self.img, self.exposure, 1.0 / denom, self.loss_rows))
+                r.backward(st, rasterised=True)
+            else:
+                r.forward(st, track_loss=(self.img, self.exposure, 1.0 / denom, self.loss_rows))
+                r.backward(st)
             check(lib.gsx_track_opt_tail(_p(self.state), _p(r.pose_ws), r.pose_blocks, _p(self.slots.Rt), _p(self.slots.dt),
                                          _p(self.slots.dR), _p(self.exposure), None, None, _p(r.viewmats),
                                          _p(self.loss_rows), r.T, 1.0 / denom, st), "gsx_track_opt_tail")

@@ -202,6 +202,14 @@ int gsx_raster_fwd_track_loss(const float *rec, const float *backgrounds, const 
                               int32_t *last_ids, float *v_render, float *loss_rows, const int32_t *tile_order,
                               int32_t *tile_work /*[T][2] nullable: (chunks, trips) per tile, the weights of gsx_tile_balance*/,
                               void *stream);
+/* K8 + tracking loss + geometry-only K9 of the tracking closure in ONE launch: gsx_raster_fwd_track_loss followed by
+ * gsx_raster_bwd(CH = 4, geometry_only = 1) with the same arguments, tile by tile inside one workgroup - colour, transmittance,
+ * last entry and d loss / d render stay in registers.  v_rec [rows,12] accumulates (cleared by the caller / the projection);
+ * alphas, last_ids and v_render are optional outputs (NULL: not written). */
+int gsx_raster_track_fused(const float *rec, const float *backgrounds, const int32_t *offsets, const int32_t *flatten_ids,
+                           int64_t M, int offsets_has_end, int64_t C, int W, int H, const float *gt, const float *exposure,
+                           float w_photo, float *alphas, int32_t *last_ids, float *v_render, float *loss_rows, float *v_rec,
+                           const int32_t *tile_order, int32_t *tile_work, void *stream);
 /* Launch order for the rasteriser kernels of a render whose T workgroups are all resident at once (T <= 2048): deals the
  * tiles into n_cus groups of near-equal weight (weight = trips + chunk_cost * chunks of tile_work, as measured by an earlier
  * gsx_raster_fwd_track_loss of a nearby pose) and writes tile_order [T] so that the workgroups i, i + n_cus, i + 2 n_cus, ...

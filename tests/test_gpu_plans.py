@@ -406,3 +406,56 @@ def test_balanced_track_closure_equals_identity_order(dev):
     assert torch.equal(a[1], b[1])                                        # per-pixel results do not depend on the order
     torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=1e-6)
     assert float((a[3] - b[3]).abs().max()) < 1e-4 * float(a[3].abs().max()) + 1e-12
+
+
+def test_fused_raster_launch_equals_forward_then_backward(dev):
+    """gsx_raster_track_fused (forward rasteriser + tracking loss + geometry-only backward of a tile in one workgroup) against
+    gsx_raster_fwd_track_loss followed by gsx_raster_bwd: same statements in the same order - tile work bit for bit, loss rows
+    to the last bits, gradient records and pose partials to the order of the float atomics"""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.plan import TrackClosure, current_stream_ptr
+    from gslam_amd.primitives import Camera
+    from gslam_amd.synthetic import make_intrinsics, make_scene, make_viewmat
+    W, H = 640, 480
+    sc = make_scene(80000, 6)
+    sc["scales"] = sc["scales"] + 0.4
+    splats = GaussianSplattingData.from_dict(sc, dev)
+    cam = Camera(make_intrinsics(W, H).to(dev), H, W)
+    img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(8)).to(dev)
+    st = current_stream_ptr(dev)
+    res = []
+    for fuse in (False, True):
+        c = TrackClosure(splats, cam, fuse_raster=fuse)
+        assert c.fuse_raster == fuse
+        c.load(make_viewmat(2.0).to(dev), img, torch.tensor([0.02, -0.01], device=dev))
+        c.r.probe()
+        denom = H * W
+        tl = (c.img, c.exposure, 1.0 / denom, c.loss_rows)
+        if fuse:
+            c.r.forward_track_fused(st, tl)
+            torch.cuda.synchronize()
+            v_rec = c.r.v_rec.clone()
+            c.r.backward(st, rasterised=True)
+        else:
+            c.r.forward(st, track_loss=tl)
+            check_v = None
+            from gslam_amd._lib import check, lib, ptr
+            r = c.r
+            check(lib.gsx_raster_bwd(ptr(r.rec), r.CH, ptr(r.backgrounds), ptr(r.offsets), ptr(r.flat), r.capacity, 1, r.C, r.W,
+                                     r.H, r.tile_w, r.tile_h, ptr(r.alphas), ptr(r.last_ids), ptr(r.v_render), None,
+                                     ptr(r.v_rec), None, ptr(r.launch_order), 1, st), "gsx_raster_bwd")
+            torch.cuda.synchronize()
+            v_rec = c.r.v_rec.clone()
+            c.r.backward(st, rasterised=True)
+        torch.cuda.synchronize()
+        assert c.r.check_capacity()
+        res.append((c.loss_rows.clone(), c.r.tile_work.clone(), v_rec,
+                    c.r.pose_ws.view(torch.float32)[:c.r.pose_blocks * 12].clone(), c.r.flat[:c.r.last_M].clone()))
+    a, b = res
+    assert torch.equal(a[4], b[4])                                        # same tile lists (same front)
+    # the same statements, but compiled inside another kernel (fused multiply-adds are contracted by context): last bits
+    assert float((a[0] - b[0]).abs().max()) < 2e-6 * float(a[0].abs().max())
+    assert torch.equal(a[1], b[1])                                        # work counters
+    assert float(a[2].abs().max()) > 0
+    assert float((a[2] - b[2]).abs().max()) < 1e-4 * float(a[2].abs().max())
+    assert float((a[3] - b[3]).abs().max()) < 1e-4 * float(a[3].abs().max()) + 1e-12
