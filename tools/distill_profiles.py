@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-dom = sys.argv[2] if len(sys.argv) > 2 else "raster_bwd"
+dom = sys.argv[2] if len(sys.argv) > 2 else None       # default: the device kernel behind the bench line's roofline.kernel
 g = lambda *p: os.path.join(ROOT, "gpurun_out", *p)
 out = lambda n: os.path.join(ROOT, "profiles", n)
 
@@ -44,10 +44,13 @@ with open(out(f"{tag}_pmc_hbm_traffic.csv"), "w", newline="") as f:
                 "hbm_bytes_per_launch=(2*FETCH+WRITE)*1024"])
     for r in rows:
         w.writerow([r[0][:120], f"{r[1]:.1f}", f"{r[2]:.1f}", f"{r[3]:.0f}"])
+bench = json.loads(line)
+if dom is None:
+    dom = {"gsx_raster_track_fused": "raster_track_fused", "gsx_raster_bwd": "raster_bwd",
+           "gsx_raster_fwd_track_loss": "raster_fwd"}.get(bench.get("roofline", {}).get("kernel", ""), "raster_bwd")
 hit = [r for r in rows if dom in r[0] and "4q<4" in r[0]] or [r for r in rows if dom in r[0]]
 if hit:
     k, fk, wk, b = hit[0]
-    bench = json.loads(line)
     tj = {"workload_gaussians": bench["config"]["gaussians"], "stage": bench["roofline"]["kernel"], "device_kernel": k[:100],
           "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": int(b),
           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/prof_closure.py --eager "
