@@ -543,7 +543,7 @@ class TrackClosure:
     PoseZhou backward, loss finish, optimiser advance).  'host': stops at the gradients (``g_dt, g_dR, g_exposure``,
     ``loss``) for an optimiser on the host."""
 
-    def __init__(self, splats, camera, tail: str = 'fused', fuse_raster: bool = True):
+    def __init__(self, splats, camera, tail: str = 'fused', fuse_raster: bool = True, front: Optional[bool] = None):
         """fuse_raster (fused tail only): forward rasteriser, loss and rasteriser backward as ONE launch
         (gsx_raster_track_fused); False keeps them as two (the independent path the tests compare against)"""
         assert tail in ('fused', 'split', 'host')
@@ -551,7 +551,7 @@ class TrackClosure:
         self.fuse_raster = bool(fuse_raster) and tail == 'fused'
         self.camera = camera
         self.r = RenderPlan(splats, 1, camera.width, camera.height, render_depth=False, grads='pose',
-                            Ks=camera.intrinsics)
+                            Ks=camera.intrinsics, front=front)
         dev = self.r.dev
         self.dev = dev
         self.slots = _PoseSlots(1, dev, [True])

@@ -408,7 +408,8 @@ def test_balanced_track_closure_equals_identity_order(dev):
     assert float((a[3] - b[3]).abs().max()) < 1e-4 * float(a[3].abs().max()) + 1e-12
 
 
-def test_fused_raster_launch_equals_forward_then_backward(dev):
+@pytest.mark.parametrize("front", [True, False])
+def test_fused_raster_launch_equals_forward_then_backward(dev, front):
     """gsx_raster_track_fused (forward rasteriser + tracking loss + geometry-only backward of a tile in one workgroup) against
     gsx_raster_fwd_track_loss followed by gsx_raster_bwd: same statements in the same order - tile work bit for bit, loss rows
     to the last bits, gradient records and pose partials to the order of the float atomics"""
@@ -425,8 +426,8 @@ def test_fused_raster_launch_equals_forward_then_backward(dev):
     st = current_stream_ptr(dev)
     res = []
     for fuse in (False, True):
-        c = TrackClosure(splats, cam, fuse_raster=fuse)
-        assert c.fuse_raster == fuse
+        c = TrackClosure(splats, cam, fuse_raster=fuse, front=front)
+        assert c.fuse_raster == fuse and c.r.front == front
         c.load(make_viewmat(2.0).to(dev), img, torch.tensor([0.02, -0.01], device=dev))
         c.r.probe()
         denom = H * W
@@ -449,7 +450,8 @@ def test_fused_raster_launch_equals_forward_then_backward(dev):
             c.r.backward(st, rasterised=True)
         torch.cuda.synchronize()
         assert c.r.check_capacity()
-        res.append((c.loss_rows.clone(), c.r.tile_work.clone(), v_rec,
+        work = c.r.tile_work.clone() if c.r.tile_work is not None else torch.zeros(1)
+        res.append((c.loss_rows.clone(), work, v_rec,
                     c.r.pose_ws.view(torch.float32)[:c.r.pose_blocks * 12].clone(), c.r.flat[:c.r.last_M].clone()))
     a, b = res
     assert torch.equal(a[4], b[4])                                        # same tile lists (same front)
