@@ -147,6 +147,7 @@ class RenderPlan:
     of all six map arrays written to ``self.v_*`` / the tensors given in ``grad_out``, plus the pose partials)."""
 
     GROW = 1.5
+    ORDER_MAX_PER_TILE = 1000       # heaviest-first launch order (by list length) below this capacity per tile
 
     def __init__(self, splats, n_cams: int, width: int, height: int, *, render_depth: bool, grads: str = 'pose',
                  Ks: Optional[torch.Tensor] = None, capacity: Optional[int] = None, need_n_touched: bool = False,
@@ -248,7 +249,7 @@ class RenderPlan:
         dev = self.dev
         self.flat = torch.empty(cap, dtype=torch.int32, device=dev)
         # heaviest-first launch order pays off while the tile lists are short (see rasterization.rasterization)
-        self.tile_order = torch.empty(self.T, dtype=torch.int32, device=dev) if cap < 1000 * self.T else None
+        self.tile_order = torch.empty(self.T, dtype=torch.int32, device=dev) if cap < self.ORDER_MAX_PER_TILE * self.T else None
         if self.front:
             nbytes = int(lib.gsx_front_workspace_bytes(self.N, self.C, self.tile_w, self.tile_h, cap))
         else:

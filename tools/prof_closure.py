@@ -21,8 +21,12 @@ def main():
     ap.add_argument("--front", type=int, default=-1, help="1 / 0 force the fused front on / off")
     ap.add_argument("--ba-front", type=int, default=-1, help="1 / 0 force the fused front of the BA plan on / off")
     ap.add_argument("--no-balance", action="store_true", help="identity launch order of the rasteriser kernels (A/B)")
+    ap.add_argument("--order-per-tile", type=int, default=None, help="RenderPlan.ORDER_MAX_PER_TILE (A/B)")
     args = ap.parse_args()
     import bench
+    if args.order_per_tile is not None:
+        import gslam_amd.plan as P2
+        P2.RenderPlan.ORDER_MAX_PER_TILE = args.order_per_tile
     if args.no_balance:
         import gslam_amd.plan as P0
         P0.RenderPlan.enable_balance = lambda self: False
