@@ -5,7 +5,7 @@
 500 k Gaussians on ONE GPU, synthetic TUM-shape sequence, the reference's iteration counts:
 
   * a "step" is one tracked frame: 10 Adam closures + one strong-Wolfe L-BFGS step of <= 25 (+1) closures on the pose and
-    exposure (gslam/frontend.py:604-662) = 36 launches of the captured tracking closure (C = 1 render forward, active-nerf
+    exposure (gslam/frontend.py:604-662) = 36 replays of the captured tracking closure, one graph launch (C = 1 render forward, active-nerf
     loss, backward to the pose; the optimiser is a device state machine, no read-back), plus the frame's output render
     (frontend.py:228-231, forward only, RGB + depth);
   * every 5th frame is a keyframe: the backend runs 15 bundle-adjustment iterations over the last 8 keyframes
@@ -317,7 +317,7 @@ def run_headline(args, dev):
                 receive(frontend_map, pending[0])
                 pending = None
                 n_sync += 1
-            tracker.track(f, sync=False)                             # 36 graph launches + report, no read-back
+            tracker.track(f, sync=False)                             # one graph launch (36 closures) + report, no read-back
             if "no-out" not in diag:
                 out_render.viewmats.copy_(tracker.plan.r.viewmats)   # the tracked pose (left there by the closure's tail)
                 out_graph.launch()
