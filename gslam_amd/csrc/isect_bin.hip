@@ -1290,6 +1290,13 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
 // left as one partial row per (front row, camera) for the consumer that finishes the pose backward (gsx_track_opt_tail /
 // gsx_pose_zhou_bwd_partials).
 constexpr int FPB_THREADS = 256;
+#ifndef GSX_FPB_SPLIT
+#define GSX_FPB_SPLIT 2
+#endif
+// a (row, camera) segment of instance records is shared by FPB_SPLIT workgroups: with one workgroup per row the launch had one
+// wavefront per SIMD and nothing to hide its gathers behind (11.1 us; 2: 9.9, 4: 10.1 and the tail's sum of the partial rows
+// +0.4, 8: 10.2 / +0.8)
+constexpr int FPB_SPLIT = GSX_FPB_SPLIT;
 
 __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
     const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
@@ -1304,7 +1311,7 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
     Cam cam;
     load_cam(viewmats, Ks, c, cam);
     float acc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int i = t; i < n; i += FPB_THREADS) {
+    for (int i = t + (int)blockIdx.z * FPB_THREADS; i < n; i += FPB_THREADS * FPB_SPLIT) {
         const int64_t idx = (int64_t)seg[i].id;
         const int64_t g = idx - (int64_t)c * N;
         if (g < 0 || g >= N) continue;                       // never from a sane front; keeps the gathers in range
@@ -1392,7 +1399,7 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < FPB_THREADS / 64; ++w) sum += s_part[w][t];
-        partials[((int64_t)row * C + c) * 12 + t] = sum;
+        partials[(((int64_t)row * FPB_SPLIT + blockIdx.z) * C + c) * 12 + t] = sum;
     }
 }
 
@@ -1511,7 +1518,7 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
 }
 
 extern "C" int64_t gsx_front_rows(int64_t N, int64_t C, int tile_w, int tile_h) {
-    return front_layout(N, C, tile_w, tile_h, 1).R;
+    return front_layout(N, C, tile_w, tile_h, 1).R * FPB_SPLIT;       // partial rows gsx_front_pose_bwd leaves
 }
 
 extern "C" int gsx_front_pose_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
@@ -1528,7 +1535,7 @@ extern "C" int gsx_front_pose_bwd(const float *means, const float *quats, const 
         return GSX_E_WORKSPACE;
     }
     const char *ws = (const char *)workspace;
-    hipLaunchKernelGGL(front_pose_bwd_kernel, dim3((unsigned)L.R, (unsigned)C), dim3(FPB_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(front_pose_bwd_kernel, dim3((unsigned)L.R, (unsigned)C, FPB_SPLIT), dim3(FPB_THREADS), 0, (hipStream_t)stream,
                        means, quats, scales, viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, flags, v_rec,
                        (const PreRec *)(ws + L.recs_off), (const int32_t *)(ws + L.ninst_off), L.R,
                        FRONT_THREADS * L.items, partials, (flags & GSX_PROJ_COMPACT) ? 1 : 0);

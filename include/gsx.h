@@ -170,7 +170,7 @@ int gsx_front_fwd(const float *means, const float *quats, const float *scales, c
 /* Pose gradient of a pose-only closure from the instance records gsx_front_fwd left in its workspace (same N, C, W, H,
  * M_cap): the pose part of gsx_project_bwd(v_means = NULL, flags | GSX_PROJ_VIEW_PARTIALS) over the visible instances
  * only.  v_rec [C,N,12]: the gradient records of gsx_raster_bwd (xy, conic and - with RENDER_DEPTH - depth columns read).
- * partials [gsx_front_rows(...)][C][12]: one partial row of d loss / d [R | t] per (front row, camera), to be summed by
+ * partials [gsx_front_rows(...)][C][12]: partial rows of d loss / d [R | t] (a few per front row and camera), to be summed by
  * gsx_track_opt_tail / gsx_pose_zhou_bwd_partials (n_blocks = gsx_front_rows). */
 int64_t gsx_front_rows(int64_t N, int64_t C, int tile_w, int tile_h);
 int gsx_front_pose_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
