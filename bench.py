@@ -321,7 +321,10 @@ def run_headline(args, dev):
             if "no-out" not in diag:
                 out_render.viewmats.copy_(tracker.plan.r.viewmats)   # the tracked pose (left there by the closure's tail)
                 out_graph.launch()
-            if (i + 1) % KF_EVERY == 0 and "no-ba" not in diag:
+            # every KF_EVERY-th frame is a keyframe; the phase puts the keyframes of the timed region at its frames 1, 6, 11, ...
+            # so that a region of K frames holds exactly K / KF_EVERY BA rounds and each of them has frames to run beside, as
+            # in the steady state (with the keyframe on the region's LAST frame a short run ends on a BA round running alone)
+            if (i - warmup) % KF_EVERY == 1 and "no-ba" not in diag:
                 # the backend's map is its own copy; its BA round only waits for the previous one and overlaps the
                 # tracking of the following frames
                 with torch.cuda.stream(map_stream):
