@@ -421,7 +421,8 @@ def run_headline(args, dev):
                 c.init_optimizer(N_ADAM, conf.pose_optim_lr, conf.lbfgs_history, MAX_EVAL)
             return reset
         # sample frames spread over the camera sweep of the timed sequence
-        samples = [frames[WINDOW + min(n_frames - 1, i)] for i in (1, 16, 31, 46, 61, 76, 91, 106)]
+        sample_ids = sorted(set(int(round(1 + k * (n_frames - 2) / 7.0)) for k in range(8)))
+        samples = [frames[WINDOW + i] for i in sample_ids]
         dom_us, closure_graph_us, Ms, per_sample = in_graph_launch_us(c, dom, [reset_to(fr) for fr in samples],
                                                                        closures_per_frame)
         M1 = int(sum(Ms) / len(Ms))
@@ -433,7 +434,7 @@ def run_headline(args, dev):
                             "timing": "HIP events on the launch stream around frames of 36 graph replays, with and without "
                                       "the launch duplicated in the captured closure; difference per closure",
                             "closure_us_in_graph": round(closure_graph_us, 2),
-                            "samples": {"frames_of_the_sequence": [1, 16, 31, 46, 61, 76, 91, 106], "n_isects": Ms,
+                            "samples": {"frames_of_the_sequence": sample_ids, "n_isects": Ms,
                                         "launch_us": [round(x, 2) for x in per_sample]},
                             "avg_launch_us_eager": round(stages[dom], 2),
                             "whole_closure_frac": line["closure"]["frac_of_hbm_peak"]}
