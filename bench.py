@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 N_ADAM, MAX_EVAL, KF_EVERY, BA_ITERS, WINDOW = 10, 25, 5, 15, 8     # frontend.py:651, torch LBFGS max_eval, backend.py:864,74,71
+SWEEP_FRAMES = 110      # frames of the synthetic sequence the default run covers (10 warm-up + 100): the roofline samples span them
 
 
 def parse():
@@ -214,8 +215,10 @@ def algorithmic_bytes(N, C, M, P, CH, T):
         # forward + tracking loss in its epilogue: reads the frame (12 B/px), writes v_render instead of the render
         "gsx_raster_fwd_track_loss": M * (28 + 4 * CH) + P * (4 * CH + 8 + 12) + C * N * 4,
         "gsx_raster_bwd": P * (4 * CH + 12) + M * (28 + 4 * CH) + C * N * (24 + 4 * CH),
-        # forward + tracking loss + backward of a tile in one launch: the images between them stay in registers
-        "gsx_raster_track_fused": 2 * M * (28 + 4 * CH) + P * 12 + C * N * 4 + C * N * (24 + 4 * CH),
+        # forward + tracking loss + backward of a tile in one launch: the images between them stay in registers and the
+        # per-intersection gather (id + record) is counted ONCE ("every array touched once": the backward re-reads it from
+        # the caches of the CU that ran the tile's forward)
+        "gsx_raster_track_fused": M * (28 + 4 * CH) + P * 12 + C * N * 4 + C * N * (24 + 4 * CH),
         "gsx_project_bwd": C * N * (40 + 28 + 24) + N * 40 + C * 64,
         "gsx_ssim_fwd": 72 * P,
         "gsx_ssim_bwd": 72 * P,
@@ -268,11 +271,17 @@ def run_headline(args, dev):
     from gslam_amd.synthetic import sequence_param
     frames, cam = make_frames(list(range(WINDOW)) + [sequence_param(i) for i in range(n_frames)], W, H, dev, gt_scene)
     del gt_scene
+
+    def sample_scene():
+        return GaussianSplattingData.from_dict(make_scene(N, 1), dev)
     keyframes = frames[:WINDOW]                             # pre-seeded window: BA runs at its full size from the start
     mailbox = MapMailbox()
     frontend_map, _ = receive(None, mailbox.publish(backend_map))      # what SYNC ships (backend.py:508-519)
     conf = TrackingConfig()
     for x in args.diag.split(","):
+        if x.startswith("cand:"):                           # cand:<rot>:<trans> (tuning runs of the candidate margins)
+            from gslam_amd.plan import TrackClosure as _TC
+            _TC.CAND_MARGINS = (float(x.split(":")[1]), float(x.split(":")[2]))
         if x.startswith("balance:"):                        # balance:<light_rate>:<chunk_cost> (tuning runs)
             from gslam_amd.plan import RenderPlan as _RP
             _RP.LIGHT_RATE, _RP.CHUNK_COST = float(x.split(":")[1]), float(x.split(":")[2])
@@ -293,7 +302,7 @@ def run_headline(args, dev):
     out_graph.capture(out_stream, out_render.forward)
     torch.cuda.synchronize()
 
-    diag = set(x for x in args.diag.split(",") if x)
+    diag = set(x for x in args.diag.split(",") if x and not x.startswith("cand:"))
     if "prio" in diag:
         lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
         print("priority range", lo, hi, file=sys.stderr)
@@ -373,6 +382,11 @@ def run_headline(args, dev):
         },
     }
 
+    if tracker.plan.r.candidates:
+        n_cand, mode, fell_back = tracker.plan.r.candidate_stats()
+        line["config"]["tracking_candidates"] = {
+            "per_frame_candidate_set": n_cand, "margins_rot_trans": list(tracker.plan.r.cand_margins),
+            "closures_of_the_last_frame_outside_the_margins": fell_back}
     if diag:
         line["INVALID"] = "diagnostic run with work left out: " + ",".join(sorted(diag))
     # ---- tracking alone / mapping alone (serial, for the breakdown) ---------------------------------------------------------
@@ -420,9 +434,16 @@ def run_headline(args, dev):
                 c.load(fr.pose().detach(), fr.img, fr.exposure_params)
                 c.init_optimizer(N_ADAM, conf.pose_optim_lr, conf.lbfgs_history, MAX_EVAL)
             return reset
-        # sample frames spread over the camera sweep of the timed sequence
-        sample_ids = sorted(set(int(round(1 + k * (n_frames - 2) / 7.0)) for k in range(8)))
-        samples = [frames[WINDOW + i] for i in sample_ids]
+        # sample frames spread over the camera sweep of the DEFAULT run (110 frames of the sequence), whatever --steps is:
+        # the same eight tile-list shapes for the driver's 20-frame run, the default run and the rocprofv3 trace under
+        # profiles/ (the samples are generated here, outside every timed region)
+        sample_ids = sorted(set(int(round(1 + k * (SWEEP_FRAMES - 2) / 7.0)) for k in range(8)))
+        samples = [frames[WINDOW + i] if i < n_frames else None for i in sample_ids]
+        missing = [i for i, fr in zip(sample_ids, samples) if fr is None]
+        if missing:
+            extra_frames, _ = make_frames([sequence_param(i) for i in missing], W, H, dev, sample_scene())
+            it = iter(extra_frames)
+            samples = [fr if fr is not None else next(it) for fr in samples]
         dom_us, closure_graph_us, Ms, per_sample = in_graph_launch_us(c, dom, [reset_to(fr) for fr in samples],
                                                                        closures_per_frame)
         M1 = int(sum(Ms) / len(Ms))
@@ -525,25 +546,54 @@ def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=F
     return res
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def cpu_baseline_tracking(N, W, H, budget_s=25.0):
-    """The oracle (oracle/gsx_oracle.c, scalar C, one host core) on the same work: tracking closures (C = 1 render forward
-    + backward to the pose at 500 k) and one camera of a BA iteration, bounded to ~25 s; frames/s extrapolated with the
-    iteration counts of the headline."""
+    """the CPU restatement of the render path (oracle/gsx_oracle.c - the reference has no CPU rasteriser of
+    its own) on ALL host cores this process may use (OpenMP build, oracle/_build/libgsx_oracle_f32_omp.so), core count and
+    CPU model stated: (i) BASELINE.json configs[0] - 10 k Gaussians, one 640x480 frame, forward only - median of >= 5 runs
+    after one warm-up; (ii) the headline's unit of work - tracking closures at 500 k (C = 1 render forward + backward to the
+    pose), bounded to ~25 s - extrapolated to frames/s with the headline's iteration counts.  Baseline only, never the target."""
     import numpy as np
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(cores)                # before libgomp initialises (first load of the OpenMP build)
     from oracle.oracle import Oracle
     from gslam_amd.synthetic import make_cameras, make_scene
-    o = Oracle(np.float32)
-    sc = {k: v.numpy() for k, v in make_scene(N, 0).items()}
+    o = Oracle(np.float32, threads=True)
     viewmats, Ks = make_cameras(1, W, H)
     viewmats, Ks = viewmats.numpy(), Ks.numpy()
+
+    def forward(sc):
+        return o.gslam_rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], viewmats, Ks,
+                                     W, H, render_mode="RGB", log_uncertainties=sc["log_uncertainties"],
+                                     backgrounds=np.zeros((1, 3), np.float32))
+
+    # (i) configs[0]
+    sc10 = {k: v.numpy() for k, v in make_scene(10_000, 0).items()}
+    forward(sc10)
+    t10 = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        forward(sc10)
+        t10.append(time.perf_counter() - t0)
+    t10.sort()
+    # (ii) the headline's closure
+    sc = {k: v.numpy() for k, v in make_scene(N, 0).items()}
     gt = np.random.default_rng(1).uniform(0, 1, (1, H, W, 3)).astype(np.float32)
     times = []
     t_start = time.perf_counter()
     while True:
         t0 = time.perf_counter()
-        out = o.gslam_rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], viewmats, Ks,
-                                    W, H, render_mode="RGB", log_uncertainties=sc["log_uncertainties"],
-                                    backgrounds=np.zeros((1, 3), np.float32))
+        out = forward(sc)
         v_render = np.zeros_like(out["render"])
         v_render[..., :3] = (out["rgbs"] - gt) * 1e-3
         v_render[..., 3:] = 1e-6
@@ -555,15 +605,20 @@ def cpu_baseline_tracking(N, W, H, budget_s=25.0):
         o.project_bwd(sc["means"], sc["quats"], scales, viewmats, Ks, W, H, out["radii"], vm,
                       np.zeros_like(out["depths"]), vc)
         times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_start + times[-1] > budget_s or len(times) >= 5:
+        if time.perf_counter() - t_start + times[-1] > budget_s or len(times) >= 9:
             break
     times.sort()
     t_c = times[len(times) // 2]
     # a BA camera costs at least a tracking closure (one more channel, SSIM, Adam on top): lower bound on the CPU time
     per_frame = (N_ADAM + MAX_EVAL + 1) * t_c + t_c + (BA_ITERS * WINDOW / KF_EVERY) * t_c
-    return {"value": round(1.0 / per_frame, 5), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{len(times)} tracking closures (render fwd + bwd to the pose, {N} Gaussians, {W}x{H}, C=1) timed on 1 "
-                      f"host core with oracle/gsx_oracle.c, median {t_c:.2f} s/closure; frames/s = 1 / ((36 + 1 + "
+    return {"value": round(1.0 / per_frame, 5), "unit": "frames/s", "cores": o.threads, "kind": "port",
+            "cpu_model": cpu_model(),
+            "config0_10k_forward_ms": round(t10[len(t10) // 2] * 1e3, 2),
+            "closure_500k_s": round(t_c, 4),
+            "sample": f"oracle/gsx_oracle.c built with OpenMP on {o.threads} host threads ({cpu_model()}): (i) BASELINE.json "
+                      f"configs[0], 10 k Gaussians, one {W}x{H} frame, forward only: median of {len(t10)} runs after 1 warm-up "
+                      f"= {t10[len(t10) // 2] * 1e3:.1f} ms; (ii) {len(times)} tracking closures (render fwd + bwd to the pose, "
+                      f"{N} Gaussians, {W}x{H}, C=1), median {t_c:.3f} s/closure; frames/s = 1 / ((36 + 1 + "
                       f"{BA_ITERS}*{WINDOW}/{KF_EVERY}) closures x that), a BA camera counted as one closure (lower bound)"}
 
 
@@ -603,7 +658,7 @@ def main():
             try:
                 line["cpu_baseline"] = cpu_baseline_tracking(N, W, H)
             except Exception as e:  # the baseline is informational; never lose the GPU number over it
-                line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port",
+                line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {e!r}"}
         print(json.dumps(line), flush=True)
         return

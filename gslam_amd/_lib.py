@@ -69,6 +69,11 @@ PROTOTYPES = {
                                          C.POINTER(i64), C.POINTER(f32), f32, f32, f32, C.POINTER(vp), i32, vp, i32, f32,
                                          vp]),
     "gsx_counters_add": (i32, [i32, C.POINTER(vp), i64, vp]),
+    "gsx_adam_multi_steps_gated": (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                         C.POINTER(i64), C.POINTER(f32), f32, f32, f32, C.POINTER(vp), i32, vp, i32, f32,
+                                         vp, vp]),
+    "gsx_counters_add_gated": (i32, [i32, C.POINTER(vp), i64, vp, vp]),
+    "gsx_status_flag": (i32, [vp, i32, i32, vp, vp]),
     "gsx_track_opt_state_bytes": (i64, []),
     "gsx_track_opt_init": (i32, [vp, i32, i32, f32, C.c_double, i32, i32, i32, C.c_double, C.c_double, vp]),
     "gsx_track_opt_advance": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, vp]),
@@ -101,6 +106,10 @@ PROTOTYPES = {
     "gsx_raster_track_fused": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gsx_front_workspace_bytes": (i64, [i64, i64, i32, i32, i64]),
     "gsx_front_rows": (i64, [i64, i64, i32, i32]),
+    "gsx_front_workspace_bytes_cand": (i64, [i64, i64, i32, i32, i64]),
+    "gsx_front_candidates": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, vp, vp, f32, f32, i64,
+                                   vp, i64, vp]),
+    "gsx_front_cand_layout": (i32, [i64, i64, i32, i32, i64, C.POINTER(i64)]),
     "gsx_front_layout": (i32, [i64, i64, i32, i32, i64, C.POINTER(i64)]),
     "gsx_front_pose_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, i64, vp, i64, vp, vp]),
     "gsx_front_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp,

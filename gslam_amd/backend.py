@@ -159,14 +159,17 @@ class Backend:
                 prune = False
                 decay = False          # the reference's mask has the old N here (it would fail on a grown map)
             else:
-                for _attempt in range(3):
+                for _attempt in range(4):
                     plan.step()
-                    pm = float(plan.out2[1].item())                   # backend.py:351 (the sync the reference has too)
-                    if plan.capacity_ok():
+                    # backend.py:351 (the sync the reference has too): loss + the iteration's overflow flag in one read.
+                    # The flag is summed over ranks by the iteration's all-reduce and gates the update launches on the
+                    # device: an iteration whose tile lists were truncated on ANY rank changed nothing on EVERY rank
+                    # (map, poses, moments, step counters), and every rank redoes it - the collectives stay in step.
+                    _total, pm, ok = plan.finish_step()
+                    if ok:
                         break
-                    # tile lists outgrew the plan's buffers: grown + re-captured by the next step().  The truncated
-                    # render already stepped the optimisers once; the redo replaces a silently wrong update by a second
-                    # small one (poses / map moved by one Adam step), which the loop tolerates.
+                else:
+                    raise RuntimeError("tile lists kept overflowing in optimize_map")
                 decay = True
             if early_stopper.stop(pm):
                 self.pause_map_optim = True
@@ -234,7 +237,13 @@ class Backend:
             k = conf.optim_window_last_n_keyframes
             nt = None if outputs is None else outputs.n_touched
             if nt is not None and radii.shape[0] > 0:
-                bad_views = ((radii[:k] > 0) & (nt[:k, :n] == 0)).sum(dim=0).to(torch.int32)
+                # the reference's statistic covers the first k keyframes of the WINDOW (backend.py:370-375); a rank holds the
+                # window cameras r, r + G, ...: select its rows by their window index, so that a G-rank run sums over the same
+                # camera set as a single-rank run
+                widx = getattr(outputs, "_window_index", None)
+                rows = list(range(min(k, radii.shape[0]))) if widx is None else [j for j, i in enumerate(widx) if i < k]
+                rows_t = torch.tensor(rows, dtype=torch.long, device=dev)
+                bad_views = ((radii[rows_t] > 0) & (nt[rows_t][:, :n] == 0)).sum(dim=0).to(torch.int32)
             else:
                 bad_views = torch.zeros(n, dtype=torch.int32, device=dev)
             shard.all_reduce_sum(bad_views)

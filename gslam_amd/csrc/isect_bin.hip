@@ -954,7 +954,58 @@ struct FrontArgs {
     PreRec *recs;        // [C][R][1024 * items]
     int compact;         // rec / v_rec rows are indexed by instance slot ((c * R + row) * seg_cap + position), not flatten id
     gsx_bal::Args bal;   // bal.order != nullptr: workgroup R of the launch computes the CU-balanced launch order instead
+    // per-frame candidate set (gsx_front_candidates; pose-only plans): what a closure's projection reads instead of culling
+    // all N Gaussians again for a pose that moved by a fraction of a pixel
+    const struct CandRec *cand;   // [R][seg_cap] pose-independent records of the row's candidates, in Gaussian order
+    const int32_t *cand_n;        // [R]
+    float *cand_hdr;              // [CAND_HDR]: reference [R | t] of every camera, margins, mode word (see cand_valid)
 };
+
+// What the projection needs of one Gaussian that does not depend on the pose: built once per frame for the Gaussians that
+// can be visible from ANY pose within the margins of the frame's first pose (gsx_front_candidates), read by every closure
+// of the frame.  The covariance is the same float expression (covar_from_rot_scale) the per-closure path evaluates, so a
+// closure over candidate records and a closure over the raw map arrays produce the same bits.
+struct CandRec {
+    float mean[3];
+    float S[6];            // world covariance 00 01 02 11 12 22
+    float opac, col[3], beta;
+    int32_t g;             // Gaussian index
+    int32_t pad;
+};
+static_assert(sizeof(CandRec) == 64, "candidate records are one 64-byte line each");
+constexpr int CAND_MAX_CAMS = 16;
+constexpr int CAND_HDR = CAND_MAX_CAMS * 12 + 8;   // [c][12] reference [R | t] rows, then rot_max, trans_max, -, -, mode, ...
+
+// Is every camera's current pose within the margins of its reference pose?  p = dR p0 + dt with dR = R R0^T,
+// dt = t - dR t0, so |p - p0| <= |dR - I|_F |p0| + |dt|: the candidate cull allowed exactly that displacement.
+// Wave-uniform (scalar loads, the same few hundred flops in every wavefront).
+__device__ __forceinline__ bool cand_valid(const float *__restrict__ viewmats, const float *__restrict__ hdr, int C) {
+    const float rot_max = hdr[CAND_MAX_CAMS * 12], trans_max = hdr[CAND_MAX_CAMS * 12 + 1];
+    bool ok = true;
+    for (int c = 0; c < C; ++c) {
+        const float *V = viewmats + 16 * c, *V0 = hdr + 12 * c;
+        float dR[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                dR[i * 3 + j] = V[i * 4 + 0] * V0[j * 4 + 0] + V[i * 4 + 1] * V0[j * 4 + 1] + V[i * 4 + 2] * V0[j * 4 + 2];
+        float rot2 = 0.f, dt2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float e = dR[i * 3 + j] - (i == j ? 1.0f : 0.0f);
+                rot2 += e * e;
+            }
+            const float d = V[i * 4 + 3] - (dR[i * 3 + 0] * V0[3] + dR[i * 3 + 1] * V0[7] + dR[i * 3 + 2] * V0[11]);
+            dt2 += d * d;
+        }
+        // (NaN poses compare false: not valid -> the full path, which culls everything)
+        ok = ok && (rot2 * 1.001f <= rot_max * rot_max) && (dt2 * 1.001f <= trans_max * trans_max);
+    }
+    return ok;
+}
 
 // Position of every flagged thread of the workgroup among the flagged ones, IN THREAD ORDER (a deterministic, monotone
 // compaction: ballot prefix inside the wavefront, wavefront bases from a scan of the per-wavefront counts in LDS), and
@@ -996,6 +1047,121 @@ __device__ __forceinline__ bool surely_culled(const float mean[3], float smax2, 
     return (pmx + rb <= 0.0f) || (pmx - rb >= (float)W) || (pmy + rb <= 0.0f) || (pmy - rb >= (float)H);
 }
 
+// surely_culled for EVERY pose within the margins of the reference pose `cam`: the camera-space position of the Gaussian may
+// move by delta = rot_max |p0| + trans_max in any direction.  True only if the exact projection is certain to cull the
+// Gaussian for all of them (z range against near / far; the bounding box test with the largest radius bound and the extreme
+// screen positions over the box [p0 - delta, p0 + delta]).
+__device__ __forceinline__ bool surely_culled_margin(const float mean[3], float smax2, const Cam &cam, float RF, float KJ,
+                                                     int W, int H, float eps2d, float near_p, float far_p, float rot_max,
+                                                     float trans_max) {
+    const float *R = cam.R;
+    const float x = ((R[0] * mean[0] + R[1] * mean[1]) + R[2] * mean[2]) + cam.t[0];
+    const float y = ((R[3] * mean[0] + R[4] * mean[1]) + R[5] * mean[2]) + cam.t[1];
+    const float z = ((R[6] * mean[0] + R[7] * mean[1]) + R[8] * mean[2]) + cam.t[2];
+    const float delta = 1.001f * (rot_max * sqrtf((x * x + y * y) + z * z) + trans_max) + 1e-6f;
+    const float zmax = z + delta, zmin = z - delta;
+    if (!(zmax >= near_p) || !(zmin <= far_p)) return !(zmax != zmax);      // out of range for every pose (NaN: keep)
+    if (!(zmin > fmaxf(near_p, 1e-3f))) return false;                        // may come arbitrarily close: no bound, keep
+    const float rzmax = 1.0f / zmin, rzmin = 1.0f / zmax;
+    const float v1b = 1.01f * (rzmax * rzmax) * KJ * RF * smax2 + 2.0f * eps2d + 0.2f;
+    const float rb = 3.0f * sqrtf(v1b) + 2.0f;
+    const float xh = x + delta, xl = x - delta, yh = y + delta, yl = y - delta;
+    const float pxh = cam.fx * (xh * (xh >= 0.f ? rzmax : rzmin)) + cam.cx, pxl = cam.fx * (xl * (xl >= 0.f ? rzmin : rzmax)) + cam.cx;
+    const float pyh = cam.fy * (yh * (yh >= 0.f ? rzmax : rzmin)) + cam.cy, pyl = cam.fy * (yl * (yl >= 0.f ? rzmin : rzmax)) + cam.cy;
+    const float slack = 1.0f + 1e-3f * (fabsf(pxh) + fabsf(pxl) + fabsf(pyh) + fabsf(pyl));   // float rounding of the estimate
+    return (pxh + rb + slack <= 0.0f) || (pxl - rb - slack >= (float)W) || (pyh + rb + slack <= 0.0f) ||
+           (pyl - rb - slack >= (float)H);
+}
+
+// Per-frame candidate set: workgroup b culls ITS chunk of the map (the rows of front_project_kernel) against every camera's
+// reference pose with the margins, compacts the survivors IN ORDER and leaves their pose-independent records and their
+// count; workgroup 0 also publishes the reference poses and the margins.
+template <int ITEMS>
+__global__ __launch_bounds__(FRONT_THREADS) void front_candidates_kernel(FrontArgs a, CandRec *__restrict__ cand_out,
+                                                                         int32_t *__restrict__ cand_n_out, float rot_max,
+                                                                         float trans_max) {
+    __shared__ int s_wcnt[FRONT_THREADS / 64];
+    const int C = a.C;
+    const int seg_cap = FRONT_THREADS * ITEMS;
+    const int64_t g0 = (int64_t)blockIdx.x * seg_cap;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < CAND_HDR; i += FRONT_THREADS) {
+            float v = 0.f;
+            if (i < 12 * C) v = a.viewmats[16 * (i / 12) + (i % 12)];
+            else if (i == CAND_MAX_CAMS * 12) v = rot_max;
+            else if (i == CAND_MAX_CAMS * 12 + 1) v = trans_max;
+            a.cand_hdr[i] = v;
+        }
+    }
+    int n_surv = 0;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t g = g0 + it * FRONT_THREADS + threadIdx.x;
+        const bool active = g < a.N;
+        bool survive = false;
+        float mean[3] = {0.f, 0.f, 0.f}, s[3] = {1.f, 1.f, 1.f};
+        if (active) {
+            mean[0] = a.means[3 * g]; mean[1] = a.means[3 * g + 1]; mean[2] = a.means[3 * g + 2];
+            s[0] = a.scales[3 * g]; s[1] = a.scales[3 * g + 1]; s[2] = a.scales[3 * g + 2];
+            if (a.flags & GSX_PROJ_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
+            const float sm = fmaxf(s[0], fmaxf(s[1], s[2]));
+            const float smax2 = sm * sm;
+            for (int c = 0; c < C; ++c) {
+                Cam cam;
+                load_cam(a.viewmats, a.Ks, c, cam);
+                const float *R = cam.R;
+                const float RF = ((R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) + (R[3] * R[3] + R[4] * R[4] + R[5] * R[5])) +
+                                 (R[6] * R[6] + R[7] * R[7] + R[8] * R[8]);
+                const float tanx = 0.5f * (float)a.W / cam.fx, tany = 0.5f * (float)a.H / cam.fy;
+                const float lx = fmaxf(((float)a.W - cam.cx) / cam.fx, cam.cx / cam.fx) + GSX_FOV_SLACK * tanx;
+                const float ly = fmaxf(((float)a.H - cam.cy) / cam.fy, cam.cy / cam.fy) + GSX_FOV_SLACK * tany;
+                const float KJ = cam.fx * cam.fx * (1.0f + lx * lx) + cam.fy * cam.fy * (1.0f + ly * ly);
+                // |R|_F^2 = 3 for every rotation; 1 % more covers a view matrix that is one only to float accuracy
+                if (!surely_culled_margin(mean, smax2, cam, 1.01f * fmaxf(RF, 3.0f), KJ, a.W, a.H, a.eps2d, a.near_p,
+                                          a.far_p, rot_max, trans_max))
+                    survive = true;
+            }
+        }
+        int tot;
+        __syncthreads();
+        const unsigned long long m = __ballot(survive);
+        if ((threadIdx.x & 63) == 0) s_wcnt[threadIdx.x >> 6] = __popcll(m);
+        __syncthreads();
+        int base = 0;
+        tot = 0;
+#pragma unroll
+        for (int w = 0; w < FRONT_THREADS / 64; ++w) {
+            const int cw = s_wcnt[w];
+            base += (w < (int)(threadIdx.x >> 6)) ? cw : 0;
+            tot += cw;
+        }
+        const int pos = n_surv + base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+        if (survive) {
+            CandRec rec;
+            float q[4] = {a.quats[4 * g], a.quats[4 * g + 1], a.quats[4 * g + 2], a.quats[4 * g + 3]};
+            QuatRot qr;
+            quat_to_rotmat(q, qr);
+            float M[9];
+            Sym3 S;
+            covar_from_rot_scale(qr.R, s, M, S);
+            rec.mean[0] = mean[0]; rec.mean[1] = mean[1]; rec.mean[2] = mean[2];
+            rec.S[0] = S.a00; rec.S[1] = S.a01; rec.S[2] = S.a02; rec.S[3] = S.a11; rec.S[4] = S.a12; rec.S[5] = S.a22;
+            rec.opac = gsx_sigmoid(a.logit_opac[g]);
+            rec.col[0] = gsx_sigmoid(a.logit_colors[3 * g]);
+            rec.col[1] = gsx_sigmoid(a.logit_colors[3 * g + 1]);
+            rec.col[2] = gsx_sigmoid(a.logit_colors[3 * g + 2]);
+            rec.beta = (a.flags & GSX_PROJ_BETAS) ? fmaxf(expf(a.log_unc[g]), GSX_BETA_MIN) : 0.f;
+            rec.g = (int32_t)g;
+            rec.pad = 0;
+            float4 *o = reinterpret_cast<float4 *>(cand_out + (int64_t)blockIdx.x * seg_cap + pos);
+            const float4 *src = reinterpret_cast<const float4 *>(&rec);
+            o[0] = src[0]; o[1] = src[1]; o[2] = src[2]; o[3] = src[3];
+        }
+        n_surv += tot;
+    }
+    if (threadIdx.x == 0) cand_n_out[blockIdx.x] = n_surv;
+}
+
 template <int ITEMS>
 __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs a) {
     extern __shared__ __attribute__((aligned(16))) int s_front[];   // [C * n_tiles] counts, [C] instance counters, survivors
@@ -1016,9 +1182,18 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
     const int seg_cap = FRONT_THREADS * ITEMS;
     const bool skip_culled = (a.flags & GSX_PROJ_SKIP_CULLED) != 0;
     const int64_t g0 = (int64_t)blockIdx.x * seg_cap;
+    // per-frame candidate records (pose-only plans): valid while every camera stays within the margins they were built for;
+    // otherwise this closure takes the full path below - same results either way, the candidates only save the cull
+    const bool use_cand = a.cand != nullptr && cand_valid(a.viewmats, a.cand_hdr, C);
+    if (a.cand != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.cand_hdr[CAND_MAX_CAMS * 12 + 4] = use_cand ? 1.0f : 0.0f;            // mode of this closure (front_pose_bwd reads it)
+        if (!use_cand) a.cand_hdr[CAND_MAX_CAMS * 12 + 5] += 1.0f;              // closures that fell back (diagnostics)
+    }
+    if (use_cand) n_surv = min(max(a.cand_n[blockIdx.x], 0), seg_cap);
     // ---- phase 1: cheap conservative cull; the survivors' local indices are compacted into LDS.  The loads of all ITEMS
     // Gaussians of a thread are issued before any of them is used (one memory round trip for the phase, not ITEMS) ---------
     float pm[ITEMS][3], psm[ITEMS];
+    if (!use_cand) {
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int64_t g = g0 + it * FRONT_THREADS + threadIdx.x;
@@ -1065,30 +1240,45 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
         if (survive) s_list[n_surv + pos] = (unsigned short)loc;
         n_surv += tot;
     }
+    }   // !use_cand
     __syncthreads();
     // ---- phase 2: the projection proper, dense over the survivors (whole wavefronts of real work) ---------------------------
     for (int s0 = 0; s0 < n_surv; s0 += FRONT_THREADS) {
         const int si = s0 + threadIdx.x;
         const bool active = si < n_surv;
-        const int64_t g = g0 + (active ? (int)s_list[si] : 0);
-        float mean[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, s[3] = {1.f, 1.f, 1.f};
+        int64_t g = g0;
+        float mean[3] = {0.f, 0.f, 0.f};
         float opac = 0.f, col[3] = {0.f, 0.f, 0.f}, beta = 0.f;
-        if (active) {
-            mean[0] = a.means[3 * g]; mean[1] = a.means[3 * g + 1]; mean[2] = a.means[3 * g + 2];
-            q[0] = a.quats[4 * g]; q[1] = a.quats[4 * g + 1]; q[2] = a.quats[4 * g + 2]; q[3] = a.quats[4 * g + 3];
-            s[0] = a.scales[3 * g]; s[1] = a.scales[3 * g + 1]; s[2] = a.scales[3 * g + 2];
-            if (a.flags & GSX_PROJ_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
-            opac = gsx_sigmoid(a.logit_opac[g]);
-            col[0] = gsx_sigmoid(a.logit_colors[3 * g]);
-            col[1] = gsx_sigmoid(a.logit_colors[3 * g + 1]);
-            col[2] = gsx_sigmoid(a.logit_colors[3 * g + 2]);
-            if (a.flags & GSX_PROJ_BETAS) beta = fmaxf(expf(a.log_unc[g]), GSX_BETA_MIN);
+        Sym3 S = {1.f, 0.f, 0.f, 1.f, 0.f, 1.f};
+        const int64_t cslot = (int64_t)blockIdx.x * seg_cap + si;      // candidate record of this thread (candidate mode)
+        if (use_cand) {
+            if (active) {
+                const float4 *src = reinterpret_cast<const float4 *>(a.cand + cslot);
+                const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+                mean[0] = r0.x; mean[1] = r0.y; mean[2] = r0.z;
+                S.a00 = r0.w; S.a01 = r1.x; S.a02 = r1.y; S.a11 = r1.z; S.a12 = r1.w; S.a22 = r2.x;
+                opac = r2.y; col[0] = r2.z; col[1] = r2.w; col[2] = r3.x; beta = r3.y;
+                g = (int64_t)__float_as_int(r3.z);
+            }
+        } else {
+            float q[4] = {1.f, 0.f, 0.f, 0.f}, s[3] = {1.f, 1.f, 1.f};
+            g = g0 + (active ? (int)s_list[si] : 0);
+            if (active) {
+                mean[0] = a.means[3 * g]; mean[1] = a.means[3 * g + 1]; mean[2] = a.means[3 * g + 2];
+                q[0] = a.quats[4 * g]; q[1] = a.quats[4 * g + 1]; q[2] = a.quats[4 * g + 2]; q[3] = a.quats[4 * g + 3];
+                s[0] = a.scales[3 * g]; s[1] = a.scales[3 * g + 1]; s[2] = a.scales[3 * g + 2];
+                if (a.flags & GSX_PROJ_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
+                opac = gsx_sigmoid(a.logit_opac[g]);
+                col[0] = gsx_sigmoid(a.logit_colors[3 * g]);
+                col[1] = gsx_sigmoid(a.logit_colors[3 * g + 1]);
+                col[2] = gsx_sigmoid(a.logit_colors[3 * g + 2]);
+                if (a.flags & GSX_PROJ_BETAS) beta = fmaxf(expf(a.log_unc[g]), GSX_BETA_MIN);
+            }
+            QuatRot qr;
+            quat_to_rotmat(q, qr);
+            float M[9];
+            covar_from_rot_scale(qr.R, s, M, S);
         }
-        QuatRot qr;
-        quat_to_rotmat(q, qr);
-        float M[9];
-        Sym3 S;
-        covar_from_rot_scale(qr.R, s, M, S);
         int n_vis = 0;
         for (int c = 0; c < C; ++c) {
             Cam cam;
@@ -1150,7 +1340,9 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
                     pr.xs = (uint32_t)r.x0 | ((uint32_t)r.x1 << 16);
                     pr.ys_c = (uint32_t)r.y0 | ((uint32_t)r.y1 << 12) | ((uint32_t)c << 24);
                     pr.depth = __float_as_uint(depth);
-                    pr.id = (uint32_t)idx;
+                    // candidate mode (compact plans: the sort key's low word is the slot, not this field): the instance's
+                    // candidate record, so that the pose backward finds mean and covariance without recomputing them
+                    pr.id = use_cand ? (uint32_t)cslot : (uint32_t)idx;
                     a.recs[slot] = pr;
                 }
             }
@@ -1302,8 +1494,11 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
     const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ viewmats, const float *__restrict__ Ks, int64_t N, int C, int W, int H, float eps2d,
     float near_p, float far_p, int flags, const float *__restrict__ v_rec, const PreRec *__restrict__ recs,
-    const int32_t *__restrict__ n_inst, int R, int seg_cap, float *__restrict__ partials /*[R][C][12]*/, int compact) {
+    const int32_t *__restrict__ n_inst, int R, int seg_cap, float *__restrict__ partials /*[R][C][12]*/, int compact,
+    const CandRec *__restrict__ cand, const float *__restrict__ cand_hdr) {
     __shared__ float s_part[FPB_THREADS / 64][12];
+    // candidate mode of THIS closure (left by its projection): the instance records name candidate records, not flatten ids
+    const bool use_cand = cand != nullptr && cand_hdr[CAND_MAX_CAMS * 12 + 4] > 0.5f;
     const int row = blockIdx.x, c = blockIdx.y;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int n = min(max(n_inst[c * R + row], 0), seg_cap);
@@ -1313,12 +1508,26 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
     float acc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = t + (int)blockIdx.z * FPB_THREADS; i < n; i += FPB_THREADS * FPB_SPLIT) {
         const int64_t idx = (int64_t)seg[i].id;
-        const int64_t g = idx - (int64_t)c * N;
-        if (g < 0 || g >= N) continue;                       // never from a sane front; keeps the gathers in range
-        const float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
-        const float q[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
-        float s[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
-        if (flags & GSX_PROJ_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
+        float mean[3];
+        Sym3 S;
+        if (use_cand) {
+            if (idx < 0 || idx >= (int64_t)R * seg_cap) continue;      // never from a sane front; keeps the gather in range
+            const float4 *src = reinterpret_cast<const float4 *>(cand + idx);
+            const float4 r0 = src[0], r1 = src[1], r2 = src[2];
+            mean[0] = r0.x; mean[1] = r0.y; mean[2] = r0.z;
+            S.a00 = r0.w; S.a01 = r1.x; S.a02 = r1.y; S.a11 = r1.z; S.a12 = r1.w; S.a22 = r2.x;
+        } else {
+            const int64_t g = idx - (int64_t)c * N;
+            if (g < 0 || g >= N) continue;                       // never from a sane front; keeps the gathers in range
+            mean[0] = means[3 * g]; mean[1] = means[3 * g + 1]; mean[2] = means[3 * g + 2];
+            const float q[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
+            float s[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+            if (flags & GSX_PROJ_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
+            QuatRot qr;
+            quat_to_rotmat(q, qr);
+            float M[9];
+            covar_from_rot_scale(qr.R, s, M, S);
+        }
         const int64_t vrow = compact ? (((int64_t)c * R + row) * seg_cap + i) : idx;
         const float4 *r4 = reinterpret_cast<const float4 *>(v_rec + vrow * 12);
         const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2];
@@ -1326,11 +1535,6 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
             float4 *w4 = const_cast<float4 *>(r4);
             w4[0] = w4[1] = w4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        QuatRot qr;
-        quat_to_rotmat(q, qr);
-        float M[9];
-        Sym3 S;
-        covar_from_rot_scale(qr.R, s, M, S);
         Proj p;
         if (!project_core(mean, S, cam, W, H, eps2d, near_p, far_p, p)) continue;
         const float vmx = q0.x, vmy = q0.y;
@@ -1405,6 +1609,7 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
 
 struct FrontLayout {
     int64_t counts_off, ninst_off, entries_off, scratch_off, matrix_off, recs_off, total;
+    int64_t cand_hdr_off, cand_n_off, cand_off, total_cand;      // candidate area, appended behind `total` (optional)
     int items, R;
 };
 
@@ -1424,6 +1629,10 @@ FrontLayout front_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M
     L.matrix_off = L.scratch_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);
     L.recs_off = L.matrix_off + gsx_align256(T * (int64_t)GB_MAX * 4);
     L.total = gsx_align256(L.recs_off + C * (int64_t)L.R * FRONT_THREADS * items * 16 + 256);
+    L.cand_hdr_off = L.total;
+    L.cand_n_off = L.cand_hdr_off + gsx_align256(CAND_HDR * 4);
+    L.cand_off = L.cand_n_off + gsx_align256((int64_t)GB_MAX * 4);
+    L.total_cand = gsx_align256(L.cand_off + (int64_t)L.R * FRONT_THREADS * items * (int64_t)sizeof(CandRec) + 256);
     return L;
 }
 
@@ -1431,6 +1640,47 @@ FrontLayout front_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M
 
 extern "C" int64_t gsx_front_workspace_bytes(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap) {
     return front_layout(N, C, tile_w, tile_h, M_cap).total;
+}
+
+extern "C" int64_t gsx_front_workspace_bytes_cand(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap) {
+    return front_layout(N, C, tile_w, tile_h, M_cap).total_cand;
+}
+
+extern "C" int gsx_front_candidates(const float *means, const float *quats, const float *scales, const float *viewmats_ref,
+                                    const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                                    float far_plane, int flags, const float *logit_opacities, const float *logit_colors,
+                                    const float *log_uncertainties, float rot_max, float trans_max, int64_t M_cap,
+                                    void *workspace, int64_t workspace_bytes, void *stream) {
+    GSX_CHECK_ARG(N >= 1 && C >= 1 && C <= CAND_MAX_CAMS && W > 0 && H > 0 && M_cap >= 1);
+    GSX_CHECK_ARG(means && quats && scales && viewmats_ref && Ks && logit_opacities && logit_colors);
+    GSX_CHECK_ARG(!(flags & GSX_PROJ_BETAS) || log_uncertainties);
+    GSX_CHECK_ARG(rot_max >= 0.f && trans_max >= 0.f && rot_max < 1.0f);
+    const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
+    const FrontLayout L = front_layout(N, C, tile_w, tile_h, M_cap);
+    if (!workspace || workspace_bytes < L.total_cand) {
+        gsx_set_error("gsx_front_candidates: workspace without the candidate area (%lld < %lld: size it with "
+                      "gsx_front_workspace_bytes_cand)", (long long)workspace_bytes, (long long)L.total_cand);
+        return GSX_E_WORKSPACE;
+    }
+    char *ws = (char *)workspace;
+    FrontArgs a = {};
+    a.means = means; a.quats = quats; a.scales = scales; a.viewmats = viewmats_ref; a.Ks = Ks;
+    a.logit_opac = logit_opacities; a.logit_colors = logit_colors; a.log_unc = log_uncertainties;
+    a.N = N; a.C = (int)C; a.W = W; a.H = H; a.flags = flags; a.tile_w = tile_w; a.tile_h = tile_h;
+    a.items = L.items; a.R = L.R; a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane;
+    a.cand_hdr = (float *)(ws + L.cand_hdr_off);
+    CandRec *cand = (CandRec *)(ws + L.cand_off);
+    int32_t *cand_n = (int32_t *)(ws + L.cand_n_off);
+    hipStream_t st = (hipStream_t)stream;
+    switch (L.items) {
+        case 1: hipLaunchKernelGGL(front_candidates_kernel<1>, dim3((unsigned)L.R), dim3(FRONT_THREADS), 0, st, a, cand, cand_n, rot_max, trans_max); break;
+        case 2: hipLaunchKernelGGL(front_candidates_kernel<2>, dim3((unsigned)L.R), dim3(FRONT_THREADS), 0, st, a, cand, cand_n, rot_max, trans_max); break;
+        case 4: hipLaunchKernelGGL(front_candidates_kernel<4>, dim3((unsigned)L.R), dim3(FRONT_THREADS), 0, st, a, cand, cand_n, rot_max, trans_max); break;
+        case 8: hipLaunchKernelGGL(front_candidates_kernel<8>, dim3((unsigned)L.R), dim3(FRONT_THREADS), 0, st, a, cand, cand_n, rot_max, trans_max); break;
+        default: gsx_set_error("gsx_front_candidates: %d Gaussians per thread unsupported", L.items); return GSX_E_UNSUPPORTED;
+    }
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
 }
 
 extern "C" int gsx_front_fwd(const float *means, const float *quats, const float *scales, const float *viewmats,
@@ -1469,6 +1719,20 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
     a.conics = conics; a.rec = rec; a.v_rec = v_rec_clear;
     a.cnt = (int32_t *)(ws + L.matrix_off); a.n_inst = (int32_t *)(ws + L.ninst_off); a.recs = (PreRec *)(ws + L.recs_off);
     a.compact = compact;
+    a.cand = nullptr; a.cand_n = nullptr; a.cand_hdr = nullptr;
+    if (flags & GSX_PROJ_CANDIDATES) {
+        // the candidate set gsx_front_candidates left in this workspace; a closure whose poses left its margins takes the
+        // full path by itself (same results), so the flag is a promise about the workspace, not about the poses
+        GSX_CHECK_ARG(compact && C <= CAND_MAX_CAMS);
+        if (workspace_bytes < L.total_cand) {
+            gsx_set_error("gsx_front_fwd: GSX_PROJ_CANDIDATES needs the candidate area (%lld < %lld)",
+                          (long long)workspace_bytes, (long long)L.total_cand);
+            return GSX_E_WORKSPACE;
+        }
+        a.cand = (const CandRec *)(ws + L.cand_off);
+        a.cand_n = (const int32_t *)(ws + L.cand_n_off);
+        a.cand_hdr = (float *)(ws + L.cand_hdr_off);
+    }
     size_t front_lds = (size_t)((T + C + FRONT_THREADS / 64) * 4 + 2 * FRONT_THREADS * L.items);   // histogram + survivor list
     a.bal.order = nullptr;
     if (balanced_order) {
@@ -1535,10 +1799,17 @@ extern "C" int gsx_front_pose_bwd(const float *means, const float *quats, const 
         return GSX_E_WORKSPACE;
     }
     const char *ws = (const char *)workspace;
+    const bool cand_on = (flags & GSX_PROJ_CANDIDATES) != 0;
+    if (cand_on && workspace_bytes < L.total_cand) {
+        gsx_set_error("gsx_front_pose_bwd: GSX_PROJ_CANDIDATES needs the candidate area");
+        return GSX_E_WORKSPACE;
+    }
     hipLaunchKernelGGL(front_pose_bwd_kernel, dim3((unsigned)L.R, (unsigned)C, FPB_SPLIT), dim3(FPB_THREADS), 0, (hipStream_t)stream,
                        means, quats, scales, viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, flags, v_rec,
                        (const PreRec *)(ws + L.recs_off), (const int32_t *)(ws + L.ninst_off), L.R,
-                       FRONT_THREADS * L.items, partials, (flags & GSX_PROJ_COMPACT) ? 1 : 0);
+                       FRONT_THREADS * L.items, partials, (flags & GSX_PROJ_COMPACT) ? 1 : 0,
+                       cand_on ? (const CandRec *)(ws + L.cand_off) : (const CandRec *)nullptr,
+                       cand_on ? (const float *)(ws + L.cand_hdr_off) : (const float *)nullptr);
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }
@@ -1546,6 +1817,16 @@ extern "C" int gsx_front_pose_bwd(const float *means, const float *quats, const 
 // out4 = { rows R, slots per (camera, row) segment, byte offset of the instance records in the workspace, byte offset of the
 // per-segment instance counts }: instance slot s = (c * R + row) * out4[1] + position; record s = 16 bytes
 // {x0 | x1 << 16, y0 | y1 << 12 | c << 24, depth bits, flatten id} at workspace + out4[2] + 16 s
+// out4 = byte offsets of { candidate header (floats: [16][12] reference poses, rot_max, trans_max, -, -, mode of the last
+// closure, closures that fell back), candidate counts int32[R], candidate records (64 bytes each, [R][slots]) } and the
+// number of header floats
+extern "C" int gsx_front_cand_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int64_t *out4) {
+    GSX_CHECK_ARG(out4 && N >= 1 && C >= 1);
+    const FrontLayout L = front_layout(N, C, tile_w, tile_h, M_cap);
+    out4[0] = L.cand_hdr_off; out4[1] = L.cand_n_off; out4[2] = L.cand_off; out4[3] = CAND_HDR;
+    return GSX_OK;
+}
+
 extern "C" int gsx_front_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int64_t *out4) {
     GSX_CHECK_ARG(out4 && N >= 1 && C >= 1);
     const FrontLayout L = front_layout(N, C, tile_w, tile_h, M_cap);

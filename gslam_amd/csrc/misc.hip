@@ -222,6 +222,9 @@ struct AdamArgs {
     int decay_min;
     float decay;
     const int32_t *decay_mask;
+    // optional gate: the launch does nothing when skip_if_positive[0] > 0 (a render of this iteration overflowed its tile
+    // lists on some rank: no update from truncated gradients; the host grows the lists and redoes the iteration)
+    const float *skip_if_positive;
 };
 
 // One element of the update (torch.optim.Adam, lerp form of the first moment)
@@ -250,6 +253,7 @@ typedef float gsx_f4v __attribute__((ext_vector_type(4)));
 constexpr int ADAM_UNITS = GSX_ADAM_UNITS, ADAM_ILP = GSX_ADAM_ILP;
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
+    if (a.skip_if_positive && a.skip_if_positive[0] > 0.f) return;         // wave-uniform (scalar load)
     int64_t u0 = (int64_t)blockIdx.x * ADAM_UNITS;
     const int64_t u_end = min(a.start[a.count], u0 + ADAM_UNITS);       // start[] is in units here
     if (u0 >= u_end) return;
@@ -341,10 +345,21 @@ struct CounterArgs {
     int64_t *p[16];
     int n;
     int64_t delta;
+    const float *skip_if_positive;
 };
 
 __global__ void counters_add_kernel(CounterArgs a) {
+    if (a.skip_if_positive && a.skip_if_positive[0] > 0.f) return;
     if (threadIdx.x < a.n) a.p[threadIdx.x][0] += a.delta;
+}
+
+// flag[0] = 1 if any of the status words has a bit of `mask` set, else 0 (a float: it travels in the step bucket and is
+// summed over ranks by the iteration's one all-reduce)
+__global__ void status_flag_kernel(const int32_t *__restrict__ status, int n, int mask, float *__restrict__ flag) {
+    int any = 0;
+    for (int i = threadIdx.x; i < n; i += 64) any |= status[i] & mask;
+    const unsigned long long b = __ballot(any != 0);
+    if (threadIdx.x == 0) flag[0] = b ? 1.0f : 0.0f;
 }
 
 // ---- self test ------------------------------------------------------------------------------------------------------
@@ -402,7 +417,7 @@ static int adam_launch(int n_tensors, float *const *params, const float *const *
                        float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1, float beta2,
                        float eps, int64_t step_host, const int64_t *step_dev, const int64_t *const *steps, void *stream,
                        int decay_tensor = -1, const int32_t *decay_mask = nullptr, int decay_min = 0,
-                       float decay = 1.0f) {
+                       float decay = 1.0f, const float *skip_if_positive = nullptr) {
     GSX_CHECK_ARG(n_tensors >= 1 && n_tensors <= ADAM_MAX && params && grads && exp_avg && exp_avg_sq && numels && lrs);
     GSX_CHECK_ARG(decay_tensor < n_tensors && (decay_tensor < 0 || decay_mask));
     GSX_CHECK_ARG(step_host >= 1 || step_dev || steps);
@@ -419,7 +434,13 @@ static int adam_launch(int n_tensors, float *const *params, const float *const *
         if (steps && in) GSX_CHECK_ARG(steps[k]);
         a.p[k] = in ? params[k] : nullptr; a.g[k] = in ? grads[k] : nullptr;
         a.m[k] = in ? exp_avg[k] : nullptr; a.v[k] = in ? exp_avg_sq[k] : nullptr;
-        a.start[k + 1] = a.start[k] + (in ? (numels[k] + 3) / 4 : 0);
+        // every tensor starts on a workgroup boundary: a workgroup then serves ONE tensor.  With the tensors packed back to
+        // back the workgroup at the end of the list walked the (dt, dR) pairs of all window poses - 16 tensors of 3 and 6
+        // floats - one after the other, each with its own dependent chain step counter -> powf -> loads -> stores, and the
+        // launch lasted as long as that one workgroup: 69 us for 7.5 M parameters that stream in ~35 (the same kernel runs
+        // at 6.8 TB/s on one large tensor: tools/ubench/adam_variants.hip)
+        const int64_t units = in ? (numels[k] + 3) / 4 : 0;
+        a.start[k + 1] = a.start[k] + (units + ADAM_UNITS - 1) / ADAM_UNITS * ADAM_UNITS;
         a.numel[k] = in ? numels[k] : 0;
         a.step_size[k] = in ? (float)((double)lrs[k] / bc1) : 0.f;
         a.lr[k] = in ? lrs[k] : 0.f;
@@ -427,6 +448,7 @@ static int adam_launch(int n_tensors, float *const *params, const float *const *
     }
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.bc2_sqrt = (float)sqrt(bc2);
     a.decay_k = decay_tensor < 0 ? -1 : decay_tensor; a.decay_mask = decay_mask; a.decay_min = decay_min; a.decay = decay;
+    a.skip_if_positive = skip_if_positive;
     const int64_t total = a.start[n_tensors];
     const int64_t blocks = (total + ADAM_UNITS - 1) / ADAM_UNITS;
     GSX_CHECK_ARG(blocks < ((int64_t)1 << 31));
@@ -461,11 +483,41 @@ extern "C" int gsx_adam_multi_steps_decay(int n_tensors, float *const *params, c
                        stream, decay_tensor, decay_mask, decay_min_count, decay);
 }
 
+extern "C" int gsx_adam_multi_steps_gated(int n_tensors, float *const *params, const float *const *grads,
+                                          float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numels,
+                                          const float *lrs, float beta1, float beta2, float eps,
+                                          const int64_t *const *steps, int decay_tensor, const int32_t *decay_mask,
+                                          int decay_min_count, float decay, const float *skip_if_positive,
+                                          void *stream) {
+    GSX_CHECK_ARG(steps);
+    return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, lrs, beta1, beta2, eps, 0, nullptr, steps,
+                       stream, decay_tensor, decay_mask, decay_min_count, decay, skip_if_positive);
+}
+
+extern "C" int gsx_status_flag(const int32_t *status, int n, int mask, float *flag, void *stream) {
+    GSX_CHECK_ARG(status && flag && n >= 1 && n <= 4096);
+    hipLaunchKernelGGL(status_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, status, n, mask, flag);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+static int counters_launch(int n, int64_t *const *counters, int64_t delta, const float *skip_if_positive, void *stream);
+
+extern "C" int gsx_counters_add_gated(int n, int64_t *const *counters, int64_t delta, const float *skip_if_positive,
+                                      void *stream) {
+    return counters_launch(n, counters, delta, skip_if_positive, stream);
+}
+
 extern "C" int gsx_counters_add(int n, int64_t *const *counters, int64_t delta, void *stream) {
+    return counters_launch(n, counters, delta, nullptr, stream);
+}
+
+static int counters_launch(int n, int64_t *const *counters, int64_t delta, const float *skip_if_positive, void *stream) {
     GSX_CHECK_ARG(n >= 1 && n <= 16 && counters);
     CounterArgs a;
     a.n = n;
     a.delta = delta;
+    a.skip_if_positive = skip_if_positive;
     for (int k = 0; k < 16; ++k) {
         a.p[k] = k < n ? counters[k] : nullptr;
         if (k < n) GSX_CHECK_ARG(counters[k]);

@@ -73,7 +73,8 @@ class KeyframeShard:
 class StepBucket:
     """Everything one BA iteration sums over ranks, in ONE flat fp32 buffer:
 
-        [ N*15 map gradients | N visible-camera counts | Cw*3 pose dt gradients | Cw*6 pose dR gradients | 2 loss values ]
+        [ N*15 map gradients | N visible-camera counts | Cw*3 pose dt gradients | Cw*6 pose dR gradients | 2 loss values |
+          overflow flag | spare ]
 
     (means3 + quats4 + scales3 + opac1 + colors3 + log_unc1 = 15 columns; Cw = cameras of the whole BA window).  The
     kernels of a launch plan (gslam_amd.plan.MappingStep) write their outputs straight into the views below - no
@@ -81,7 +82,11 @@ class StepBucket:
     the per-Gaussian visibility counts (isotropic term backend.py:287, opacity decay :357; exact in fp32: counts <= C),
     the pose gradients (each rank fills the rows of the cameras it rendered, the rest are zero) and the loss terms
     (each rank's share of the window means), so every rank can apply the identical update to the map and to ALL window
-    poses and take the identical early-stop decision without a second collective or a pose broadcast."""
+    poses and take the identical early-stop decision without a second collective or a pose broadcast.  The overflow flag
+    (1.0 from every rank whose render truncated a tile list this iteration, gsx_status_flag) rides in the same sum: the
+    update launches are gated on it ON THE DEVICE (gsx_adam_multi_steps_gated), so either every rank applies the iteration's
+    update or none does, and every rank reads the same flag next to the loss value - the decision to redo an iteration is
+    collective by construction."""
 
     def __init__(self, shapes: Sequence[Sequence[int]], n_window_cams: int, device, group=None):
         self.group = group
@@ -90,7 +95,7 @@ class StepBucket:
         self.Cw = cw = int(n_window_cams)
         numels = [int(torch.Size(s).numel()) for s in shapes]
         n_map = sum(numels)
-        self.flat = torch.zeros(n_map + n + cw * 9 + 2, dtype=torch.float32, device=device)
+        self.flat = torch.zeros(n_map + n + cw * 9 + 4, dtype=torch.float32, device=device)
         self.views, off = [], 0
         for s, k in zip(shapes, numels):
             self.views.append(self.flat[off:off + k].view(s))
@@ -101,6 +106,8 @@ class StepBucket:
         self.g_dt = self.flat[off:off + cw * 3].view(cw, 3); off += cw * 3
         self.g_dR = self.flat[off:off + cw * 6].view(cw, 6); off += cw * 6
         self.out2 = self.flat[off:off + 2]
+        self.overflow = self.flat[off + 2:off + 3]         # > 0 after the reduction: some rank's tile lists overflowed
+        self.out4 = self.flat[off:off + 4]                 # (total, photometric, overflow flag, spare): one read-back
         self.vis_i32 = torch.zeros(n, dtype=torch.int32, device=device)   # window-wide counts after the reduction
 
     @property

@@ -127,9 +127,12 @@ class AdamPack:
     gradient of each parameter is a caller-owned persistent buffer (``grad_of[id(p)]``) instead of ``p.grad``, the Adam
     moments and the device step counters of the (capturable) optimisers are created up front, and ``launch(stream)``
     issues one gsx_counters_add plus one multi-tensor launch per (betas, eps) class - nothing is allocated, so the call
-    can be recorded into a HIP graph.  ``decay`` as in step_all.  Parameters without an entry in ``grad_of`` are skipped."""
+    can be recorded into a HIP graph.  ``decay`` as in step_all.  Parameters without an entry in ``grad_of`` are skipped.
+    ``gate``: a device float; the launches do nothing while gate[0] > 0 (gsx_adam_multi_steps_gated: no update from an
+    iteration whose render overflowed its tile lists)."""
 
-    def __init__(self, optimizers, grad_of: dict, decay=None):
+    def __init__(self, optimizers, grad_of: dict, decay=None, gate: torch.Tensor | None = None):
+        self._gate = gate
         self._groups = []
         counters: dict = {}
         classes: dict = {}
@@ -198,6 +201,15 @@ class AdamPack:
                     self._adam_calls.append((common, steps, None))
 
     def launch(self, stream_ptr_: int):
+        if self._gate is not None:
+            gate = self._gate.data_ptr()
+            for n, ptrs in self._counter_calls:
+                check(lib.gsx_counters_add_gated(n, ptrs, 1, gate, stream_ptr_), "gsx_counters_add_gated")
+            for common, steps, dec in self._adam_calls:
+                d = dec if dec is not None else (-1, None, 0, 1.0)
+                check(lib.gsx_adam_multi_steps_gated(*common, steps, d[0], d[1], d[2], d[3], gate, stream_ptr_),
+                      "gsx_adam_multi_steps_gated")
+            return
         for n, ptrs in self._counter_calls:
             check(lib.gsx_counters_add(n, ptrs, 1, stream_ptr_), "gsx_counters_add")
         for common, steps, dec in self._adam_calls:

@@ -33,6 +33,7 @@ _VIEW_PARTIALS = 8      # GSX_PROJ_VIEW_PARTIALS
 _RESET_V_REC = 64       # GSX_PROJ_RESET_V_REC
 _SKIP_CULLED = 16       # GSX_PROJ_SKIP_CULLED
 _COMPACT = 32           # GSX_PROJ_COMPACT
+_CANDIDATES = 128       # GSX_PROJ_CANDIDATES
 
 
 def _arr(ptrs: Sequence[Optional[int]]):
@@ -233,6 +234,9 @@ class RenderPlan:
             self.v_rec = torch.zeros(n_slots, 12, dtype=f32, device=dev)
         self.capacity = 0
         self.flat = self.tile_order = self.isect_ws = None
+        # per-frame candidate set (gsx_front_candidates): enable_candidates() + build_candidates() per frame
+        self.candidates = False
+        self.cand_margins = (0.0, 0.0)
         # CU-balanced launch order (gsx_tile_balance): a render whose T workgroups are all resident at once (more than one
         # and at most five per CU) runs as long as its most loaded CU; enable_balance() makes the rasteriser launches follow
         # an order computed from the work the tiles took in an earlier closure
@@ -250,12 +254,65 @@ class RenderPlan:
         self.flat = torch.empty(cap, dtype=torch.int32, device=dev)
         # heaviest-first launch order pays off while the tile lists are short (see rasterization.rasterization)
         self.tile_order = torch.empty(self.T, dtype=torch.int32, device=dev) if cap < self.ORDER_MAX_PER_TILE * self.T else None
-        if self.front:
+        if self.front and self.candidates:
+            nbytes = int(lib.gsx_front_workspace_bytes_cand(self.N, self.C, self.tile_w, self.tile_h, cap))
+        elif self.front:
             nbytes = int(lib.gsx_front_workspace_bytes(self.N, self.C, self.tile_w, self.tile_h, cap))
         else:
             nbytes = int(lib.gsx_isect_bin_workspace_bytes_n(self.C, self.N, self.tile_w, self.tile_h, cap))
         self.isect_ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        if self.front and self.candidates:
+            # an all-zero header never validates (reference rotation 0): closures take the full path until
+            # build_candidates() has run over THIS workspace
+            self._cand_header().zero_()
         self.stale = True
+
+    # ---- per-frame candidate set ---------------------------------------------------------------------------------------
+    def enable_candidates(self, rot_max: float = 0.02, trans_max: float = 0.02) -> bool:
+        """Pose-only plans on the fused front: closures read the candidate set that ``build_candidates`` leaves in the
+        workspace (the Gaussians that can be visible from any pose within ``rot_max`` (|R R0^T - I|_F) and ``trans_max`` of the
+        reference poses, with their pose-independent projection inputs) instead of culling the whole map again; a closure
+        whose poses left the margins takes the full path by itself - results are identical either way.  -> whether this
+        plan's shape qualifies."""
+        if not (self.front and self.compact and self.C <= 16):
+            return False
+        if not self.candidates:
+            self.candidates = True
+            if self.capacity:
+                self._alloc_lists(self.capacity)
+        self.cand_margins = (float(rot_max), float(trans_max))
+        return True
+
+    def _cand_layout(self):
+        lay = (C.c_int64 * 4)()
+        check(lib.gsx_front_cand_layout(self.N, self.C, self.tile_w, self.tile_h, self.capacity, lay), "gsx_front_cand_layout")
+        return int(lay[0]), int(lay[1]), int(lay[2]), int(lay[3])
+
+    def _cand_header(self) -> torch.Tensor:
+        hdr_off, _, _, n = self._cand_layout()
+        return self.isect_ws[hdr_off:hdr_off + 4 * n].view(torch.float32)
+
+    def build_candidates(self, st: Optional[int] = None):
+        """once per frame (per refinement), with ``self.viewmats`` holding the poses the closures start from, and again
+        whenever the map's arrays were written: one launch on ``st`` (default: torch's current stream)"""
+        if not self.candidates or self.capacity == 0:
+            return
+        st = current_stream_ptr(self.dev) if st is None else st
+        m = self.map
+        check(lib.gsx_front_candidates(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
+                                       self.H, self.eps2d, self.near, self.far, self.flags, _p(m[3]), _p(m[4]), _p(m[5]),
+                                       self.cand_margins[0], self.cand_margins[1], self.capacity, _p(self.isect_ws),
+                                       self.isect_ws.numel(), st), "gsx_front_candidates")
+
+    def candidate_stats(self):
+        """(candidates in all rows, mode of the last closure (1 = candidates used), closures that fell back to the full path
+        since the last build) - three small blocking reads, for tests and diagnostics"""
+        hdr_off, n_off, _, _ = self._cand_layout()
+        lay = (C.c_int64 * 4)()
+        check(lib.gsx_front_layout(self.N, self.C, self.tile_w, self.tile_h, self.capacity, lay), "gsx_front_layout")
+        counts = self.isect_ws[n_off:n_off + 4 * int(lay[0])].view(torch.int32)
+        hdr = self._cand_header()
+        return int(counts.sum().item()), int(hdr[16 * 12 + 4].item()), int(hdr[16 * 12 + 5].item())
 
     def probe(self, stream_ptr: Optional[int] = None):
         """sizes the tile lists from the current map and poses with ONE synchronous read of sum(tiles_per_gauss) (an upper
@@ -275,6 +332,13 @@ class RenderPlan:
         False the capacity has been grown (``stale`` is set): re-capture and redo.  One blocking read of 12 bytes."""
         st, m = int(self.status.item()), int(self.M_dev.item())
         self.last_M = m
+        if st & 2:
+            # the binning kernels clamped a negative / out-of-range tile count (hardening flag, csrc/isect_bin.hip): the
+            # lists of this render were built from corrupt counts - never a silent "ok"
+            self.status.zero_()
+            raise RuntimeError(f"corrupt tile counts in a render plan (status {st}, M {m}, N {self.N}, C {self.C}, "
+                               f"{self.W}x{self.H}, capacity {self.capacity}): the count matrix was overwritten or the "
+                               "inputs are not finite")
         if st & 1:
             self.status.zero_()
             self._alloc_lists(int(max(m, self.capacity) * self.GROW) + 4096)
@@ -294,7 +358,15 @@ class RenderPlan:
         check(lib.gsx_front_layout(self.N, self.C, self.tile_w, self.tile_h, self.capacity, lay), "gsx_front_layout")
         n_slots = self.C * int(lay[0]) * int(lay[1])
         recs = self.isect_ws[int(lay[2]):int(lay[2]) + n_slots * 16].view(torch.int32).view(n_slots, 4)
-        return recs[:, 3].long() & 0xFFFFFFFF
+        ids = recs[:, 3].long() & 0xFFFFFFFF
+        if self.candidates and self.candidate_stats()[1] == 1:
+            # the last closure ran on the candidate set: the records name candidate records, whose word 14 is the Gaussian
+            _, _, cand_off, _ = self._cand_layout()
+            n_cand = int(lay[0]) * int(lay[1])
+            cg = self.isect_ws[cand_off:cand_off + n_cand * 64].view(torch.int32).view(n_cand, 16)[:, 14].long()
+            cam = (recs[:, 1].long() >> 24) & 0xFF
+            ids = cam * self.N + cg[ids.clamp(max=n_cand - 1)]
+        return ids
 
     def as_output(self):
         """the plan's buffers seen as the reference's RasterizationOutput (views, no copies): what pruning, insertion and
@@ -360,7 +432,8 @@ class RenderPlan:
     def _front(self, st: int):
         m = self.map
         lean = self.lean
-        flags = self.flags | (_SKIP_CULLED if lean else 0) | (_COMPACT if self.compact else 0)
+        flags = self.flags | (_SKIP_CULLED if lean else 0) | (_COMPACT if self.compact else 0) | (
+            _CANDIDATES if self.candidates else 0)
         check(lib.gsx_front_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                 self.H, self.eps2d, self.near, self.far, flags,
                                 _p(m[3]), _p(m[4]), _p(m[5]), None if self.compact else _p(self.radii),
@@ -461,7 +534,8 @@ class RenderPlan:
         if self.grads == 'pose' and self.front:
             check(lib.gsx_front_pose_bwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C,
                                          self.W, self.H, self.eps2d, self.near, self.far,
-                                         self.flags | reset | (_COMPACT if self.compact else 0), vr, self.capacity,
+                                         self.flags | reset | (_COMPACT if self.compact else 0) | (
+                                             _CANDIDATES if self.candidates else 0), vr, self.capacity,
                                          _p(self.isect_ws), self.isect_ws.numel(), _p(self.pose_ws), st),
                   "gsx_front_pose_bwd")
             return
@@ -544,9 +618,17 @@ class TrackClosure:
     PoseZhou backward, loss finish, optimiser advance).  'host': stops at the gradients (``g_dt, g_dR, g_exposure``,
     ``loss``) for an optimiser on the host."""
 
-    def __init__(self, splats, camera, tail: str = 'fused', fuse_raster: bool = True, front: Optional[bool] = None):
+    CAND_MARGINS = (0.02, 0.02)    # |R R0^T - I|_F (~0.8 degrees) and metres the closures of a frame may move from its first pose
+
+    def __init__(self, splats, camera, tail: str = 'fused', fuse_raster: bool = True, front: Optional[bool] = None,
+                 candidates: bool = False):
         """fuse_raster (fused tail only): forward rasteriser, loss and rasteriser backward as ONE launch
-        (gsx_raster_track_fused); False keeps them as two (the independent path the tests compare against)"""
+        (gsx_raster_track_fused); False keeps them as two (the independent path the tests compare against).
+        candidates: per-frame candidate set for the closures' projection (gsx_front_candidates).  OFF by default - measured
+        on the headline sequence: the 36 evaluation points of a frame spread over up to ~0.1 rad / 0.1 m (Adam's
+        lr-sized steps, the line search's trial points); margins that cover them make the candidate set as large as what
+        the per-closure cull keeps (334 k of 500 k at 0.06 / 0.06 against ~170 k visible), and tighter ones send most
+        closures to the full path.  Results are identical either way."""
         assert tail in ('fused', 'split', 'host')
         self.tail = tail
         self.fuse_raster = bool(fuse_raster) and tail == 'fused'
@@ -560,6 +642,7 @@ class TrackClosure:
         self.g_exposure = torch.zeros(2, device=dev)
         self.img = torch.zeros(camera.height, camera.width, 3, device=dev)
         self.out2 = torch.zeros(2, device=dev)
+        self._zeros9 = torch.zeros(9, device=dev)
         self.state = torch.zeros(int(lib.gsx_track_opt_state_bytes()), dtype=torch.uint8, device=dev)
         self.report = torch.zeros(8, dtype=torch.float32, device=dev)
         self.map_ws = torch.empty(int(lib.gsx_map_loss_workspace_bytes(1, self.r.H, self.r.W)), dtype=torch.uint8,
@@ -569,6 +652,10 @@ class TrackClosure:
         self.loss_rows = torch.zeros(self.r.T, 6, device=dev)
         if tail == 'fused':
             self.r.enable_balance()       # the fused forward leaves the tiles' work counters: CU-balanced launch order
+        # the 36 closures of a frame re-project the same map for poses that differ by fractions of a pixel: the map is culled
+        # ONCE per frame, with margins (gsx_front_candidates), and the closures read that candidate set
+        if candidates:
+            self.r.enable_candidates(*self.CAND_MARGINS)
         self.stream = torch.cuda.Stream(device=dev)
         self.graph = HipGraph()
         self._chains: Dict[int, HipGraph] = {}
@@ -603,6 +690,35 @@ class TrackClosure:
         self.img.copy_(img)
         self.exposure.copy_(exposure.reshape(2))
         self.r.viewmats[0].copy_(Rt)                    # dR = dt = 0: the first evaluation's view matrix
+        self.r.build_candidates()                       # the frame's candidate set, around that pose (map as of now)
+
+    def load_frame(self, pose, img: torch.Tensor, exposure: torch.Tensor):
+        """``load`` of a frame whose pose is a PoseZhou module, in THREE launches on torch's current stream instead of the
+        ~20 torch ops of ``load(pose().detach(), ...)`` (PoseZhou.forward alone is a normalize / cross / stack / cat chain and a
+        4x4 matmul that lands on hipBLASLt): gsx_pose_zhou_fwd writes the frame's view matrix straight into the plan, one
+        row-copy launch fills the slot (Rt <- that matrix, dR = dt = 0, exposure, image), then the frame's candidate set."""
+        from .transport import copy_rows
+        st = current_stream_ptr(self.dev)
+        learn = 1 if getattr(pose, "is_learnable", True) else 0
+        check(lib.gsx_pose_zhou_fwd(1, _arr([pose.Rt.data_ptr()]), _arr([pose.dR.data_ptr()]), _arr([pose.dt.data_ptr()]),
+                                    (C.c_int * 1)(learn), _p(self.r.viewmats), st), "gsx_pose_zhou_fwd")
+        z = self._zeros9
+        img, exposure = img.detach(), exposure.detach().reshape(1, 2)
+        if not (img.is_contiguous() and img.dtype == torch.float32 and img.shape == self.img.shape):
+            raise RuntimeError("frame image must be a contiguous float32 [H,W,3] tensor of the plan's size")
+        copy_rows([self.slots.Rt.view(1, 16), self.slots.dR.view(1, 6), self.slots.dt.view(1, 3), self.exposure.view(1, 2),
+                   self.img.view(1, -1)],
+                  [self.r.viewmats.view(1, 16), z[:6].view(1, 6), z[6:].view(1, 3), exposure.contiguous(),
+                   img.view(1, -1)], 1)
+        self.r.build_candidates(st)
+
+    def store_frame(self, pose, exposure_out: torch.Tensor):
+        """the tracked pose and exposure back into the frame's objects, one launch: pose.Rt <- the view matrix the closure's
+        tail left in the plan, pose.dR = pose.dt = 0 (frontend.py:659-662 keeps the optimised pose as the frame's pose)"""
+        from .transport import copy_rows
+        z = self._zeros9
+        copy_rows([pose.Rt.view(1, 16), pose.dR.data.view(1, 6), pose.dt.data.view(1, 3), exposure_out.data.view(1, 2)],
+                  [self.r.viewmats.view(1, 16), z[:6].view(1, 6), z[6:].view(1, 3), self.exposure.view(1, 2)], 1)
 
     def enqueue(self, st: int):
         r = self.r
@@ -826,6 +942,7 @@ class MappingStep:
         self.grad_views = dict(zip(GRAD_PARAMS, self.bucket.views))
         self.counts, self.g_dt, self.g_dR = self.bucket.counts, self.bucket.g_dt, self.bucket.g_dR
         self.out2, self.vis_i32 = self.bucket.out2, self.bucket.vis_i32
+        self.out4, self.overflow = self.bucket.out4, self.bucket.overflow
         # ---- poses -----------------------------------------------------------------------------------------------------
         self.learnable = [bool(getattr(f.pose, "is_learnable", True) and f.pose.dR.requires_grad) for f in self.window]
         for f in self.window:
@@ -872,7 +989,9 @@ class MappingStep:
         self._vis = vis
         from .optim import AdamPack
         decay = (splats.opacities, vis, 1, float(conf.opacity_decay)) if decay_opacity else None
-        self.adam = AdamPack([optimizers.splat_opt, optimizers.pose_opt], grad_of, decay)
+        # gated on the iteration's overflow flag (device side): a truncated render never reaches the map, the poses, the
+        # moments or the step counters - on any rank
+        self.adam = AdamPack([optimizers.splat_opt, optimizers.pose_opt], grad_of, decay, gate=self.overflow)
         pose_grads = {k: v for k, v in grad_of.items() if k not in {id(getattr(splats, n)) for n in GRAD_PARAMS}}
         self.adam_poses = AdamPack([optimizers.pose_opt], pose_grads) if pose_grads else None
         self.stream = torch.cuda.Stream(device=dev)
@@ -947,6 +1066,8 @@ class MappingStep:
         check(lib.gsx_loss_finish(_p(self.map_ws), Cl, H, W, _p(self.ssim_ws) if n_ssim else None, n_ssim, _p(iso_ws),
                                   n_iso, c0, c1, w_ssim if n_ssim else 0.0, 0.0, None, _p(self.g_exposure),
                                   _p(self.out2), st), "gsx_loss_finish")
+        # this rank's share of the overflow flag: 1.0 if the render above truncated a tile list (sticky status bit 1)
+        check(lib.gsx_status_flag(_p(r.status), 1, 1, _p(self.overflow), st), "gsx_status_flag")
 
     def reduce(self):
         """the ONE data-path collective of an iteration (eager, on torch's current stream, between the two graphs)"""
@@ -1054,7 +1175,22 @@ class MappingStep:
                                     float(self.conf.opacity_decay), current_stream_ptr(self.dev)), "gsx_opacity_decay")
 
     def capacity_ok(self) -> bool:
+        """LOCAL check of this rank's sticky overflow status (grows the lists and marks the plan stale on overflow)"""
         return True if self.r is None else self.r.check_capacity()
+
+    def finish_step(self):
+        """Reads the iteration's (total, photometric, overflow) in ONE blocking read-back - the reference's loss.item() of
+        gslam/backend.py:351 - and settles the overflow protocol: the flag is the sum over ranks, so every rank takes the same
+        branch.  -> (total, photometric, ok).  ok = False: the iteration applied NO update anywhere (the update launches are
+        gated on the flag on the device); the ranks whose lists overflowed have grown them (their next step() re-captures);
+        the caller redoes the iteration - on all ranks, or the collectives go out of step."""
+        total, pm, flag, _ = self.out4.tolist()
+        if flag > 0.0:
+            self.capacity_ok()
+            # host bookkeeping of the skipped update
+            self.adam.note_steps(-1)
+            return total, pm, False
+        return total, pm, True
 
     def as_output(self):
         """RasterizationOutput over this rank's cameras (None for a rank without cameras)"""
@@ -1062,6 +1198,7 @@ class MappingStep:
             return None
         out = self.r.as_output()
         out._window_cams = self.Cw
+        out._window_index = list(self.mine)          # row j of the per-camera arrays = window camera mine[j]
         return out
 
     def depthmaps(self):

@@ -110,6 +110,10 @@ class IsectCapacity:
         if self.M_dev is not None:
             st, m = int(self.status.item()), int(self.M_dev.item())
             self.last_M = m
+            if st & 2:                         # hardening flag of the binning kernels: lists built from corrupt counts
+                self.status.zero_()
+                raise RuntimeError(f"corrupt tile counts in a sync-free render (status {st}, M {m}, capacity "
+                                   f"{self.capacity})")
             if st & 1:
                 ok = False
                 # M can be an under-estimate when the overflow was in the pre-sort's instance records (csrc/isect_bin.hip

@@ -156,7 +156,7 @@ class GraphedTracker:
         self._grads = [c.g_dt, c.g_dR, c.g_exposure]
         self._state, self._report = c.state, c.report
         self.loss = c.loss
-        self._retrying = False
+        self._retrying = 0
 
     @property
     def graph(self):
@@ -167,7 +167,11 @@ class GraphedTracker:
 
     def load(self, frame: Frame, prev_exposure: Optional[torch.Tensor] = None):
         exposure = frame.exposure_params if prev_exposure is None else prev_exposure
-        self.plan.load(frame.pose().detach(), frame.img, exposure.detach())
+        pose = frame.pose
+        if all(hasattr(pose, k) for k in ("Rt", "dR", "dt")) and pose.Rt.is_cuda and frame.img.is_contiguous():
+            self.plan.load_frame(pose, frame.img, exposure)         # three launches, no torch PoseZhou forward
+        else:
+            self.plan.load(frame.pose().detach(), frame.img, exposure.detach())
 
     def capture(self):
         """probe the tile-list capacity for the loaded frame, warm up and record the closure (the slot is left as loaded)"""
@@ -191,6 +195,12 @@ class GraphedTracker:
         return self.loss
 
     def _write_back(self, frame: Frame):
+        pose = frame.pose
+        if self.fused_tail and all(hasattr(pose, k) for k in ("Rt", "dR", "dt")) and pose.Rt.is_cuda \
+                and pose.Rt.is_contiguous() and frame.exposure_params.is_contiguous():
+            with torch.no_grad():
+                self.plan.store_frame(pose, frame.exposure_params)  # one launch
+            return
         with torch.no_grad():
             # fused tail: the closure's last launch left the view matrix of the final parameters in the plan
             new_pose = self.plan.r.viewmats[0] if self.fused_tail else self.pose().detach().clone()
@@ -222,12 +232,9 @@ class GraphedTracker:
             rep = rep.cpu()
             # the map under the captured closure changes between frames (BA updates, in-place SYNC): if its tile lists
             # outgrew the capacity baked into the graph, re-capture with the grown buffers and track this frame again
-            if not self.plan.r.check_capacity() and not self._retrying:
-                self._retrying = True
-                try:
-                    return self.track(frame, prev_exposure, max_eval, sync)
-                finally:
-                    self._retrying = False
+            # (frame.pose is only written after a clean run: every attempt starts from the frame's own pose and exposure)
+            if not self.plan.r.check_capacity():
+                return self._retry(frame, prev_exposure, max_eval, sync)
             self._write_back(frame)
             return float(rep[4]), int(rep[1])
         n_evals = 0
@@ -248,14 +255,25 @@ class GraphedTracker:
         lbfgs = torch.optim.LBFGS(self.params, history_size=conf.lbfgs_history, line_search_fn='strong_wolfe',
                                   tolerance_change=1e-9, lr=conf.pose_optim_lr, **kw)
         lbfgs.step(closure)
-        if not self.plan.r.check_capacity() and not self._retrying:
-            self._retrying = True
-            try:
-                return self.track(frame, prev_exposure, max_eval, sync)
-            finally:
-                self._retrying = False
+        if not self.plan.r.check_capacity():
+            return self._retry(frame, prev_exposure, max_eval, sync)
         self._write_back(frame)
         return last, n_evals
+
+    MAX_ATTEMPTS = 3
+
+    def _retry(self, frame, prev_exposure, max_eval, sync):
+        """the closure's tile lists overflowed during this frame (the buffers have been grown, the plan is stale): track the
+        frame again from its own pose - nothing of the truncated attempt was written back - and give up loudly after
+        MAX_ATTEMPTS instead of handing out a pose optimised on truncated renders"""
+        self._retrying += 1
+        try:
+            if self._retrying >= self.MAX_ATTEMPTS:
+                raise RuntimeError(f"tracking closure: tile lists overflowed in {self.MAX_ATTEMPTS} consecutive attempts "
+                                   f"(capacity {self.plan.r.capacity}, M {self.plan.r.last_M})")
+            return self.track(frame, prev_exposure, max_eval, sync)
+        finally:
+            self._retrying -= 1
 
     def capacity_ok(self) -> bool:
         """blocking check of the sticky overflow status (for callers of ``track(sync=False)``)"""

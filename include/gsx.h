@@ -59,6 +59,10 @@ extern "C" {
                                      so (depth, slot) sorts exactly like (depth, flatten id); record s of the front's workspace
                                      holds the flatten id of slot s.  radii / tiles_per_gauss become nullable. */
 #define GSX_PROJ_BETAS 4          /* gslam record: append beta=clamp(exp(log_unc),0.01) (rasterization.py:149,249-256) */
+#define GSX_PROJ_CANDIDATES 128   /* gsx_front_fwd / gsx_front_pose_bwd (with GSX_PROJ_COMPACT): the workspace carries the per-frame
+                                     candidate set of gsx_front_candidates; closures whose poses stay within its margins project
+                                     the candidates' pose-independent records instead of culling all N Gaussians again - same
+                                     results bit for bit, and a closure outside the margins takes the full path by itself */
 
 int gsx_version(void);
 const char *gsx_last_error(void);
@@ -166,6 +170,25 @@ int gsx_front_fwd(const float *means, const float *quats, const float *scales, c
                    * launch does the work of gsx_tile_balance(tile_work, ...) -> balanced_order, hidden behind the projection */
                   const int32_t *tile_work, int32_t *balanced_order, float chunk_cost, float light_rate, int n_cus,
                   void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Per-frame candidate set for the closures of a pose optimiser (tracking: gslam/frontend.py:604-662 evaluates 36 renders per
+ * frame whose poses differ by fractions of a pixel; window refinement: gslam/backend.py:447-506).  For every camera's
+ * REFERENCE pose (viewmats_ref) the Gaussians that the exact projection could keep for ANY pose within the margins - relative
+ * rotation |R R0^T - I|_F <= rot_max, relative translation |t - R R0^T t0| <= trans_max - are compacted in Gaussian order,
+ * per projection workgroup, together with what the projection needs of them that does not depend on the pose (mean, world
+ * covariance, activated opacity / colour / beta: 64 bytes each).  Lives in the candidate area behind the front's workspace
+ * (gsx_front_workspace_bytes_cand); gsx_front_fwd / gsx_front_pose_bwd use it under GSX_PROJ_CANDIDATES.  Must be rebuilt
+ * whenever the map's arrays change. */
+int64_t gsx_front_workspace_bytes_cand(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap);
+int gsx_front_candidates(const float *means, const float *quats, const float *scales, const float *viewmats_ref,
+                         const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane, float far_plane,
+                         int flags, const float *logit_opacities, const float *logit_colors, const float *log_uncertainties,
+                         float rot_max, float trans_max, int64_t M_cap, void *workspace, int64_t workspace_bytes,
+                         void *stream);
+/* out4 = byte offsets in the workspace of {candidate header, candidate counts int32 [rows], candidate records [rows][slots]
+ * x 64 bytes} and the number of header floats: [16][12] reference [R | t] rows, rot_max, trans_max, 0, 0, mode of the last
+ * closure (1 = candidates used), number of closures that fell back to the full path since the set was built */
+int gsx_front_cand_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int64_t *out4);
 
 /* Pose gradient of a pose-only closure from the instance records gsx_front_fwd left in its workspace (same N, C, W, H,
  * M_cap): the pose part of gsx_project_bwd(v_means = NULL, flags | GSX_PROJ_VIEW_PARTIALS) over the visible instances
@@ -338,6 +361,19 @@ int gsx_adam_multi_steps(int n_tensors, float *const *params, const float *const
                          float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1, float beta2,
                          float eps, const int64_t *const *steps, void *stream);
 int gsx_counters_add(int n, int64_t *const *counters, int64_t delta, void *stream);
+/* The update behind a DEVICE-SIDE GATE: gsx_adam_multi_steps_decay / gsx_counters_add that do nothing when
+ * skip_if_positive[0] > 0 (nullable: no gate).  The mapping plans set that float from the sticky overflow status of the
+ * iteration's render (gsx_status_flag: flag = any(status[i] & mask) ? 1 : 0) - summed over ranks by the iteration's one
+ * all-reduce - so an iteration whose tile lists were truncated on ANY rank applies no update on EVERY rank (no roll-back
+ * needed, the replicas stay identical); the host reads the flag with the loss value it reads anyway (the reference's
+ * loss.item(), gslam/backend.py:351), grows the lists and redoes the iteration. */
+int gsx_adam_multi_steps_gated(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                               float *const *exp_avg_sq, const int64_t *numels, const float *lrs, float beta1,
+                               float beta2, float eps, const int64_t *const *steps, int decay_tensor /* -1: none */,
+                               const int32_t *decay_mask, int decay_min_count, float decay,
+                               const float *skip_if_positive, void *stream);
+int gsx_counters_add_gated(int n, int64_t *const *counters, int64_t delta, const float *skip_if_positive, void *stream);
+int gsx_status_flag(const int32_t *status, int n, int mask, float *flag, void *stream);
 
 /* ---- device-resident tracking optimiser: the host logic of gslam/frontend.py:604-662 (10 torch.optim.Adam steps, then
  * ONE torch.optim.LBFGS(line_search_fn='strong_wolfe').step()) as a state machine advanced once per closure

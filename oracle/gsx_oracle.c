@@ -25,12 +25,24 @@
  * -ffp-contract=off so integer outputs are reproducible) and REAL=double
  * (finite-difference checks of the hand-derived VJPs).
  *
+ * Third build, for bench.py's cpu_baseline leg ONLY: -fopenmp (libgsx_oracle_f32_omp.so): the loops over Gaussians,
+ * image rows and tiles below carry OpenMP pragmas (all host cores).  Without -fopenmp the pragmas are
+ * no-ops and the two oracle builds are the serial code they always were; with it, per-Gaussian gradient sums use
+ * `omp atomic` (their summation order - not their value beyond float round-off - then depends on the schedule, which is
+ * why the tests never load that build).
+ *
  * All pointers are host pointers.  Every function returns 0 on success.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+int gsxo_omp_threads(void) { return omp_get_max_threads(); }
+#else
+int gsxo_omp_threads(void) { return 1; }
+#endif
 
 #ifdef GSXO_DOUBLE
 typedef double real;
@@ -210,6 +222,7 @@ int gsxo_project_fwd(int64_t N, int64_t C, const real *means, const real *quats,
                      real *comps /*nullable*/) {
     for (int64_t c = 0; c < C; ++c) {
         const real *V = viewmats + 16 * c, *K = Ks + 9 * c;
+#pragma omp parallel for schedule(static)
         for (int64_t g = 0; g < N; ++g) {
             int64_t idx = c * N + g;
             radii[idx] = 0;
@@ -251,6 +264,9 @@ int gsxo_project_bwd(int64_t N, int64_t C, const real *means, const real *quats,
     for (int64_t c = 0; c < C; ++c) {
         const real *V = viewmats + 16 * c, *K = Ks + 9 * c;
         const real Rv[9] = {V[0], V[1], V[2], V[4], V[5], V[6], V[8], V[9], V[10]};
+        real vVc[16] = {0};      /* this camera's view-matrix sums (left to right over g in the serial builds) */
+        if (v_viewmats) memcpy(vVc, v_viewmats + 16 * c, sizeof(vVc));
+#pragma omp parallel for schedule(static) reduction(+ : vVc[:16])
         for (int64_t g = 0; g < N; ++g) {
             int64_t idx = c * N + g;
             if (radii[idx] <= 0) continue;
@@ -321,10 +337,9 @@ int gsxo_project_bwd(int64_t N, int64_t C, const real *means, const real *quats,
             for (int j = 0; j < 3; ++j)
                 v_means[3 * g + j] += Rv[0 * 3 + j] * vpc[0] + Rv[1 * 3 + j] * vpc[1] + Rv[2 * 3 + j] * vpc[2];
             if (v_viewmats) {
-                real *vV = v_viewmats + 16 * c;
                 for (int i = 0; i < 3; ++i) {
-                    for (int j = 0; j < 3; ++j) vV[i * 4 + j] += vR[i * 3 + j];
-                    vV[i * 4 + 3] += vpc[i];
+                    for (int j = 0; j < 3; ++j) vVc[i * 4 + j] += vR[i * 3 + j];
+                    vVc[i * 4 + 3] += vpc[i];
                 }
             }
             /* 6. S = M M^T : vM = 2 vS M ; M = Rq diag(s) */
@@ -349,6 +364,7 @@ int gsxo_project_bwd(int64_t N, int64_t C, const real *means, const real *quats,
             const real dotp = vq[0] * qn[0] + vq[1] * qn[1] + vq[2] * qn[2] + vq[3] * qn[3];
             for (int k = 0; k < 4; ++k) v_quats[4 * g + k] += (vq[k] - dotp * qn[k]) * inv;
         }
+        if (v_viewmats) memcpy(v_viewmats + 16 * c, vVc, sizeof(vVc));
     }
     return 0;
 }
@@ -427,7 +443,28 @@ int gsxo_isect_emit_sort(int64_t C, int64_t N, const float *means2d, const int32
                 ++k;
             }
     }
+#ifdef _OPENMP
+    if (do_sort) {
+        /* same total order (key, emission sequence): a stable counting partition by (camera, tile) = key >> 32, then the
+           segments sorted independently on all cores */
+        const int64_t n_seg = (C << tile_n_bits);
+        int64_t *seg = (int64_t *)calloc((size_t)n_seg + 1, sizeof(int64_t));
+        kv_t *kv2 = (kv_t *)malloc(sizeof(kv_t) * (size_t)M);
+        if (!seg || !kv2) { free(seg); free(kv2); free(kv); return -1; }
+        for (int64_t k = 0; k < M; ++k) seg[(kv[k].key >> 32) + 1] += 1;
+        for (int64_t t = 0; t < n_seg; ++t) seg[t + 1] += seg[t];
+        int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_seg);
+        memcpy(cur, seg, sizeof(int64_t) * (size_t)n_seg);
+        for (int64_t k = 0; k < M; ++k) kv2[cur[kv[k].key >> 32]++] = kv[k];
+#pragma omp parallel for schedule(dynamic, 16)
+        for (int64_t t = 0; t < n_seg; ++t)
+            if (seg[t + 1] - seg[t] > 1) qsort(kv2 + seg[t], (size_t)(seg[t + 1] - seg[t]), sizeof(kv_t), kv_cmp);
+        free(cur); free(seg); free(kv);
+        kv = kv2;
+    }
+#else
     if (do_sort) qsort(kv, (size_t)M, sizeof(kv_t), kv_cmp);
+#endif
     for (int64_t k = 0; k < M; ++k) { isect_ids[k] = kv[k].key; flatten_ids[k] = kv[k].val; }
     free(kv);
     return 0;
@@ -459,12 +496,13 @@ int gsxo_raster_fwd(int64_t C, int64_t N, int CH, const real *means2d, const rea
                     int tile_w, int tile_h, const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
                     real vis_min_T, real *render /*[C,H,W,CH]*/, real *alphas /*[C,H,W]*/,
                     int32_t *last_ids /*[C,H,W]*/, int32_t *n_touched /*[C*N] zeroed here*/) {
-    (void)N;
+    if (CH < 1 || CH > 64) return -2;
     for (int64_t i = 0; i < C * N; ++i) n_touched[i] = 0;
     const int64_t n_tiles = (int64_t)tile_w * tile_h;
-    real *pix = (real *)malloc(sizeof(real) * (size_t)(CH > 0 ? CH : 1));
     for (int64_t c = 0; c < C; ++c)
-        for (int py = 0; py < H; ++py)
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int py = 0; py < H; ++py) {
+            real pix[64];                                           /* CH <= 64 (checked by the caller) */
             for (int px = 0; px < W; ++px) {
                 const int64_t tile = c * n_tiles + (int64_t)(py / tile_size) * tile_w + (px / tile_size);
                 const int64_t start = offsets[tile];
@@ -484,7 +522,10 @@ int gsxo_raster_fwd(int64_t C, int64_t N, int CH, const real *means2d, const rea
                     if (nT <= GSXO_T_MIN) break;
                     const real vis = alpha * T;
                     for (int k = 0; k < CH; ++k) pix[k] += colors[(int64_t)g * CH + k] * vis;
-                    if (nT > vis_min_T) n_touched[g] += 1;
+                    if (nT > vis_min_T) {
+#pragma omp atomic
+                        n_touched[g] += 1;
+                    }
                     last = (int32_t)e;
                     T = nT;
                 }
@@ -494,7 +535,7 @@ int gsxo_raster_fwd(int64_t C, int64_t N, int CH, const real *means2d, const rea
                 alphas[p] = RC(1.0) - T;
                 last_ids[p] = last;
             }
-    free(pix);
+        }
     return 0;
 }
 
@@ -508,10 +549,12 @@ int gsxo_raster_bwd(int64_t C, int64_t N, int CH, const real *means2d, const rea
                     real *v_means2d /*+=*/, real *v_conics /*+=*/, real *v_colors /*+=*/, real *v_opacities /*+=*/,
                     real *v_means2d_abs /*nullable, +=*/) {
     (void)N; (void)M;
+    if (CH < 1 || CH > 64) return -2;
     const int64_t n_tiles = (int64_t)tile_w * tile_h;
-    real *buf = (real *)malloc(sizeof(real) * (size_t)(CH > 0 ? CH : 1));
     for (int64_t c = 0; c < C; ++c)
-        for (int py = 0; py < H; ++py)
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int py = 0; py < H; ++py) {
+            real buf[64];                                           /* CH <= 64 (checked by the caller) */
             for (int px = 0; px < W; ++px) {
                 const int64_t p = (c * H + py) * W + px;
                 const int32_t last = last_ids[p];
@@ -540,6 +583,7 @@ int gsxo_raster_bwd(int64_t C, int64_t N, int CH, const real *means2d, const rea
                     real v_alpha = RC(0.0);
                     for (int k = 0; k < CH; ++k) {
                         const real ck = colors[(int64_t)g * CH + k];
+#pragma omp atomic
                         v_colors[(int64_t)g * CH + k] += fac * vo[k];
                         v_alpha += (ck * T - buf[k] * ra) * vo[k];
                         buf[k] += ck * fac;
@@ -548,18 +592,29 @@ int gsxo_raster_bwd(int64_t C, int64_t N, int CH, const real *means2d, const rea
                     v_alpha += -T_final * ra * bg_dot;
                     if (opacities[g] * vis <= GSXO_ALPHA_MAX) {
                         const real v_sigma = -opacities[g] * vis * v_alpha;
+#pragma omp atomic
                         v_conics[3 * g] += RC(0.5) * v_sigma * dx * dx;
+#pragma omp atomic
                         v_conics[3 * g + 1] += v_sigma * dx * dy;
+#pragma omp atomic
                         v_conics[3 * g + 2] += RC(0.5) * v_sigma * dy * dy;
                         const real gx = v_sigma * (a * dx + b * dy), gy = v_sigma * (b * dx + cc * dy);
+#pragma omp atomic
                         v_means2d[2 * g] += gx;
+#pragma omp atomic
                         v_means2d[2 * g + 1] += gy;
-                        if (v_means2d_abs) { v_means2d_abs[2 * g] += R_FABS(gx); v_means2d_abs[2 * g + 1] += R_FABS(gy); }
+                        if (v_means2d_abs) {
+#pragma omp atomic
+                            v_means2d_abs[2 * g] += R_FABS(gx);
+#pragma omp atomic
+                            v_means2d_abs[2 * g + 1] += R_FABS(gy);
+                        }
+#pragma omp atomic
                         v_opacities[g] += vis * v_alpha;
                     }
                 }
             }
-    free(buf);
+        }
     return 0;
 }
 

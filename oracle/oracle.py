@@ -23,7 +23,7 @@ _BUILD = os.path.join(_HERE, "_build")
 def build(force: bool = False) -> None:
     """Compile oracle/gsx_oracle.c (gcc) into oracle/_build/ if missing or stale."""
     src = os.path.join(_HERE, "gsx_oracle.c")
-    outs = [os.path.join(_BUILD, f"libgsx_oracle_{s}.so") for s in ("f32", "f64")]
+    outs = [os.path.join(_BUILD, f"libgsx_oracle_{s}.so") for s in ("f32", "f64", "f32_omp")]
     stale = force or any((not os.path.exists(o)) or os.path.getmtime(o) < os.path.getmtime(src) for o in outs)
     if stale:
         subprocess.run(["make", "-C", _HERE, "-B", "all"], check=True, capture_output=True)
@@ -34,13 +34,16 @@ def _p(a):
 
 
 class Oracle:
-    def __init__(self, dtype=np.float32):
+    def __init__(self, dtype=np.float32, threads: bool = False):
+        """threads=True: the OpenMP build (all host cores) - for bench.py's cpu_baseline leg only; its gradient sums are
+        atomics whose order depends on the schedule, so the tests use the serial builds"""
         build()
         self.dtype = np.dtype(dtype)
-        suffix = "f64" if self.dtype == np.float64 else "f32"
+        suffix = "f64" if self.dtype == np.float64 else ("f32_omp" if threads else "f32")
         self.lib = C.CDLL(os.path.join(_BUILD, f"libgsx_oracle_{suffix}.so"))
         self.real = C.c_double if self.dtype == np.float64 else C.c_float
         assert self.lib.gsxo_sizeof_real() == self.dtype.itemsize
+        self.threads = int(self.lib.gsxo_omp_threads())
 
     # -- helpers -----------------------------------------------------------
     def r(self, a, shape=None):

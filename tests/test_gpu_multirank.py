@@ -71,8 +71,10 @@ def _worker(rank, world, port, n_kf, q):
     # the scale gradients after adding it here
     d_cnt = int((plan.vis_i32 - ref_vis).abs().max())
     tail = slice(n15 + s2.means.shape[0], None)
-    d_pose = float((flat[tail][:-2] - ref_flat[tail][:-2]).abs().max()) / (float(ref_flat[tail][:-2].abs().max()) + 1e-9)
-    d_photo = abs(float(flat[-1]) - float(ref_flat[-1])) / abs(float(ref_flat[-1]))
+    # tail of the bucket: pose rows | total, photometric | overflow flag, spare
+    d_pose = float((flat[tail][:-4] - ref_flat[tail][:-4]).abs().max()) / (float(ref_flat[tail][:-4].abs().max()) + 1e-9)
+    d_photo = abs(float(flat[-3]) - float(ref_flat[-3])) / abs(float(ref_flat[-3]))
+    ok = ok and float(flat[-2]) == 0.0
     # two full iterations (graph | all-reduce | graph), then the parameters against the one-rank run
     plan.step()
     plan.step()
@@ -119,6 +121,80 @@ def test_two_rank_ba_step_equals_one_rank(n_kf):
             assert v < 2e-5, (rank, k, v)
         assert d_posepar < 2e-3 and moved > 0, (rank, d_posepar, moved)
         assert same_poses and same_map                        # replicas stay bit-identical: no pose broadcast needed
+
+
+def _overflow_worker(rank, world, port, q):
+    """rank 1's tile lists are sized with no head-room; the map then grows fatter on both replicas: rank 1's render overflows
+    inside the replayed graph, rank 0's does not.  The flag travels in the iteration's all-reduce, the update launches are
+    gated on it on the device: NOTHING moves on either rank, both read ok = False, rank 1 re-captures, both redo."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from gslam_amd import dist as gdist
+    from gslam_amd.mapping import BundleAdjuster
+    assert gdist.init_from_env(backend="gloo") == (rank, world)
+    s2, w2 = _build(dev, 4)
+    ba2 = BundleAdjuster(s2, capturable=True)
+    plan = ba2.plan(w2)
+    plan.r.GROW = 1.0 if rank == 1 else 3.0                   # instance attribute: head-room of the capacity probe
+    plan.step()
+    total0, pm0, ok0 = plan.finish_step()
+    names = ("means", "quats", "scales", "opacities", "colors", "log_uncertainties")
+    with torch.no_grad():
+        s2.scales.add_(0.25)                                  # every splat 28 % wider: M grows by more than rank 1's slack
+    torch.cuda.synchronize()
+    before = {k: getattr(s2, k).detach().clone() for k in names}
+    poses_before = torch.cat([torch.cat([f.pose.dR, f.pose.dt]) for f in w2]).detach().clone()
+    m_before = ba2.optimizers.splat_opt.state[s2.means]["exp_avg"].clone()
+    ctr_before = int(ba2.optimizers.splat_opt._shared_step.item())
+    cap_before = plan.r.capacity
+    plan.step()
+    total1, pm1, ok1 = plan.finish_step()                     # overflowed on rank 1 -> False on BOTH ranks
+    untouched = all(torch.equal(before[k], getattr(s2, k).detach()) for k in names)
+    untouched = untouched and torch.equal(poses_before, torch.cat([torch.cat([f.pose.dR, f.pose.dt]) for f in w2]).detach())
+    untouched = untouched and torch.equal(m_before, ba2.optimizers.splat_opt.state[s2.means]["exp_avg"])
+    untouched = untouched and int(ba2.optimizers.splat_opt._shared_step.item()) == ctr_before
+    grew = plan.r.capacity > cap_before
+    for _ in range(3):
+        plan.step()                                           # rank 1 re-captures with the grown lists; both redo
+        total2, pm2, ok2 = plan.finish_step()
+        if ok2:
+            break
+    moved = not torch.equal(before["means"], s2.means.detach())
+    stepped = int(ba2.optimizers.splat_opt._shared_step.item()) == ctr_before + 1
+
+    def same(t):
+        t = t.detach().contiguous().cpu()
+        both = [torch.zeros_like(t) for _ in range(world)]
+        td.all_gather(both, t)
+        return all(torch.equal(both[0], b) for b in both[1:])
+
+    replicas = all(same(getattr(s2, k)) for k in names) and same(torch.stack([f.pose().detach() for f in w2]))
+    q.put((rank, ok0, ok1, untouched, grew, ok2, moved, stepped, replicas, pm1, pm2))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_two_rank_overflow_is_collective_and_applies_no_update():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overflow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok0, ok1, untouched, grew, ok2, moved, stepped, replicas, pm1, pm2 in res:
+        assert ok0, rank                                      # the first iteration fitted on both ranks
+        assert not ok1, rank                                  # the overflow of rank 1 is seen by BOTH ranks
+        assert untouched, rank                                # ... and nothing moved on either: map, poses, moments, counters
+        assert grew == (rank == 1), (rank, grew)              # only the rank that overflowed grows its lists
+        assert ok2 and moved and stepped and replicas, (rank, ok2, moved, stepped, replicas)
+    assert res[0][-1] == res[1][-1]                           # same loss value read on both ranks
 
 
 def _backend_worker(rank, world, port, q):

@@ -461,3 +461,131 @@ def test_fused_raster_launch_equals_forward_then_backward(dev, front):
     assert float(a[2].abs().max()) > 0
     assert float((a[2] - b[2]).abs().max()) < 1e-4 * float(a[2].abs().max())
     assert float((a[3] - b[3]).abs().max()) < 1e-4 * float(a[3].abs().max()) + 1e-12
+
+
+def test_overflowed_ba_iteration_applies_no_update_and_bit2_raises(dev):
+    """single rank: a BA iteration whose tile lists overflow inside the replayed graph leaves map, poses, Adam moments and step
+    counters bit-identical (the update launches are gated on the overflow flag on the device), finish_step() reports it, the
+    redo with the grown lists equals a run that never overflowed; and the hardening flag of the binning kernels (status bit
+    2: a clamped, corrupt tile count) is an exception, never a silent ok"""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.mapping import BundleAdjuster
+    from gslam_amd.primitives import Camera, Frame, PoseZhou
+    from gslam_amd.synthetic import make_cameras, make_scene
+    n, W, H, C = 6000, 320, 240, 3
+    sc = make_scene(n, 41)
+    sc["scales"] = sc["scales"] + 0.5
+    viewmats, Ks = make_cameras(C, W, H)
+    gt = torch.rand(C, H, W, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+
+    def build(grow):
+        splats = GaussianSplattingData.from_dict({k: v.clone() for k, v in sc.items()}, dev)
+        window = [Frame(img=gt[i], timestamp=0.0, camera=Camera(Ks[i].to(dev), H, W),
+                        pose=PoseZhou(viewmats[i].to(dev)).to(dev), gt_pose=viewmats[i].to(dev), index=i,
+                        exposure_params=torch.zeros(2, device=dev)) for i in range(C)]
+        ba = BundleAdjuster(splats, capturable=True)
+        plan = ba.plan(window)
+        plan.r.GROW = grow
+        return splats, window, ba, plan
+
+    names = ("means", "quats", "scales", "opacities", "colors", "log_uncertainties")
+    res = []
+    for grow in (1.0, 4.0):                      # no head-room (overflows after the map fattens) / plenty
+        splats, window, ba, plan = build(grow)
+        plan.step()
+        assert plan.finish_step()[2]
+        with torch.no_grad():
+            splats.scales.add_(0.25)
+        before = {k: getattr(splats, k).detach().clone() for k in names}
+        ctr = int(ba.optimizers.splat_opt._shared_step.item())
+        plan.step()
+        total, pm, ok = plan.finish_step()
+        if grow == 1.0:
+            assert not ok
+            assert all(torch.equal(before[k], getattr(splats, k).detach()) for k in names)
+            assert int(ba.optimizers.splat_opt._shared_step.item()) == ctr
+            assert float(window[1].pose.dR.abs().max()) > 0        # (moved by the first, clean iteration only)
+            dR = window[1].pose.dR.detach().clone()
+            plan.step()                                            # re-captured with the grown lists
+            total, pm, ok = plan.finish_step()
+            assert ok and not torch.equal(dR, window[1].pose.dR.detach())
+        assert ok and int(ba.optimizers.splat_opt._shared_step.item()) == ctr + 1
+        res.append(({k: getattr(splats, k).detach().clone() for k in names}, pm))
+    assert abs(res[0][1] - res[1][1]) < 1e-5 * abs(res[1][1])
+    for k in names:
+        assert float((res[0][0][k] - res[1][0][k]).abs().mean()) < 2e-5, k
+    # status bit 2: poison the sticky status word the way the binning kernels do when they clamp a corrupt count
+    splats, window, ba, plan = build(2.0)
+    plan.step()
+    torch.cuda.synchronize()
+    plan.r.status.fill_(2)
+    with pytest.raises(RuntimeError, match="corrupt tile counts"):
+        plan.capacity_ok()
+    assert int(plan.r.status.item()) == 0 and plan.capacity_ok()
+
+
+def _track_closure(dev, n, seed, candidates, W=640, H=480, scale_shift=0.0):
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.plan import TrackClosure
+    from gslam_amd.primitives import Camera
+    from gslam_amd.synthetic import make_intrinsics, make_scene
+    sc = make_scene(n, seed)
+    sc["scales"] = sc["scales"] + scale_shift
+    splats = GaussianSplattingData.from_dict(sc, dev)
+    cam = Camera(make_intrinsics(W, H).to(dev), H, W)
+    return splats, TrackClosure(splats, cam, tail='fused', candidates=candidates)
+
+
+@pytest.mark.parametrize("n,W,H,shift", [(60000, 640, 480, 0.3), (500000, 640, 480, 0.0), (9000, 320, 240, 0.8)])
+def test_candidate_set_closures_equal_full_path(dev, n, W, H, shift):
+    """per-frame candidate set (gsx_front_candidates): closures that project the candidates' pose-independent records give the
+    SAME tile lists, records and pose gradient, bit for bit, as closures that cull the whole map - at the frame's first pose,
+    at poses inside the margins, and (by falling back on their own) at a pose outside them"""
+    from gslam_amd.synthetic import make_viewmat
+    res = {}
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(H, W, 3, generator=g).to(dev)
+    deltas = [(0.0, 0.0), (0.004, 0.006), (0.012, 0.012), (0.2, 0.3)]        # the last one leaves the 0.02 / 0.02 margins
+    for cand in (False, True):
+        splats, c = _track_closure(dev, n, 5, cand, W, H, shift)
+        V0 = make_viewmat(2.5).to(dev)
+        c.load(V0, img, torch.zeros(2, device=dev))
+        c.prepare()
+        c.load(V0, img, torch.zeros(2, device=dev))
+        if cand:
+            n_cand, _, _ = c.r.candidate_stats()
+            assert 0 < n_cand < n
+        out = []
+        for k, (dr, dtr) in enumerate(deltas):
+            # move the slot's pose (dR / dt of PoseZhou) and re-evaluate through the captured closure; the optimiser's step is
+            # disabled (lr 0) so that the evaluation point is the one set here
+            with torch.no_grad():
+                c.slots.dR.zero_(); c.slots.dt.zero_()
+                c.slots.dR[0, 1] = dr
+                c.slots.dt[0, 0] = dtr
+            c.slots.forward(c.r.viewmats, torch.cuda.current_stream().cuda_stream)
+            c.init_optimizer(10, 0.0, 5, 25)
+            c.launch(1)
+            torch.cuda.synchronize()
+            assert c.r.check_capacity()
+            M = int(c.r.M_dev.item())
+            flat_ids = c.r.slot_flatten_ids()[c.r.flat[:M].long()]
+            out.append((M, c.r.flat[:M].clone(), flat_ids.clone(), c.r.offsets.clone(), c.r.rec.clone(),
+                        c.r.pose_ws.clone()[:c.r.pose_blocks * 12 * 4], c.loss_rows.clone()))
+            if cand:
+                _, mode, fell_back = c.r.candidate_stats()
+                assert mode == (1 if k < 3 else 0), (k, mode)
+                assert fell_back == (0 if k < 3 else 1)
+        res[cand] = out
+    for k in range(len(deltas)):
+        a, b = res[False][k], res[True][k]
+        assert a[0] == b[0] > 0
+        assert torch.equal(a[1], b[1])                       # the same slots in the same order: tile lists bit-exact
+        assert torch.equal(a[2], b[2])                       # ... naming the same (camera, Gaussian) pairs
+        assert torch.equal(a[3], b[3])
+        live = torch.zeros(a[4].shape[0], dtype=torch.bool, device=dev)
+        live[a[1].long()] = True
+        assert torch.equal(a[4][live], b[4][live])           # records of every listed instance: same bits
+        assert torch.equal(a[6], b[6])                       # loss partials of the fused rasteriser: same bits
+        pa, pb = a[5].view(torch.float32), b[5].view(torch.float32)
+        assert float((pa - pb).abs().max()) <= 2e-4 * float(pa.abs().max()) + 1e-12      # (float atomics in the backward)

@@ -159,7 +159,7 @@ def _worker(rank, world, port, q):
     mine = shard.select(window)
     assert mine == [i for i in window if i % world == rank]
     bucket = gdist.StepBucket(shapes, cw, "cpu")
-    assert bucket.flat.numel() == n * 15 + n + cw * 9 + 2 and bucket.world_size == world
+    assert bucket.flat.numel() == n * 15 + n + cw * 9 + 4 and bucket.world_size == world
     assert [tuple(v.shape) for v in bucket.views] == shapes
     # what a rank's launch plan writes: map gradients of its cameras (per-camera mean rule C_local / C of SURVEY 8e folded
     # into the weights), its cameras' pose rows, its share of the loss; rows of other ranks' cameras stay zero
@@ -214,4 +214,4 @@ def test_keyframe_sharded_ba_collectives_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, ok, vis, mx, t, numel in res:
-        assert ok and vis == 5 and mx == 1 and t == 1.0 and numel == 50 * 16 + 5 * 9 + 2
+        assert ok and vis == 5 and mx == 1 and t == 1.0 and numel == 50 * 16 + 5 * 9 + 4       # map | counts | pose rows | 2 loss values + overflow flag + spare
