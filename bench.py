@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads of the 1-GPU line")
     ap.add_argument("--ba-only", action="store_true", help="1 GPU: run the G > 1 workload (configs[3]) on one GPU")
+    ap.add_argument("--full-cycle-only", action="store_true", help="1 GPU: only the full-mapping-cycle variant of the headline")
     ap.add_argument("--diag", default="", help="DIAGNOSTIC runs of the headline with work left out (comma list of "
                     "'no-ba', 'no-out'): the line is marked invalid, it only tells where the frame time goes")
     return ap.parse_args()
@@ -382,6 +383,7 @@ def run_headline(args, dev):
         },
     }
 
+    line["config"]["raster_launch_order"] = tracker.plan.r.balance_note
     if tracker.plan.r.candidates:
         n_cand, mode, fell_back = tracker.plan.r.candidate_stats()
         line["config"]["tracking_candidates"] = {
@@ -462,6 +464,157 @@ def run_headline(args, dev):
         line["stage_us_eager"] = {k: round(v, 2) for k, v in stages.items()}
         tracker.capacity_ok()
     return line, (N, W, H)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# 1 GPU, the reference's WHOLE mapping cycle beside the tracker (second value of the headline workload)
+# ------------------------------------------------------------------------------------------------------------------------
+def run_full_cycle(dev, N, W, H, steps=60, warmup=10):
+    """The headline workload with everything the reference's backend does per idle cycle and per frame, through
+    gslam_amd.backend.Backend's OWN methods on a second host thread and HIP stream (the reference runs the two parties as two
+    processes on one GPU, main.py:61-91): per keyframe interval ``optimize_map()`` (<= 15 iterations, each with the reference's
+    loss read-back and early stop, backend.py:249-407), ``run_pruning()`` (:409-445: render + opacity / size pruning, the map
+    is re-packed when anything goes), ``optimize_poses_lbfgs()`` (:447-506, <= 26 closures over the 8-camera window on the
+    device refiner) and ``sync()`` (:508-519); per frame the 2-camera keyframe test render ``to_insert_keyframe`` (:739-792)
+    with its host reads.  The frontend tracks every frame (36 closures + output render) and takes each SYNC at the next frame
+    boundary; when pruning changed N the map tensors are new and the tracking closure is re-captured, as the product does.
+    Keyframe INSERTION is left out, as in the headline (the window is the pre-seeded 8 keyframes).
+    value = frames / s until both parties have finished the timed frames' work."""
+    import queue
+    import threading
+    from copy import deepcopy
+    from gslam_amd._sync import capture_lock
+    from gslam_amd.backend import Backend, MapConfig
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.messages import BackendMessage
+    from gslam_amd.plan import HipGraph, RenderPlan
+    from gslam_amd.synthetic import make_scene, sequence_param
+    from gslam_amd.tracking import GraphedTracker, TrackingConfig
+    from gslam_amd.transport import receive
+    gt_scene = GaussianSplattingData.from_dict(make_scene(N, 1), dev)
+    n_frames = warmup + steps
+    frames, cam = make_frames(list(range(WINDOW)) + [sequence_param(i) for i in range(n_frames)], W, H, dev, gt_scene)
+    del gt_scene
+    to_backend, to_frontend = queue.Queue(), queue.Queue()
+    be = Backend(MapConfig(device=str(dev)), to_backend, to_frontend)
+    be.splats = GaussianSplattingData.from_dict(make_scene(N, 0), dev)
+    be.initialize_optimizers()
+    for i, f in enumerate(frames[:WINDOW]):
+        f.index = i
+        if i == 0:
+            for p in f.pose.parameters():
+                p.requires_grad_(False)               # the first keyframe's pose stays fixed (backend.py:459-462)
+        f.exposure_params = f.exposure_params.detach()
+        be.keyframes[i] = f
+        be.pose_graph[i] = set()
+    for i in range(WINDOW):
+        be.ba.optimizers.add_pose(be.keyframes[i].pose)
+    be._render_last_keyframe()
+    be.sync()
+    state = {"map": None, "tracker": None, "out": None, "recaptures": 0}
+    conf = TrackingConfig()
+    out_stream = torch.cuda.Stream()
+
+    def take_sync(msg):
+        assert msg[0] == BackendMessage.SYNC
+        new_map, replaced = receive(state["map"], msg[4])
+        if replaced or state["tracker"] is None:
+            state["map"] = new_map
+            state["tracker"] = GraphedTracker(new_map, cam, conf, device_optimizer=True, max_eval=MAX_EVAL)
+            r = RenderPlan(new_map, 1, W, H, render_depth=True, grads='none', Ks=cam.intrinsics)
+            state["out"] = (r, HipGraph(), False)
+            state["recaptures"] += 1
+
+    take_sync(to_frontend.get())
+    counters = {"cycles": 0, "ba_iters": 0, "kf_tests": 0, "pruned": 0, "errors": []}
+    be_stream = torch.cuda.Stream()
+
+    def backend_thread():
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(be_stream):
+                while True:
+                    tok = to_backend.get()
+                    if tok is None:
+                        return
+                    with capture_lock:
+                        if tok[0] == "frame":
+                            torch.cuda.current_stream().wait_event(tok[2])      # the frontend's copy of the frame is complete
+                            last = be.keyframes[sorted(be.keyframes)[-1]]
+                            be.to_insert_keyframe(last, tok[1])
+                            counters["kf_tests"] += 1
+                        else:
+                            n0, s0 = int(be.splats.means.shape[0]), be.total_step
+                            be.pause_map_optim = False
+                            be.optimize_map()
+                            be.run_pruning()
+                            be.optimize_poses_lbfgs()
+                            be.sync()
+                            counters["cycles"] += 1
+                            counters["ba_iters"] += be.total_step - s0
+                            counters["pruned"] += n0 - int(be.splats.means.shape[0])
+                    to_backend.task_done()
+        except BaseException as e:  # noqa: BLE001
+            counters["errors"].append(repr(e))
+            while True:                               # unblock join()
+                try:
+                    to_backend.task_done()
+                except ValueError:
+                    break
+
+    th = threading.Thread(target=backend_thread, daemon=True)
+    th.start()
+
+    def run(first, count):
+        for i in range(first, first + count):
+            f = frames[WINDOW + i]
+            while not to_frontend.empty():
+                take_sync(to_frontend.get())
+            tr = state["tracker"]
+            tr.track(f, sync=False)
+            r, g, captured = state["out"]
+            r.viewmats.copy_(tr.plan.r.viewmats)
+            if not captured:
+                r.probe()
+                out_stream.wait_stream(torch.cuda.current_stream())
+                with capture_lock:
+                    g.capture(out_stream, r.forward)
+                torch.cuda.current_stream().wait_stream(out_stream)
+                state["out"] = (r, g, True)
+            g.launch()
+            # ADD_FRAME ships a copy of the tracked frame (frontend.py:250 deep-copies it into the queue)
+            shipped = deepcopy(f)
+            ev = torch.cuda.Event()
+            ev.record()
+            to_backend.put(("frame", shipped, ev))
+            if (i - warmup) % KF_EVERY == 1:
+                to_backend.put(("cycle",))
+        to_backend.join()
+        torch.cuda.synchronize()
+
+    track_stream = torch.cuda.Stream()
+    track_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(track_stream):
+        run(0, warmup)
+        base = dict(counters)
+        rec0 = state["recaptures"]
+        t0 = time.perf_counter()
+        run(warmup, steps)
+        elapsed = time.perf_counter() - t0
+    to_backend.put(None)
+    th.join(timeout=30.0)
+    ok = state["tracker"].capacity_ok()
+    return {"workload": "configs[2] with the reference's whole mapping cycle (backend.py:843-866): per keyframe interval "
+                        "optimize_map() + run_pruning() + optimize_poses_lbfgs() + sync(), per frame the 2-camera keyframe test "
+                        "render, through gslam_amd.backend.Backend on its own host thread and stream",
+            "frames_per_s": round(steps / elapsed, 2), "ms_per_frame": round(elapsed / steps * 1e3, 3), "frames": steps,
+            "mapping_cycles": counters["cycles"] - base["cycles"],
+            "ba_iterations": counters["ba_iters"] - base["ba_iters"],
+            "keyframe_test_renders": counters["kf_tests"] - base["kf_tests"],
+            "gaussians_pruned_in_timed_region": counters["pruned"] - base["pruned"],
+            "gaussians_at_end": int(be.splats.means.shape[0]),
+            "tracker_recaptures_in_timed_region": state["recaptures"] - rec0,
+            "tile_lists_ok": bool(ok), "errors": counters["errors"]}
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -640,6 +793,10 @@ def main():
     import torch.distributed as td
     gdist.init_from_env(backend=os.environ.get("GSX_DIST_BACKEND"), device=dev)
 
+    if world == 1 and args.full_cycle_only:
+        print(json.dumps(run_full_cycle(dev, args.gaussians or 500_000, args.width, args.height,
+                                        steps=args.steps or 60, warmup=10 if args.warmup is None else args.warmup)), flush=True)
+        return
     if world == 1 and not args.ba_only:
         line, (N, W, H) = run_headline(args, dev)
         if not args.no_extras:
@@ -653,6 +810,11 @@ def main():
             extra["ba_100k_window1"] = {"workload": "BASELINE.json configs[1]: 100k Gaussians, 1 keyframe, full BA step",
                                         "keyframes_per_s": round(r["keyframes_per_s"], 2),
                                         "ms_per_ba_iteration": round(r["ms_per_iter"], 4), "n_isects": r["n_isects_local"]}
+            torch.cuda.empty_cache()
+            try:
+                extra["full_mapping_cycle"] = run_full_cycle(dev, N, W, H)
+            except Exception as e:  # a second value, never at the price of the headline line
+                extra["full_mapping_cycle"] = {"frames_per_s": None, "error": repr(e)}
             line["extra"] = extra
         if not args.no_cpu_baseline:
             try:

@@ -101,6 +101,7 @@ PROTOTYPES = {
     "gsx_host_alloc": (i32, [C.POINTER(vp), C.POINTER(vp), i64]),
     "gsx_host_free": (i32, [vp]),
     "gsx_zero_words": (i32, [vp, i64, vp]),
+    "gsx_probe_wg_placement": (i32, [i32, i32, i32, vp, vp]),
     "gsx_raster_fwd_track_loss": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gsx_tile_balance": (i32, [vp, i64, f32, f32, i32, vp, vp]),
     "gsx_raster_track_fused": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -139,6 +139,42 @@ def _map_tensors(splats):
     return out
 
 
+_PLACEMENT: Dict[tuple, tuple] = {}
+
+
+def placement_ok(dev, n_wgs: int, n_cus: int, lds_bytes: int = 25 * 1024):
+    """Does workgroup i of an ``n_wgs``-workgroup launch (256 threads, the rasteriser's LDS footprint, all resident at once)
+    share its compute unit with workgroups i + G, i + 2 G, ... on this device?  The CU-balanced launch order
+    (csrc/tile_balance.h) deals the tiles into G groups on that assumption - an undocumented property of the dispatcher,
+    traced on MI355X / ROCm 7.2.  Probed ONCE per (device, shape) on a drained chip (gsx_probe_wg_placement,
+    ~50 us); on a mismatch the plans keep the identity / heaviest-first order and the reason is logged.  -> (ok, note)"""
+    key = (str(dev), int(n_wgs), int(n_cus), int(lds_bytes))
+    hit = _PLACEMENT.get(key)
+    if hit is not None:
+        return hit
+    if torch.cuda.is_current_stream_capturing():
+        return False, "placement probe skipped (stream is capturing)"
+    torch.cuda.synchronize(dev)
+    keys = torch.full((n_wgs,), -1, dtype=torch.int32, device=dev)
+    check(lib.gsx_probe_wg_placement(int(n_wgs), int(lds_bytes), 30, _p(keys), current_stream_ptr(dev)),
+          "gsx_probe_wg_placement")
+    k = keys.cpu()
+    first = k[:n_cus]
+    distinct = int(torch.unique(first).numel())
+    same = bool((k == first[torch.arange(n_wgs) % n_cus]).all())
+    if distinct == n_cus and same:
+        res = (True, f"cu-balanced (placement probe ok: {n_wgs} workgroups on {n_cus} compute units, i and i + {n_cus} "
+                     "share one)")
+    else:
+        bad = int((k != first[torch.arange(n_wgs) % n_cus]).sum())
+        res = (False, f"identity order (placement probe FAILED: {distinct} distinct compute units among the first {n_cus} "
+                      f"workgroups, {bad} of {n_wgs} workgroups off the i mod {n_cus} pattern)")
+        import warnings
+        warnings.warn("gslam_amd: " + res[1])
+    _PLACEMENT[key] = res
+    return res
+
+
 class RenderPlan:
     """One render of gslam ``rasterization()`` (gslam/rasterization.py:44-360 with the live argument set of
     gslam/map.py:88-103) and its backward, as launches over buffers owned by the plan.
@@ -241,6 +277,7 @@ class RenderPlan:
         # and at most five per CU) runs as long as its most loaded CU; enable_balance() makes the rasteriser launches follow
         # an order computed from the work the tiles took in an earlier closure
         self.tile_work = self.balanced_order = None
+        self.balance_note = "identity / heaviest-first order (shape does not qualify for the balanced order)"
         self.n_cus = int(torch.cuda.get_device_properties(dev).multi_processor_count) if dev.type == 'cuda' else 0
         self.last_M = 0
         self.stale = False          # set when the buffers were re-allocated: graphs over the old ones must be re-captured
@@ -449,10 +486,14 @@ class RenderPlan:
     LIGHT_RATE = 0.92       # a CU with 4 workgroups gets through 0.92 of the work of one with 5 in the same time (same trace)
 
     def enable_balance(self) -> bool:
-        """-> whether this render's shape qualifies (all workgroups resident at once, several per CU)"""
+        """-> whether this render's shape qualifies (all workgroups resident at once, several per CU) AND the dispatcher
+        places workgroups the way the balanced order assumes (``placement_ok``: probed once per device and shape)"""
         if self.front and self.n_cus and self.n_cus < self.T <= min(5 * self.n_cus, 2048) and self.balanced_order is None:
-            self.balanced_order = torch.arange(self.T, dtype=torch.int32, device=self.dev)
-            self.tile_work = torch.zeros(self.T, 2, dtype=torch.int32, device=self.dev)
+            ok, why = placement_ok(self.dev, self.T, self.n_cus)
+            self.balance_note = why
+            if ok:
+                self.balanced_order = torch.arange(self.T, dtype=torch.int32, device=self.dev)
+                self.tile_work = torch.zeros(self.T, 2, dtype=torch.int32, device=self.dev)
         return self.balanced_order is not None
 
     def rebalance(self, st: int):

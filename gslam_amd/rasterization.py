@@ -201,9 +201,6 @@ def rasterization(
     assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
     if covars is not None:
         raise NotImplementedError("covars= is a dead branch in the reference (rasterization.py:129-134 vs :147)")
-    if packed:
-        raise NotImplementedError("packed=True is not used on the gslam hot path (map.py:99 passes packed=False); "
-                                  "use gslam_amd.rasterization.get_new_splat_depth for the packed projection")
     if rasterize_mode != "classic" or camera_model != "pinhole" or sparse_grad:
         raise NotImplementedError("only rasterize_mode='classic', camera_model='pinhole', sparse_grad=False")
     if logit_colors.dim() != 2 or logit_colors.shape != (N, 3):
@@ -238,6 +235,16 @@ def rasterization(
         means, quats, log_scales, viewmats, Ks, logit_opacities, logit_colors, log_uncertainties, int(width),
         int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip), False, flags, True, True,
         True, v_rec_buf)
+
+    packed_means2d = packed_sel = None
+    if packed:
+        # packed=True: the [nnz, 2] means2d the caller gets must be the node the rasteriser's gradient passes through
+        # (means2d.retain_grad() on the packed array, as with gsplat's packed projection): pack first, and hand the
+        # rasteriser the dense array rebuilt from the packed rows (same values: culled rows are zero either way)
+        packed_sel = torch.nonzero((radii > 0).reshape(-1)).squeeze(1)
+        packed_means2d = means2d.reshape(-1, 2)[packed_sel]
+        means2d = torch.zeros(C * N, 2, dtype=means2d.dtype, device=means2d.device).index_put(
+            (packed_sel,), packed_means2d).view(C, N, 2)
 
     # backgrounds: [C,3] + 0 for depth + e^1 for beta (rasterization.py:236-239,251-255)
     bg = _packed_backgrounds(backgrounds, C, depth_index is not None, betas_index is not None)
@@ -299,7 +306,31 @@ def rasterization(
         out.betas = render[..., betas_index]
     # private extras for the fused loss (gslam_amd.losses): the un-split render and per-Gaussian visibility counts
     out._render, out._depth_index, out._betas_index, out._vis_count = render, depth_index, betas_index, vis_count
+    if packed:
+        _pack_output(out, N, C, packed_sel, packed_means2d)
     return out
+
+
+def _pack_output(out: RasterizationOutput, N: int, C: int, sel: Tensor, means2d_packed: Tensor) -> None:
+    """packed=True (the signature's default, gslam/rasterization.py:58,174-182): the images are those of the dense render -
+    packing is a layout of the per-(camera, Gaussian) arrays - and the per-pair fields become [nnz, ...] over the visible
+    pairs in flatten-id order with ``camera_ids`` / ``gaussian_ids`` beside them, as gsplat's packed projection returns
+    them; ``flatten_ids`` then index those packed rows.  The row selection is differentiable indexing, so ``means2d`` is
+    still a graph node that supports ``retain_grad()`` (backend.py:326).  One host sync (nnz), as in the reference's packed
+    path; the only caller in the reference passes packed=False (map.py:99)."""
+    vis = out.radii > 0                                                   # sel: flatten ids of the visible pairs, ascending
+    out.camera_ids, out.gaussian_ids = sel // N, sel % N
+    rank = torch.cumsum(vis.reshape(-1).to(torch.int64), 0) - 1           # flatten id -> packed row
+    take = lambda t, tail=(): t.reshape((C * N,) + tuple(tail))[sel]
+    out.radii = take(out.radii)
+    out.means2d = means2d_packed
+    out.depths = take(out.depths)
+    out.conics = take(out.conics, (3,))
+    out.opacities = take(out.opacities)
+    out.tiles_per_gauss = take(out.tiles_per_gauss)
+    if out.n_touched is not None:
+        out.n_touched = take(out.n_touched)
+    out._flatten_ids = rank[out.flatten_ids.long()].to(torch.int32)       # (the property materialises the sync-free buffers)
 
 
 def get_new_splat_depth(new_params: dict, viewmats: Tensor, Ks: Tensor, width: int, height: int,

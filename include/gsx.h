@@ -443,6 +443,11 @@ int gsx_host_alloc(void **host_out, void **dev_out, int64_t bytes);
 int gsx_host_free(void *host);
 /* n_words 4-byte words at ptr := 0, by a kernel (a captured hipMemsetAsync node misbehaved on replay, ROCm 7.2) */
 int gsx_zero_words(void *ptr, int64_t n_words, void *stream);
+/* Self-check of the CU-balanced launch order (gsx_tile_balance): n_wgs workgroups of 256 threads and lds_bytes of LDS that
+ * stay resident for spin_us microseconds write where they ran: keys[i] = XCC_ID << 8 | SE_ID << 5 | SH_ID << 4 | CU_ID of
+ * workgroup i.  The balanced order assumes keys[i] == keys[i mod G] with G distinct values on a drained chip; the host
+ * verifies that once per device and shape and falls back to the identity order otherwise. */
+int gsx_probe_wg_placement(int n_wgs, int lds_bytes, int spin_us, int32_t *keys, void *stream);
 
 /* ---- self tests of device primitives (wave64 reductions); returns 0 if all pass.  scratch: >= 64 KiB device ----- */
 int gsx_selftest(void *scratch, int64_t scratch_bytes, void *stream);

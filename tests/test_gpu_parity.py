@@ -684,3 +684,40 @@ def test_pose_batch_matches_reference_and_torch(dev):
     (V0[0] * torch.from_numpy(g["w"]).to(dev)).sum().backward()
     np.testing.assert_allclose(_np(p0.dR.grad), g["grad_dR"], atol=1e-5)
     np.testing.assert_allclose(_np(p0.dt.grad), g["grad_dt"], atol=1e-5)
+
+
+def test_gslam_rasterization_packed_default(dev, oracle32):
+    """rasterization(packed=True) - the signature's DEFAULT (gslam/rasterization.py:58) - returns the same images and the
+    per-pair arrays packed over the visible pairs in flatten-id order, as gsplat's packed projection lays them out
+    (rasterization.py:174-182); gradients through the packed means2d equal those of the dense call"""
+    from gslam_amd.rasterization import rasterization
+    n, c, W, H = 3000, 2, 320, 240
+    sc, viewmats, Ks = _scene(n, 14, c, W, H)
+    names = ("means", "quats", "scales", "opacities", "colors", "log_uncertainties")
+    res = []
+    for packed in (False, True):
+        pa = {k: sc[k].clone().to(dev).requires_grad_(True) for k in names}
+        kw = {} if packed else {"packed": False}                  # packed=True via the default
+        out = rasterization(pa["means"], pa["quats"], pa["scales"], pa["opacities"], pa["colors"], viewmats.to(dev),
+                            Ks.to(dev), W, H, render_mode="RGB+D", log_uncertainties=pa["log_uncertainties"],
+                            backgrounds=torch.zeros(c, 3, device=dev), **kw)
+        out.means2d.retain_grad()
+        (out.rgbs.square().sum() + out.depthmaps.sum() + 0.1 * out.means2d.sum()).backward()
+        res.append((out, pa))
+    (d, pd), (p, pp) = res
+    assert torch.equal(d.rgbs, p.rgbs) and torch.equal(d.alphas, p.alphas) and torch.equal(d.depthmaps, p.depthmaps)
+    vis = d.radii > 0
+    sel = torch.nonzero(vis.reshape(-1)).squeeze(1)
+    nnz = int(sel.shape[0])
+    assert 0 < nnz < c * n and p.camera_ids.shape == p.gaussian_ids.shape == (nnz,)
+    assert torch.equal(p.camera_ids * n + p.gaussian_ids, sel)
+    assert torch.equal(p.radii, d.radii.reshape(-1)[sel]) and torch.equal(p.means2d, d.means2d.reshape(-1, 2)[sel])
+    assert torch.equal(p.depths, d.depths.reshape(-1)[sel]) and torch.equal(p.conics, d.conics.reshape(-1, 3)[sel])
+    assert torch.equal(p.opacities, d.opacities.reshape(-1)[sel]) and torch.equal(p.n_touched, d.n_touched.reshape(-1)[sel])
+    assert torch.equal(sel[p.flatten_ids.long()], d.flatten_ids.long())        # packed rows <-> flatten ids, same lists
+    assert torch.equal(p.isect_ids, d.isect_ids) and torch.equal(p.isect_offsets, d.isect_offsets)
+    assert p.means2d.grad.shape == (nnz, 2)
+    assert float((p.means2d.grad - d.means2d.grad.reshape(-1, 2)[sel]).abs().max()) <= 1e-4 * float(d.means2d.grad.abs().max())
+    for k in names:
+        a, b = pp[k].grad, pd[k].grad
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9, k

@@ -589,3 +589,19 @@ def test_candidate_set_closures_equal_full_path(dev, n, W, H, shift):
         assert torch.equal(a[6], b[6])                       # loss partials of the fused rasteriser: same bits
         pa, pb = a[5].view(torch.float32), b[5].view(torch.float32)
         assert float((pa - pb).abs().max()) <= 2e-4 * float(pa.abs().max()) + 1e-12      # (float atomics in the backward)
+
+
+def test_balanced_order_placement_probe(dev):
+    """the start-up self-check behind the CU-balanced launch order: on a drained MI355X workgroups i and i + G share a compute
+    unit (G = 256); a shape for which that cannot hold (more distinct units asked for than exist) reports failure with a
+    reason instead of a silent order"""
+    import warnings
+    from gslam_amd.plan import placement_ok
+    n_cus = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    ok, note = placement_ok(dev, 1200, n_cus)
+    assert ok, note
+    assert "probe ok" in note
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        bad, why = placement_ok(dev, 1200, n_cus + 37)       # a wrong G: the pattern cannot hold
+        assert not bad and "FAILED" in why and len(w) == 1

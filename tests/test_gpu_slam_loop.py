@@ -9,6 +9,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# bounds of the end-to-end assertion below: ~3x the values measured on MI355X (printed by the test)
+ATE_BOUND_M, PSNR_BOUND_DB, SSIM_BOUND = 0.04, 17.0, 0.6      # measured: 1.2 cm, 21.5 dB, 0.77 (13 frames, 0.3 m path)
+
 
 @pytest.fixture(scope="module")
 def dev():
@@ -86,6 +89,21 @@ def test_slam_loop_messages_and_tracking(dev):
         assert p.shape[0] == n, name
     st = be.ba.optimizers.splat_opt.state[be.splats.means]
     assert st["exp_avg"].shape[0] == n
+    # ---- end-to-end quality on the synthetic sequence (gslam/trajectory.py:14-97, gslam/frontend.py:374-409) ---------------------
+    # the map starts from a MOCK depth map (monocular initialisation, backend.py:604-660), so scale is free: the absolute
+    # trajectory error is taken after the similarity alignment the reference uses (Kabsch-Umeyama).  The camera moves 2.5 cm
+    # and 1 degree per frame over 13 frames (path length 0.3 m).
+    import numpy as np
+    from gslam_amd.evaluation import evaluate_reconstruction, to_uint8
+    from gslam_amd.trajectory import evaluate_trajectories
+    ates = evaluate_trajectories({"frontend": fe.frames, "keyframes": list(be.keyframes.values())})
+    kfs = list(be.keyframes.values())
+    rec = evaluate_reconstruction(be.splats, kfs, [to_uint8(f.img) for f in kfs])
+    print(f"slam loop quality: ATE frontend {ates['ate_frontend'] * 100:.2f} cm, keyframes {ates['ate_keyframes'] * 100:.2f} cm "
+          f"over {len(fe.frames)} frames; keyframe renders PSNR {rec['psnr']:.2f} dB, SSIM {rec['ssim']:.3f} "
+          f"({n} Gaussians after {be.total_step} mapping iterations)")
+    assert np.isfinite(ates["ate_frontend"]) and ates["ate_frontend"] < ATE_BOUND_M
+    assert rec["psnr"] > PSNR_BOUND_DB and rec["ssim"] > SSIM_BOUND
     # end of stream: None -> END_SYNC with the final map
     to_backend.put(None)
     assert not be.handle(to_backend.get())
