@@ -18,8 +18,8 @@
   closure launches are issued for every frame whether or not the line search converged earlier.
 
 --gpus G > 1 = BASELINE.json configs[3], STRONG scaling of keyframe bundle adjustment: 2 M Gaussians, a fixed window of 8
-keyframes dealt round-robin over the G ranks, one all-reduce of the step bucket (map + pose gradients, visibility counts,
-loss) per iteration over RCCL; value = keyframe renders (forward + backward) per second over the whole job = 8 x BA
+keyframes dealt round-robin over the G ranks, the update sharded over Gaussians (head all-reduce, reduce-scatter of the
+gradient bucket, Adam on each rank's chunk, all-gather of the parameters) over RCCL; value = keyframe renders (forward + backward) per second over the whole job = 8 x BA
 iterations / s.  The 1-GPU value of the SAME workload is measured by the --gpus 1 run as well and reported there as
 ``extra.ba_2m_window8`` so that the scaling curve has its 1-GPU point next to the headline.
 
@@ -672,8 +672,9 @@ def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=F
         print(f"bench.py[rank {rank}]: tile-list overflow on attempt {attempt}, re-running", file=sys.stderr)
     else:
         raise RuntimeError("tile lists kept overflowing")
-    # the collective alone, same bucket
-    reduce_us = None
+    # the collectives alone, same buffers: head all-reduce + reduce-scatter of the gradient bucket, and the all-gather of the
+    # updated parameter chunks
+    reduce_us = gather_us = None
     if world > 1:
         barrier()
         t0 = time.perf_counter()
@@ -681,11 +682,17 @@ def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=F
             plan.reduce()
         barrier()
         reduce_us = (time.perf_counter() - t0) / 10 * 1e6
-        t = torch.tensor([elapsed, reduce_us], device=dev, dtype=torch.float64)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            plan.gather_params()
+        barrier()
+        gather_us = (time.perf_counter() - t0) / 10 * 1e6
+        t = torch.tensor([elapsed, reduce_us, gather_us], device=dev, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed, reduce_us = float(t[0]), float(t[1])
+        elapsed, reduce_us, gather_us = float(t[0]), float(t[1]), float(t[2])
     res = {"elapsed": elapsed, "ms_per_iter": elapsed / steps * 1e3, "keyframes_per_s": window_size * steps / elapsed,
-           "reduce_us": reduce_us, "bucket_bytes": int(plan.flat.numel() * 4),
+           "reduce_us": reduce_us, "gather_us": gather_us, "bucket_bytes": int(plan.flat.numel() * 4),
+           "head_bytes": int(plan.bucket.head.numel() * 4),
            "n_isects_local": int(plan.r.M_dev.item()) if plan.r is not None else 0, "local_cameras": len(plan.mine)}
     if stage_timing and rank == 0 and plan.r is not None:
         from gslam_amd.plan import current_stream_ptr
@@ -852,14 +859,18 @@ def main():
                             "window sharded across the GPUs (step = one BA iteration: render fwd+bwd CH=5 + full mapping loss + "
                             "fused Adam)",
                 "gaussians": N, "width": W, "height": H, "window": WINDOW, "cameras_on_rank0": r["local_cameras"],
-                "parallelism": f"keyframe-sharded BA x{world}: one all-reduce(sum) of a {r['bucket_bytes'] / 1e6:.1f} MB fp32 bucket "
-                               "(map + pose gradients, visibility counts, loss) per iteration over RCCL",
-                "launch": "hip-graph replay (render+loss+backward | isotropic+Adam) around one eager all-reduce"
+                "parallelism": f"keyframe-sharded BA x{world}, update sharded over Gaussians: all-reduce of a "
+                               f"{r['head_bytes'] / 1e6:.1f} MB head (visibility counts, pose gradients, loss, overflow flag), "
+                               f"reduce-scatter of the {r['bucket_bytes'] / 1e6:.1f} MB fp32 gradient bucket, Adam on each rank's "
+                               f"1/{world} of the map, all-gather of the updated parameter chunks, over RCCL",
+                "launch": "hip-graph replay (render+loss+backward | Adam on the rank's chunk) around the eager collectives"
                           if world > 1 else "hip-graph replay of the whole step",
             },
             "one_gpu_reference": one_gpu,
-            "all_reduce_us": None if r["reduce_us"] is None else round(r["reduce_us"], 1),
-            "all_reduce_algbw_gbs": None if not r["reduce_us"] else round(r["bucket_bytes"] / r["reduce_us"] * 1e-3, 1),
+            "reduce_us": None if r["reduce_us"] is None else round(r["reduce_us"], 1),
+            "gather_us": None if r.get("gather_us") is None else round(r["gather_us"], 1),
+            "collectives_algbw_gbs": None if not r["reduce_us"] else round(
+                2.0 * r["bucket_bytes"] / (r["reduce_us"] + r["gather_us"]) * 1e-3, 1),
             "rccl": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "RCCL_MSCCL_ENABLE") if os.environ.get(k)},
         }
         if "stage_us" in r:

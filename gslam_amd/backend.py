@@ -214,6 +214,7 @@ class Backend:
                                           means2d=torch.zeros(0, n, 2, device=dev), width=plan.W, height=plan.H,
                                           n_cameras=0)
             outputs.means2d.grad = torch.zeros(0, n, 2, device=dev)
+        self.ba.sync_moments()
         self.insertion_3dgs.step(self.splats, self.splat_optimizers, outputs, None, None,
                                  window_cameras=plan.Cw, reduce_sum=shard.all_reduce_sum if shard.world_size > 1 else None)
 
@@ -248,6 +249,7 @@ class Backend:
                 bad_views = torch.zeros(n, dtype=torch.int32, device=dev)
             shard.all_reduce_sum(bad_views)
             remove |= bad_views > self.pruning_conditioning.max_frames_thing      # = PruneIllConditionedGaussians.step
+        self.ba.sync_moments()                      # (multi-GPU: whole moments on every rank before the rows move)
         remove |= self.pruning_size.step(self.splats, self.splat_optimizers, max_radii)
         remove |= self.pruning_opacity.step(self.splats, self.splat_optimizers)
         if prune_using_mask(self.splats, self.splat_optimizers, ~remove) > 0:
@@ -352,6 +354,7 @@ class Backend:
         with torch.no_grad():
             outputs = self.splats([frame.camera], [frame.pose], render_depth=True)
         outputs.depthmaps = outputs.depthmaps * conf.initial_scale
+        self.ba.sync_moments()
         self.insertion_depth_map.step(self.splats, self.splat_optimizers, outputs, frame, N=100,
                                       keyframes=list(self.keyframes.values()))
         self.ba.map_changed()

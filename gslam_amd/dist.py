@@ -2,11 +2,13 @@
 (backend "nccl" on ROCm; "gloo" in the CPU tests).  New design - the reference is single-GPU with no collectives
 (SURVEY.md §2.1, §8e).
 
-Partitioning: the map (60 B/Gaussian params + 60 B grads + 120 B Adam state) is replicated; rank r renders the
-keyframes {c : c mod G == r} of the BA window.  Per iteration there is exactly ONE data-path collective: an
-all-reduce(sum) of a single contiguous fp32 bucket (``StepBucket``: map gradients, visibility counts, pose gradients,
-loss terms).  xGMI is point-to-point (7 links x ~153 GB/s per GPU): one large bucket lets RCCL drive all links; many
-small per-tensor all-reduces would be latency-bound.  Between iterations: all-reduce(max) of the screen radii before
+Partitioning: the map's parameters (60 B/Gaussian) are replicated, rank r renders the keyframes {c : c mod G == r} of the BA
+window, and the UPDATE is sharded over Gaussians: per iteration one small all-reduce of the "head" (visibility counts, pose
+gradients, loss, overflow flag), one reduce-scatter of the flat gradient bucket (rank r receives the window-wide sum of
+chunk r), Adam on that 1/G of the map (the moments live only on their owner: 120 B/Gaussian / G) and one all-gather of the
+updated parameter chunks (``StepBucket``).  Same bytes on the wire as an all-reduce of the bucket, optimiser time / G.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): two large collectives let RCCL drive all links; per-tensor
+collectives would be latency-bound.  Between iterations: all-reduce(max) of the screen radii before
 size pruning (backend.py:364) and all-reduce(sum) of the densification statistic (insertion.py:298-308), both
 ``KeyframeShard`` helpers called by gslam_amd.backend.
 """
@@ -70,62 +72,150 @@ class KeyframeShard:
                 td.broadcast(t, src=src, group=self.group)
 
 
+def bucket_layout(shapes: Sequence[Sequence[int]], world: int):
+    """tensor-major layout of the six per-Gaussian arrays in ONE flat fp32 buffer: every array starts on a 16-byte boundary
+    and the whole is padded to ``world`` chunks of equal length L (a multiple of 4 floats).  The parameters, their gradients
+    and the two Adam moments all use this layout, so chunk r of one is chunk r of the others.
+    -> (offsets, numels, S_pad, L)"""
+    offs, numels, off = [], [], 0
+    for s in shapes:
+        k = int(torch.Size(tuple(int(x) for x in s)).numel())
+        offs.append(off)
+        numels.append(k)
+        off += (k + 3) // 4 * 4
+    unit = 4 * max(int(world), 1)
+    s_pad = (off + unit - 1) // unit * unit
+    return offs, numels, s_pad, s_pad // max(int(world), 1)
+
+
 class StepBucket:
-    """Everything one BA iteration sums over ranks, in ONE flat fp32 buffer:
+    """What one BA iteration exchanges between ranks (new design: the reference is single-GPU).
 
-        [ N*15 map gradients | N visible-camera counts | Cw*3 pose dt gradients | Cw*6 pose dR gradients | 2 loss values |
-          overflow flag | spare ]
+    ``flat`` - the map gradients of this rank's cameras, tensor-major (``bucket_layout``): means3 | quats4 | scales3 |
+    opac1 | colors3 | log_unc1 per Gaussian, 15 N floats.  The kernels of a launch plan (gslam_amd.plan.MappingStep) write
+    straight into the views; between ranks it goes through ONE reduce-scatter: rank r receives the window-wide sum of chunk r
+    (``gchunk``), runs Adam on that 1/G of the map (its slices of the parameters and of the moments) and the updated
+    parameter chunks come back to everybody through ONE all-gather - the same bytes on the wire as an all-reduce of the
+    bucket, the optimiser's 28 B per parameter divided by G, and moments that are only ever valid on their owner.
 
-    (means3 + quats4 + scales3 + opac1 + colors3 + log_unc1 = 15 columns; Cw = cameras of the whole BA window).  The
-    kernels of a launch plan (gslam_amd.plan.MappingStep) write their outputs straight into the views below - no
-    cat / split copies - and ``reduce()`` is the single all-reduce(sum) of the iteration: it carries the map gradients,
-    the per-Gaussian visibility counts (isotropic term backend.py:287, opacity decay :357; exact in fp32: counts <= C),
-    the pose gradients (each rank fills the rows of the cameras it rendered, the rest are zero) and the loss terms
-    (each rank's share of the window means), so every rank can apply the identical update to the map and to ALL window
-    poses and take the identical early-stop decision without a second collective or a pose broadcast.  The overflow flag
-    (1.0 from every rank whose render truncated a tile list this iteration, gsx_status_flag) rides in the same sum: the
-    update launches are gated on it ON THE DEVICE (gsx_adam_multi_steps_gated), so either every rank applies the iteration's
-    update or none does, and every rank reads the same flag next to the loss value - the decision to redo an iteration is
-    collective by construction."""
+    ``head`` - what every rank needs whole, in one small all-reduce BEFORE the reduce-scatter: the per-Gaussian
+    visible-camera counts (isotropic term backend.py:287, opacity decay :357; exact in fp32, counts <= C), the pose
+    gradients of all window cameras (each rank fills its cameras' rows; every rank then applies the identical pose update),
+    the loss values (each rank's share of the window means) and the overflow flag (1.0 from every rank whose render
+    truncated a tile list: the update launches are gated on the sum ON THE DEVICE, so every rank applies the iteration or
+    none does and they all read the same flag with the loss - the decision to redo an iteration is collective by
+    construction).   [ N counts | Cw*3 dt | Cw*6 dR | total, photometric | overflow, spare ]
 
-    def __init__(self, shapes: Sequence[Sequence[int]], n_window_cams: int, device, group=None):
+    One rank: no collective; ``flat`` and the head's tail are simply where the kernels leave their results."""
+
+    def __init__(self, shapes: Sequence[Sequence[int]], n_window_cams: int, device, group=None, world: int | None = None,
+                 rank: int | None = None):
+        """world / rank: default = those of ``group`` (the default process group); world = 1 makes a local bucket whatever
+        process group exists (the single-rank reference of the multi-rank tests)"""
         self.group = group
         shapes = [tuple(int(x) for x in s) for s in shapes]
         self.N = n = shapes[0][0]
         self.Cw = cw = int(n_window_cams)
-        numels = [int(torch.Size(s).numel()) for s in shapes]
-        n_map = sum(numels)
-        self.flat = torch.zeros(n_map + n + cw * 9 + 4, dtype=torch.float32, device=device)
-        self.views, off = [], 0
-        for s, k in zip(shapes, numels):
-            self.views.append(self.flat[off:off + k].view(s))
-            off += k
-        self.map_part = self.flat[:n_map]
-        self.counts = self.flat[off:off + n]; off += n
-        self.tail = self.flat[off:]                       # pose rows + loss slots: re-zeroed every iteration when sharded
-        self.g_dt = self.flat[off:off + cw * 3].view(cw, 3); off += cw * 3
-        self.g_dR = self.flat[off:off + cw * 6].view(cw, 6); off += cw * 6
-        self.out2 = self.flat[off:off + 2]
-        self.overflow = self.flat[off + 2:off + 3]         # > 0 after the reduction: some rank's tile lists overflowed
-        self.out4 = self.flat[off:off + 4]                 # (total, photometric, overflow flag, spare): one read-back
+        self.world = self.world_size if world is None else int(world)
+        self.rank = (td.get_rank(group) if self.world > 1 else 0) if rank is None else int(rank)
+        self.offsets, self.numels, self.S_pad, self.L = bucket_layout(shapes, self.world)
+        self.flat = torch.zeros(self.S_pad, dtype=torch.float32, device=device)
+        self.views = [self.flat[o:o + k].view(s) for s, o, k in zip(shapes, self.offsets, self.numels)]
+        self.map_part = self.flat
+        self.head = torch.zeros(n + cw * 9 + 4, dtype=torch.float32, device=device)
+        self.counts = self.head[:n]
+        off = n
+        self.tail = self.head[off:]                       # pose rows + loss slots + flag: re-zeroed every iteration when sharded
+        self.g_dt = self.head[off:off + cw * 3].view(cw, 3); off += cw * 3
+        self.g_dR = self.head[off:off + cw * 6].view(cw, 6); off += cw * 6
+        self.out2 = self.head[off:off + 2]
+        self.overflow = self.head[off + 2:off + 3]        # > 0 after the reduction: some rank's tile lists overflowed
+        self.out4 = self.head[off:off + 4]                # (total, photometric, overflow flag, spare): one read-back
         self.vis_i32 = torch.zeros(n, dtype=torch.int32, device=device)   # window-wide counts after the reduction
+        # this rank's chunk of the summed gradients (what its slice of Adam reads)
+        self.gchunk = torch.zeros(self.L, dtype=torch.float32, device=device) if self.world > 1 else None
 
     @property
     def world_size(self) -> int:
         return td.get_world_size(self.group) if (td.is_available() and td.is_initialized()) else 1
 
+    def chunk_range(self, rank: int | None = None):
+        r = self.rank if rank is None else int(rank)
+        return r * self.L, (r + 1) * self.L
+
+    def pieces(self, rank: int | None = None):
+        """[(tensor index k, start inside tensor k, length, start inside the chunk)] - the slices of the six arrays that
+        rank's chunk covers (boundaries fall on multiples of 4 floats: 16-byte accesses everywhere)"""
+        lo, hi = self.chunk_range(rank)
+        out = []
+        for k, (o, n) in enumerate(zip(self.offsets, self.numels)):
+            a, b = max(lo, o), min(hi, o + n)
+            if b > a:
+                out.append((k, a - o, b - a, a - lo))
+        return out
+
     @torch.no_grad()
-    def reduce(self, local_vis: torch.Tensor | None):
-        """local_vis: this rank's int32 [N] visible-camera counts, or None when it rendered no camera of the window (a
-        window shorter than the world size): it then contributes zeros and still joins the collective"""
-        if self.world_size == 1:
+    def reduce(self, local_vis: torch.Tensor | None, between=None):
+        """The gradient exchange of one iteration: all-reduce of the head, then - with the window-wide visibility known -
+        ``between()`` (the plan adds what depends on it to the LOCAL gradients: the isotropic term, on rank 0 alone so that
+        it enters the sum once), then the reduce-scatter of the gradient bucket into ``gchunk``.
+        local_vis: this rank's int32 [N] visible-camera counts, or None when it rendered no camera of the window (a window
+        shorter than the world size): it then contributes zeros and still joins the collectives"""
+        if self.world == 1:
             if local_vis is not None:
                 self.vis_i32.copy_(local_vis)
             return
         if local_vis is not None:
             self.counts.copy_(local_vis)
         else:
-            self.map_part.zero_()
+            self.flat.zero_()
             self.counts.zero_()
-        td.all_reduce(self.flat, op=td.ReduceOp.SUM, group=self.group)
+        td.all_reduce(self.head, op=td.ReduceOp.SUM, group=self.group)
         self.vis_i32.copy_(self.counts)
+        if between is not None:
+            between()
+        td.reduce_scatter_tensor(self.gchunk, self.flat, op=td.ReduceOp.SUM, group=self.group)
+
+    @torch.no_grad()
+    def gather(self, whole: torch.Tensor, staging: torch.Tensor):
+        """all-gather of a chunked flat buffer (updated parameters after the sharded Adam; the moments before the map is
+        re-packed): ``whole`` [S_pad] holds this rank's valid chunk, every rank ends with all of it.  ``staging`` [L]."""
+        if self.world == 1:
+            return
+        lo, hi = self.chunk_range()
+        staging.copy_(whole[lo:hi])
+        td.all_gather_into_tensor(whole, staging, group=self.group)
+
+
+def flatten_map_state(splats, opt, bucket: StepBucket):
+    """Re-homes the six per-Gaussian parameter tensors of ``splats`` and their Adam moments (``opt``: the FusedAdam that owns
+    them) into three flat buffers of the bucket's layout - the tensors keep their shapes and become views - so that chunk r of
+    the parameters, of the gradients and of both moments is the same slice of the map.  Idempotent while the map's tensors
+    stay where this put them (every launch plan over the same map shares the buffers); a re-packed map (pruning, insertion)
+    has new tensors and is flattened again by its next plan.  -> dict(pflat, mflat, vflat, stage, sharded)"""
+    params = [getattr(splats, n) for n in GRAD_PARAMS]
+    st = getattr(splats, "_gsx_flat", None)
+    if st is not None and st["S_pad"] == bucket.S_pad and st["offsets"] == bucket.offsets and all(
+            p.data_ptr() == st["pflat"].data_ptr() + 4 * o and p.numel() == k
+            for p, o, k in zip(params, bucket.offsets, bucket.numels)):
+        return st
+    dev = params[0].device
+    pflat = torch.zeros(bucket.S_pad, dtype=torch.float32, device=dev)
+    mflat, vflat = torch.zeros_like(pflat), torch.zeros_like(pflat)
+    with torch.no_grad():
+        for p, o, k in zip(params, bucket.offsets, bucket.numels):
+            if not (p.is_cuda and p.dtype == torch.float32):
+                raise RuntimeError("sharded update needs float32 map tensors on the GPU")
+            view = pflat[o:o + k].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            state = opt.state[p]
+            for name, flat in (("exp_avg", mflat), ("exp_avg_sq", vflat)):
+                mv = flat[o:o + k].view(p.shape)
+                if name in state:
+                    mv.copy_(state[name])
+                state[name] = mv
+    st = dict(pflat=pflat, mflat=mflat, vflat=vflat, stage=torch.zeros(bucket.L, dtype=torch.float32, device=dev),
+              S_pad=bucket.S_pad, offsets=list(bucket.offsets), sharded=False)
+    splats._gsx_flat = st
+    return st

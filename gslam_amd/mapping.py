@@ -137,6 +137,15 @@ class BundleAdjuster:
         self.last_outputs: Optional[RasterizationOutput] = None
         self._plans: dict = {}
 
+    def sync_moments(self):
+        """Multi-GPU, before anything re-packs the map (pruning, insertion): the sharded update keeps each Adam moment valid
+        on its owner only, and a re-pack moves rows between the owners' chunks - every rank gets both moments whole first (two
+        all-gathers; a collective: all ranks call it at the same point of the loop).  No-op on one rank."""
+        for p in self._plans.values():
+            if getattr(p, "world", 1) > 1 and p.flat_state is not None and p.matches(self.splats, p.window):
+                p.gather_moments()
+                return
+
     def map_changed(self):
         """call after gslam_amd.pruning / gslam_amd.insertion re-packed the map (new parameter tensors, new N): launch
         plans and their captured graphs describe the old tensors and are dropped"""

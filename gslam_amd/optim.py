@@ -131,11 +131,23 @@ class AdamPack:
     ``gate``: a device float; the launches do nothing while gate[0] > 0 (gsx_adam_multi_steps_gated: no update from an
     iteration whose render overflowed its tile lists)."""
 
-    def __init__(self, optimizers, grad_of: dict, decay=None, gate: torch.Tensor | None = None):
+    def __init__(self, optimizers, grad_of: dict, decay=None, gate: torch.Tensor | None = None, pieces=None):
+        """pieces (sharded update, gslam_amd.dist.StepBucket): explicit slices instead of whole parameters - a list of
+        dicts {p, g, m, v: 1-D float32 views of equal length, lr, betas, eps, step: device int64 [1], group: the owning
+        param group}; ``decay[0]`` then names one of the ``p`` views and the mask has one int32 per element of it."""
         self._gate = gate
         self._groups = []
         counters: dict = {}
         classes: dict = {}
+        for pc in (pieces or []):
+            p, g, m, v = pc["p"], pc["g"], pc["m"], pc["v"]
+            if not all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() == p.numel() for t in (p, g, m, v)):
+                raise RuntimeError("AdamPack: a piece needs four contiguous float32 GPU views of equal length")
+            counters.setdefault(id(pc["step"]), pc["step"])
+            if pc.get("group") is not None and all(pc["group"] is not g_ for g_ in self._groups):
+                self._groups.append(pc["group"])
+            key = (tuple(pc["betas"]), float(pc["eps"]), p.device)
+            classes.setdefault(key, []).append((p, g, {"exp_avg": m, "exp_avg_sq": v}, float(pc["lr"]), pc["step"]))
         for opt in optimizers:
             if opt is None:
                 continue

@@ -945,14 +945,15 @@ class MappingStep:
     backward -> isotropic term added into the scale gradient -> [all-reduce] -> six splat Adams + pose Adam + opacity
     decay in one launch (backend.py:554-602, :356-359).
 
-    Every gradient lives in ONE flat fp32 bucket ``[N*15 map | N visible-camera counts | Cw*3 pose dt | Cw*6 pose dR |
-    2 loss values]`` (Cw = cameras of the whole window).  Multi-GPU: the window's cameras are dealt
-    round-robin over ranks, each rank renders its own against its replica of the map, and a single all-reduce(sum) of that
-    bucket carries the map gradients, the visibility counts, the pose gradients (each rank fills the rows of its own
-    cameras, the others are zero) and the loss terms; every rank then applies the identical update to the map AND to
-    all window poses, so replicas never diverge and no pose broadcast is needed.  Per-camera means are scaled by
-    C_local / C_window, the TV sum is not, the isotropic term is applied after the reduction from the window-wide
-    visibility (identical on all ranks).  The step is two graphs around the one collective; with one rank, one graph.
+    The map gradients live in ONE flat fp32 bucket (tensor-major, 15 N floats), the small things every rank needs whole
+    - visible-camera counts [N], pose gradients of all Cw window cameras, loss values, overflow flag - in the "head".
+    Multi-GPU (gslam_amd.dist.StepBucket): the window's cameras are dealt round-robin over ranks, each rank
+    renders its own against its replica of the map; the head is all-reduced, the gradient bucket REDUCE-SCATTERED (rank r
+    gets the window-wide sum of chunk r), each rank runs Adam on its 1 / G of the map (parameters and moments are flat
+    buffers of the same layout) and the updated parameter chunks are ALL-GATHERED; every rank applies the identical update
+    to all window poses from the head, so replicas never diverge and no pose broadcast is needed.  Per-camera means are
+    scaled by C_local / C_window, the TV sum is not, the isotropic term is added once (rank 0) between the two collectives
+    from the window-wide visibility.  The step is two graphs around the collectives; with one rank, one graph.
 
     ``optimizers``: mapping.MapOptimizers built with capturable=True.  Exposure parameters of keyframes are constants
     here (the backend freezes them when it adds a keyframe, gslam_amd/backend.py add_keyframe)."""
@@ -978,12 +979,18 @@ class MappingStep:
         self.dev, self.N = dev, N
         # ---- the bucket (gslam_amd.dist.StepBucket: map gradients | counts | pose rows | loss slots) -------------------
         from .dist import StepBucket
-        self.bucket = StepBucket([p.shape for p in params], Cw, dev, group=self.group)
+        self.bucket = StepBucket([p.shape for p in params], Cw, dev, group=self.group, world=self.world, rank=self.rank)
         self.flat = self.bucket.flat
         self.grad_views = dict(zip(GRAD_PARAMS, self.bucket.views))
         self.counts, self.g_dt, self.g_dR = self.bucket.counts, self.bucket.g_dt, self.bucket.g_dR
         self.out2, self.vis_i32 = self.bucket.out2, self.bucket.vis_i32
         self.out4, self.overflow = self.bucket.out4, self.bucket.overflow
+        # sharded update (world > 1): parameters and Adam moments re-homed into flat buffers of the bucket's layout, BEFORE
+        # the render plan below takes their addresses
+        self.flat_state = None
+        if self.world > 1:
+            from .dist import flatten_map_state
+            self.flat_state = flatten_map_state(splats, optimizers.splat_opt, self.bucket)
         # ---- poses -----------------------------------------------------------------------------------------------------
         self.learnable = [bool(getattr(f.pose, "is_learnable", True) and f.pose.dR.requires_grad) for f in self.window]
         for f in self.window:
@@ -1029,11 +1036,32 @@ class MappingStep:
         vis = self.vis_i32 if self.world > 1 else (self.r.vis_count if self.r is not None else self.vis_i32)
         self._vis = vis
         from .optim import AdamPack
-        decay = (splats.opacities, vis, 1, float(conf.opacity_decay)) if decay_opacity else None
+        pose_grads = {k: v for k, v in grad_of.items() if k not in {id(getattr(splats, n)) for n in GRAD_PARAMS}}
         # gated on the iteration's overflow flag (device side): a truncated render never reaches the map, the poses, the
         # moments or the step counters - on any rank
-        self.adam = AdamPack([optimizers.splat_opt, optimizers.pose_opt], grad_of, decay, gate=self.overflow)
-        pose_grads = {k: v for k, v in grad_of.items() if k not in {id(getattr(splats, n)) for n in GRAD_PARAMS}}
+        if self.world == 1:
+            decay = (splats.opacities, vis, 1, float(conf.opacity_decay)) if decay_opacity else None
+            self.adam = AdamPack([optimizers.splat_opt, optimizers.pose_opt], grad_of, decay, gate=self.overflow)
+        else:
+            # Adam on THIS RANK'S CHUNK of the map: the slices of the six arrays its 1 / G of the flat layout covers, read from
+            # the reduce-scattered gradient chunk; the window poses (a few dozen scalars) are updated by every rank alike
+            opt = optimizers.splat_opt
+            groups = opt.param_groups                      # one group per array, in GRAD_PARAMS order (mapping.SPLAT_LRS)
+            if opt._shared_step is None:
+                opt._shared_step = torch.full((1,), groups[0]["_host_step"], dtype=torch.int64, device=dev)
+            fs, pieces, decay = self.flat_state, [], None
+            for k, a, n_el, c_off in self.bucket.pieces():
+                o = self.bucket.offsets[k] + a
+                pc = dict(p=fs["pflat"][o:o + n_el], g=self.bucket.gchunk[c_off:c_off + n_el], m=fs["mflat"][o:o + n_el],
+                          v=fs["vflat"][o:o + n_el], lr=groups[k]["lr"], betas=groups[k]["betas"], eps=groups[k]["eps"],
+                          step=opt._shared_step, group=groups[k])
+                pieces.append(pc)
+                if decay_opacity and GRAD_PARAMS[k] == 'opacities':
+                    decay = (pc["p"], self.vis_i32[a:a + n_el], 1, float(conf.opacity_decay))
+            self.adam = AdamPack([optimizers.pose_opt], pose_grads, decay, gate=self.overflow, pieces=pieces)
+            for g_ in groups:                              # host bookkeeping follows all six arrays on every rank
+                if all(g_ is not h for h in self.adam._groups):
+                    self.adam._groups.append(g_)
         self.adam_poses = AdamPack([optimizers.pose_opt], pose_grads) if pose_grads else None
         self.stream = torch.cuda.Stream(device=dev)
         self.graph, self.graph2 = HipGraph(), HipGraph()
@@ -1067,7 +1095,7 @@ class MappingStep:
         shard = Cl / float(self.Cw)
         multi = self.world > 1
         w_photo, w_ssim = shard * (1.0 - conf.ssim_weight), shard * conf.ssim_weight
-        w_iso = 0.0 if multi else conf.isotropic_regularization_weight
+        w_iso = 0.0 if multi else conf.isotropic_regularization_weight    # (multi-rank: added between the collectives)
         w_tv = conf.depth_regularization_weight if self.regularize else 0.0
         mode = 0 if conf.active_gs else 1
         check(lib.gsx_pose_zhou_fwd(Cl, self._Rt, self._dR, self._dt, self._flags, _p(r.viewmats), st),
@@ -1111,18 +1139,36 @@ class MappingStep:
         check(lib.gsx_status_flag(_p(r.status), 1, 1, _p(self.overflow), st), "gsx_status_flag")
 
     def reduce(self):
-        """the ONE data-path collective of an iteration (eager, on torch's current stream, between the two graphs)"""
+        """the gradient exchange of an iteration (eager, on torch's current stream, between the two graphs): all-reduce of the
+        head, the isotropic term added ONCE (rank 0) into the local scale gradients from the window-wide visibility, then the
+        reduce-scatter of the gradient bucket (gslam_amd.dist.StepBucket.reduce)"""
+        if self.world == 1:
+            return
+        w = self.conf.isotropic_regularization_weight
+
+        def between():
+            if self.rank == 0 and w != 0.0:
+                check(lib.gsx_isotropic_loss_acc(_p(self.splats.scales.detach()), _p(self.vis_i32), self.N, w, None,
+                                                 _p(self.grad_views['scales']), _p(self.iso_ws), self.iso_ws.numel(),
+                                                 current_stream_ptr(self.dev)), "gsx_isotropic_loss_acc")
+        self.bucket.reduce(None if self.r is None else self.r.vis_count, between)
+
+    def gather_params(self):
+        """all-gather of the parameter chunks the ranks' slices of Adam just updated (eager, after the update graph)"""
         if self.world > 1:
-            self.bucket.reduce(None if self.r is None else self.r.vis_count)
+            self.bucket.gather(self.flat_state["pflat"], self.flat_state["stage"])
+            self.flat_state["sharded"] = True          # from here on a moment is valid on its owner only
+
+    def gather_moments(self):
+        """both Adam moments whole on every rank again: before the map is re-packed (pruning, insertion), which moves rows -
+        and with them the ownership of a moment - between chunks"""
+        if self.world > 1 and self.flat_state["sharded"]:
+            self.bucket.gather(self.flat_state["mflat"], self.flat_state["stage"])
+            self.bucket.gather(self.flat_state["vflat"], self.flat_state["stage"])
+            self.flat_state["sharded"] = False
 
     def enqueue_update(self, st: int):
-        """isotropic term from the window-wide visibility (multi-rank) + Adam + opacity decay"""
-        conf = self.conf
-        w = conf.isotropic_regularization_weight
-        if self.world > 1 and w != 0.0:
-            check(lib.gsx_isotropic_loss_acc(_p(self.splats.scales.detach()), _p(self.vis_i32), self.N, w, None,
-                                             _p(self.grad_views['scales']), _p(self.iso_ws), self.iso_ws.numel(), st),
-                  "gsx_isotropic_loss_acc")
+        """Adam (+ opacity decay) on the whole map (one rank) or on this rank's chunk of it, and on the window poses"""
         self.adam.launch(st)
 
     def _enqueue_all(self, st: int):
@@ -1186,6 +1232,7 @@ class MappingStep:
                 self.graph2.launch(st)
             else:
                 self.enqueue_update(st)
+            self.gather_params()
         self.adam.note_steps(1)
         self.steps += 1
         return self.out2[0], self.out2[1]

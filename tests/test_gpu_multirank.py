@@ -50,6 +50,7 @@ def _worker(rank, world, port, n_kf, q):
     ref.render_backward()
     torch.cuda.synchronize()
     ref_flat = ref.flat.clone()
+    ref_head = ref.bucket.head.clone()
     ref_vis = ref.r.vis_count.clone()
     ref.step(graphed=False)                                  # same start: render_backward moved nothing
     ref.step(graphed=False)
@@ -60,29 +61,35 @@ def _worker(rank, world, port, n_kf, q):
     assert ba2.shard.world_size == world
     plan = ba2.plan(w2)
     assert plan.world == world and plan.mine == [i for i in range(n_kf) if i % world == rank]
-    plan.render_backward()                                   # includes the collective
+    b = plan.bucket
+    assert b.S_pad == ref.bucket.S_pad and b.offsets == ref.bucket.offsets and b.L * world == b.S_pad
+    # the map and both moments live in flat buffers of the bucket's layout now (views keep the tensors' shapes)
+    fs = plan.flat_state
+    assert s2.means.data_ptr() == fs["pflat"].data_ptr() and s2.quats.data_ptr() == fs["pflat"].data_ptr() + 4 * b.offsets[1]
+    plan.render_backward()                                   # includes the collectives: head all-reduce + reduce-scatter
     torch.cuda.synchronize()
     ok = plan.capacity_ok()
-    flat = plan.flat.clone()
-    n15 = s2.means.shape[0] * 15
-    scale = float(ref_flat[:n15].abs().max())
-    d_map = float((flat[:n15] - ref_flat[:n15]).abs().max()) / scale
-    # in the sharded step the isotropic term is added after the reduction; the one-rank bucket holds it already: compare
-    # the scale gradients after adding it here
+    lo, hi = b.chunk_range()
+    # this rank's chunk of the window-wide gradient sums against the same slice of the one-rank bucket (the isotropic term
+    # is in both: inside the loss launch on one rank, added by rank 0 between the collectives on two)
+    scale = float(ref_flat.abs().max())
+    d_map = float((b.gchunk - ref_flat[lo:hi]).abs().max()) / scale
     d_cnt = int((plan.vis_i32 - ref_vis).abs().max())
-    tail = slice(n15 + s2.means.shape[0], None)
-    # tail of the bucket: pose rows | total, photometric | overflow flag, spare
-    d_pose = float((flat[tail][:-4] - ref_flat[tail][:-4]).abs().max()) / (float(ref_flat[tail][:-4].abs().max()) + 1e-9)
-    d_photo = abs(float(flat[-3]) - float(ref_flat[-3])) / abs(float(ref_flat[-3]))
-    ok = ok and float(flat[-2]) == 0.0
-    # two full iterations (graph | all-reduce | graph), then the parameters against the one-rank run
+    N_ = s2.means.shape[0]
+    head, rhead = b.head.clone(), ref_head
+    # tail of the head: pose rows | total, photometric | overflow flag, spare
+    d_pose = float((head[N_:-4] - rhead[N_:-4]).abs().max()) / (float(rhead[N_:-4].abs().max()) + 1e-9)
+    d_photo = abs(float(head[-3]) - float(rhead[-3])) / abs(float(rhead[-3]))
+    ok = ok and float(head[-2]) == 0.0
+    # two full iterations (graph | head all-reduce, reduce-scatter | graph: Adam on this rank's chunk | all-gather), then the
+    # parameters against the one-rank run
     plan.step()
     plan.step()
     torch.cuda.synchronize()
-    ok = ok and plan.capacity_ok() and plan.graph.captured and plan.graph2.captured
+    ok = ok and plan.capacity_ok() and plan.graph.captured and plan.graph2.captured and fs["sharded"]
     d_par = {k: float((getattr(s1, k) - getattr(s2, k)).abs().mean()) for k in
              ("means", "quats", "scales", "opacities", "colors", "log_uncertainties")}
-    d_posepar = max(float((a.pose.dR - b.pose.dR).abs().max()) for a, b in zip(w1, w2))
+    d_posepar = max(float((a.pose.dR - b_.pose.dR).abs().max()) for a, b_ in zip(w1, w2))
     n_learn = sum(plan.learnable)
     moved = max([float(f.pose.dR.abs().max()) for f in w2[1:]], default=1.0)
     # every replica holds the same poses: compare rank 0's and rank 1's after the steps
@@ -90,10 +97,25 @@ def _worker(rank, world, port, n_kf, q):
     both = [torch.zeros_like(mine) for _ in range(world)]
     td.all_gather(both, mine)
     same_poses = bool(torch.equal(both[0], both[1]))
-    means = s2.means.detach().cpu()
+    means = fs["pflat"].detach().cpu()                       # the WHOLE flat parameter buffer: all six arrays
     mboth = [torch.zeros_like(means) for _ in range(world)]
     td.all_gather(mboth, means)
     same_map = bool(torch.equal(mboth[0], mboth[1]))
+    # the moments are sharded: valid on their owner only, until gather_moments() makes them whole (before a re-pack);
+    # then they equal the one-rank run's moments
+    m1 = ba1.optimizers.splat_opt.state[s1.means]["exp_avg"]
+    own_before = float((fs["mflat"][lo:hi] - torch.cat([ba1.optimizers.splat_opt.state[getattr(s1, k)]["exp_avg"].reshape(-1)
+                                                        for k in ("means", "quats", "scales", "opacities", "colors",
+                                                                  "log_uncertainties")])[lo:hi]).abs().max())
+    ba2.sync_moments()
+    m2 = ba2.optimizers.splat_opt.state[s2.means]["exp_avg"]
+    d_mom = float((m1 - m2).abs().max()) / (float(m1.abs().max()) + 1e-12)
+    why = dict(capacity=ok, sharded_cleared=not fs["sharded"], own_before=own_before, m1max=float(m1.abs().max()), d_mom=d_mom)
+    # (bounds: float-atomic noise of the backward, amplified by Adam's normalised first step; a stale or missing moment
+    # would be off by its whole magnitude)
+    ok = ok and not fs["sharded"] and own_before < 2e-2 * float(m1.abs().max()) + 1e-9 and d_mom < 2e-2
+    if not ok:
+        print("rank", rank, "not ok:", why, flush=True)
     q.put((rank, ok, d_map, d_cnt, d_pose, d_photo, d_par, d_posepar, moved, same_poses, same_map))
     td.barrier()
     td.destroy_process_group()

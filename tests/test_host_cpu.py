@@ -159,26 +159,47 @@ def _worker(rank, world, port, q):
     mine = shard.select(window)
     assert mine == [i for i in window if i % world == rank]
     bucket = gdist.StepBucket(shapes, cw, "cpu")
-    assert bucket.flat.numel() == n * 15 + n + cw * 9 + 4 and bucket.world_size == world
-    assert [tuple(v.shape) for v in bucket.views] == shapes
+    offs, numels, s_pad, L = gdist.bucket_layout(shapes, world)
+    assert bucket.flat.numel() == s_pad == world * L and L % 4 == 0 and s_pad >= n * 15
+    assert bucket.head.numel() == n + cw * 9 + 4 and bucket.world_size == world and bucket.gchunk.numel() == L
+    assert [tuple(v.shape) for v in bucket.views] == shapes and all(o % 4 == 0 for o in offs)
+    # the chunks partition the six arrays: every element of every array belongs to exactly one rank's pieces
+    cover = [torch.zeros(k, dtype=torch.int32) for k in numels]
+    for r_ in range(world):
+        for k, a, ln, c_off in bucket.pieces(r_):
+            cover[k][a:a + ln] += 1
+            assert a % 4 == 0 and c_off % 4 == 0 and 0 <= c_off and c_off + ln <= L
+    assert all(bool((c == 1).all()) for c in cover)
     # what a rank's launch plan writes: map gradients of its cameras (per-camera mean rule C_local / C of SURVEY 8e folded
     # into the weights), its cameras' pose rows, its share of the loss; rows of other ranks' cameras stay zero
-    for v in bucket.views:
-        v.fill_(sum(c + 1 for c in mine) / cw)
+    for k, v in enumerate(bucket.views):
+        v.fill_((k + 1) * sum(c + 1 for c in mine) / cw)
     for c in mine:
         bucket.g_dt[c] = float(c + 1)
         bucket.g_dR[c] = float(10 * (c + 1))
     bucket.out2[0] = float(len(mine))
     bucket.out2[1] = 0.5 * len(mine)
+    bucket.overflow[0] = 1.0 if rank == 1 else 0.0             # rank 1's tile lists overflowed: both ranks must see it
     local_vis = torch.full((n,), len(mine), dtype=torch.int32)
-    bucket.reduce(local_vis)
-    expect = sum(c + 1 for c in window) / cw
-    ok = all(torch.allclose(v, torch.full_like(v, expect)) for v in bucket.views)
+    seen = []
+    bucket.reduce(local_vis, between=lambda: seen.append(int(bucket.vis_i32[0])))
+    assert seen == [cw]                                         # the hook runs with the window-wide visibility known
+    # reduce-scatter: this rank holds the window-wide sums of ITS chunk
+    ok = True
+    for k, a, ln, c_off in bucket.pieces():
+        expect = (k + 1) * sum(c + 1 for c in window) / cw
+        ok = ok and torch.allclose(bucket.gchunk[c_off:c_off + ln], torch.full((ln,), expect))
     ok = ok and torch.equal(bucket.vis_i32, torch.full((n,), cw, dtype=torch.int32))
     ok = ok and torch.equal(bucket.g_dt[:, 0], torch.arange(1, cw + 1, dtype=torch.float32))
     ok = ok and torch.equal(bucket.g_dR[:, 5], 10.0 * torch.arange(1, cw + 1, dtype=torch.float32))
-    ok = ok and float(bucket.out2[0]) == cw and float(bucket.out2[1]) == 0.5 * cw
-    # a window shorter than the world: the rank without cameras contributes zeros and still joins the collective
+    ok = ok and float(bucket.out2[0]) == cw and float(bucket.out2[1]) == 0.5 * cw and float(bucket.overflow[0]) == 1.0
+    # all-gather of the chunks each rank "updated" (its own slice of a flat buffer): everybody ends with all of it
+    whole = torch.full((s_pad,), -1.0)
+    lo, hi = bucket.chunk_range()
+    whole[lo:hi] = torch.arange(lo, hi, dtype=torch.float32)
+    bucket.gather(whole, torch.zeros(L))
+    ok = ok and torch.equal(whole, torch.arange(s_pad, dtype=torch.float32))
+    # a window shorter than the world: the rank without cameras contributes zeros and still joins the collectives
     b2 = gdist.StepBucket(shapes, 1, "cpu")
     if rank == 0:
         for v in b2.views:
@@ -190,7 +211,8 @@ def _worker(rank, world, port, q):
             v.fill_(123.0)                           # stale values of an earlier window must not leak into the sum
         b2.tail.zero_()                              # (the plan's first launch of an iteration clears the tail)
         b2.reduce(None)
-    ok = ok and all(torch.equal(v, torch.full_like(v, 2.0)) for v in b2.views)
+    for k, a, ln, c_off in b2.pieces():
+        ok = ok and torch.equal(b2.gchunk[c_off:c_off + ln], torch.full((ln,), 2.0))
     ok = ok and torch.equal(b2.vis_i32, torch.ones(n, dtype=torch.int32)) and float(b2.g_dt[0, 0]) == 3.0
     vis = shard.all_reduce_sum(torch.tensor([len(mine)], dtype=torch.int32))
     mx = shard.all_reduce_max(torch.tensor([rank]))
@@ -214,4 +236,4 @@ def test_keyframe_sharded_ba_collectives_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, ok, vis, mx, t, numel in res:
-        assert ok and vis == 5 and mx == 1 and t == 1.0 and numel == 50 * 16 + 5 * 9 + 4       # map | counts | pose rows | 2 loss values + overflow flag + spare
+        assert ok and vis == 5 and mx == 1 and t == 1.0 and numel == 760          # six arrays of 50 rows, each padded to 16 bytes, in 2 chunks of 380 floats
