@@ -313,12 +313,18 @@ class Backend:
     def sync(self):
         """backend.py:508-519.  The map travels as a view of a double-buffered device slot filled by one launch
         (gslam_amd.transport.MapMailbox) instead of seven clones; the tuple keeps the reference's shape."""
-        if self.splats.means.is_cuda:
+        import queue as _queue
+        if self.splats.means.is_cuda and isinstance(self.frontend_queue, _queue.Queue):
+            # same process (one process per GPU, the frontend on another thread and stream): the double-buffered mailbox
             if getattr(self, "_mailbox", None) is None:
                 from .transport import MapMailbox
                 self._mailbox = MapMailbox()
             payload = self._mailbox.publish(self.splats)
         else:
+            # another process on the other end (the reference's topology, main.py:61-91: torch.multiprocessing queues): the
+            # reference's own payload, a no-grad clone; it crosses the process boundary as device memory (HIP IPC handles,
+            # torch.multiprocessing's reductions order the consumer behind the producer's stream) - no host copy, and no
+            # slot that could be re-used under a lagging consumer
             payload = self.splats.no_grad_clone()
         self.frontend_queue.put((BackendMessage.SYNC, deepcopy(self.keyframes), self.last_kf_depthmap.detach(),
                                  self.last_kf_rgbs.detach(), payload, deepcopy(self.pose_graph)))
