@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads of the 1-GPU line")
     ap.add_argument("--ba-only", action="store_true", help="1 GPU: run the G > 1 workload (configs[3]) on one GPU")
     ap.add_argument("--full-cycle-only", action="store_true", help="1 GPU: only the full-mapping-cycle variant of the headline")
+    ap.add_argument("--cfg5-only", action="store_true", help="1 GPU: only BASELINE.json configs[4] (5M SH-3 1080p render)")
     ap.add_argument("--diag", default="", help="DIAGNOSTIC runs of the headline with work left out (comma list of "
                     "'no-ba', 'no-out'): the line is marked invalid, it only tells where the frame time goes")
     return ap.parse_args()
@@ -467,6 +468,68 @@ def run_headline(args, dev):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: 5 M Gaussians, SH degree 3, 1920x1080, one camera (HBM-roofline stress)
+# ------------------------------------------------------------------------------------------------------------------------
+def run_cfg5(dev, N=5_000_000, W=1920, H=1080, reps=6):
+    """render forward + backward through the gsplat-shaped entry point (gslam_amd.rendering.rasterization, pipeline.py:106-116:
+    post-activation inputs, sh_degree = 3), sync-free (IsectCapacity), eager launches; median of ``reps`` after two warm-up
+    steps, HIP events on the launch stream.  Algorithmic bytes: SURVEY.md 8(d) B_fwd + B_bwd at CH = 3 plus the SH terms."""
+    from gslam_amd.rasterization import IsectCapacity
+    from gslam_amd.rendering import rasterization as gs_rasterization
+    from gslam_amd.synthetic import make_cameras, make_scene
+    sc = make_scene(N, 0, sh_degree=3)
+    viewmats, Ks = make_cameras(1, W, H)
+    viewmats, Ks = viewmats.to(dev), Ks.to(dev)
+    bg = torch.zeros(1, 3, device=dev)
+    cap = IsectCapacity(dev)
+    p = {k: v.to(dev).requires_grad_(v.is_floating_point()) for k, v in sc.items()}
+    del sc
+    fwd_only = {"on": False}
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        with torch.set_grad_enabled(not fwd_only["on"]):
+            render, alphas, info = gs_rasterization(p["means"], p["quats"], torch.exp(p["scales"]),
+                                                    torch.sigmoid(p["opacities"]), p["sh_coeffs"], viewmats, Ks, W, H,
+                                                    sh_degree=3, packed=False, backgrounds=bg, capacity=cap)
+            if not fwd_only["on"]:
+                (render.sum() + alphas.sum()).backward()
+
+    def timed():
+        ts = []
+        for i in range(reps + 2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step()
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    step()
+    assert cap.validate()
+    ms = timed()
+    assert cap.validate()
+    M = cap.last_M
+    fwd_only["on"] = True
+    ms_fwd = timed()
+    C, P, CH = 1, W * H, 3
+    b_fwd = C * N * 92 + M * (72 + 4 * CH) + P * (4 * CH + 8) + N * 192 + C * N * 12
+    b_bwd = C * N * (116 + 4 * CH) + N * 40 + M * (28 + 4 * CH) + P * (4 * CH + 12) + 2 * N * 192 + C * N * 12
+    del p
+    torch.cuda.empty_cache()
+    return {"workload": "BASELINE.json configs[4]: 5M Gaussians, SH degree 3, 1920x1080, one camera, gsplat-shaped entry point",
+            "gaussians": N, "n_isects": int(M), "fwd_ms": round(ms_fwd, 3), "fwd_bwd_ms": round(ms, 3),
+            "algorithmic_bytes_fwd": int(b_fwd), "algorithmic_bytes_fwd_bwd": int(b_fwd + b_bwd),
+            "fwd_gbs": round(b_fwd / ms_fwd * 1e-6, 1), "fwd_bwd_gbs": round((b_fwd + b_bwd) / ms * 1e-6, 1),
+            "fwd_bwd_frac_of_hbm_peak": round((b_fwd + b_bwd) / ms * 1e-6 / HBM_PEAK_GBS, 4),
+            "launch": "eager (autograd-shaped operators, sync-free capacity buffers)"}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
 # 1 GPU, the reference's WHOLE mapping cycle beside the tracker (second value of the headline workload)
 # ------------------------------------------------------------------------------------------------------------------------
 def run_full_cycle(dev, N, W, H, steps=60, warmup=10):
@@ -800,6 +863,9 @@ def main():
     import torch.distributed as td
     gdist.init_from_env(backend=os.environ.get("GSX_DIST_BACKEND"), device=dev)
 
+    if world == 1 and args.cfg5_only:
+        print(json.dumps(run_cfg5(dev)), flush=True)
+        return
     if world == 1 and args.full_cycle_only:
         print(json.dumps(run_full_cycle(dev, args.gaussians or 500_000, args.width, args.height,
                                         steps=args.steps or 60, warmup=10 if args.warmup is None else args.warmup)), flush=True)
@@ -817,6 +883,11 @@ def main():
             extra["ba_100k_window1"] = {"workload": "BASELINE.json configs[1]: 100k Gaussians, 1 keyframe, full BA step",
                                         "keyframes_per_s": round(r["keyframes_per_s"], 2),
                                         "ms_per_ba_iteration": round(r["ms_per_iter"], 4), "n_isects": r["n_isects_local"]}
+            torch.cuda.empty_cache()
+            try:
+                extra["render_5m_sh3_1080p"] = run_cfg5(dev)
+            except Exception as e:
+                extra["render_5m_sh3_1080p"] = {"fwd_bwd_ms": None, "error": repr(e)}
             torch.cuda.empty_cache()
             try:
                 extra["full_mapping_cycle"] = run_full_cycle(dev, N, W, H)

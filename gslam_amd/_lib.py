@@ -40,6 +40,8 @@ PROTOTYPES = {
     "gsx_raster_bwd": (i32, [vp, i32, vp, vp, vp, i64, i32, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "gsx_sh_fwd": (i32, [i32, vp, vp, vp, i64, i64, i32, vp, vp]),
     "gsx_sh_bwd": (i32, [i32, vp, vp, vp, vp, i64, i64, i32, vp, vp, vp]),
+    "gsx_sh_fwd_means": (i32, [i32, vp, vp, vp, vp, i64, i64, i32, vp, vp]),
+    "gsx_sh_bwd_means": (i32, [i32, vp, vp, vp, vp, vp, i64, i64, i32, vp, vp, vp, vp]),
     "gsx_ssim_workspace_bytes": (i64, [i64, i32, i32, i32]),
     "gsx_ssim_fwd": (i32, [vp, vp, i64, i32, i32, i32, C.POINTER(i64), C.POINTER(i64), i32, vp, vp, vp, vp, vp, i64, vp]),
     "gsx_ssim_bwd": (i32, [vp, vp, i64, i32, i32, i32, C.POINTER(i64), C.POINTER(i64), i32, vp, vp, vp, vp, f32, vp, vp]),

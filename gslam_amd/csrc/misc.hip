@@ -102,11 +102,14 @@ __device__ __forceinline__ void sh_stage_in(const float *__restrict__ coeffs, in
     }
 }
 
+// campos != nullptr: `dirs` holds the MEANS [N,3] and the view direction of (camera c, Gaussian g) is means[g] - campos[c],
+// formed in registers - no [C,N,3] direction array is written and read back (120 MB at 5 M Gaussians)
 template <int DEG>
 __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(const float *__restrict__ dirs,
                                                           const float *__restrict__ coeffs,
                                                           const int32_t *__restrict__ radii, int64_t N, int C, int Kc,
-                                                          float *__restrict__ colors) {
+                                                          float *__restrict__ colors,
+                                                          const float *__restrict__ campos = nullptr) {
     constexpr int NB = (DEG + 1) * (DEG + 1), NBC = NB * 3, PITCH = NBC | 1;
     __shared__ float s_rows[SH_BLOCK * PITCH];
     const int64_t g0 = (int64_t)blockIdx.x * SH_BLOCK;
@@ -118,11 +121,15 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(const float *__restric
     float co[NBC];
 #pragma unroll
     for (int k = 0; k < NBC; ++k) co[k] = s_rows[threadIdx.x * PITCH + k];
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    if (campos) { m0 = dirs[3 * g]; m1 = dirs[3 * g + 1]; m2 = dirs[3 * g + 2]; }
     for (int c = 0; c < C; ++c) {
         const int64_t idx = (int64_t)c * N + g;
         float o0 = 0.f, o1 = 0.f, o2 = 0.f;
         if (!radii || radii[idx] > 0) {
-            float x = dirs[3 * idx], y = dirs[3 * idx + 1], z = dirs[3 * idx + 2];
+            float x, y, z;
+            if (campos) { x = m0 - campos[3 * c]; y = m1 - campos[3 * c + 1]; z = m2 - campos[3 * c + 2]; }
+            else { x = dirs[3 * idx]; y = dirs[3 * idx + 1]; z = dirs[3 * idx + 2]; }
             const float n = sqrtf(x * x + y * y + z * z);
             const float inv = n > 0.f ? 1.0f / n : 0.f;
             x *= inv; y *= inv; z *= inv;
@@ -141,9 +148,13 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(const float *__restric
                                                           const float *__restrict__ coeffs,
                                                           const int32_t *__restrict__ radii,
                                                           const float *__restrict__ v_colors, int64_t N, int C, int Kc,
-                                                          float *__restrict__ v_coeffs, float *__restrict__ v_dirs) {
+                                                          float *__restrict__ v_coeffs, float *__restrict__ v_dirs,
+                                                          const float *__restrict__ campos = nullptr,
+                                                          float *__restrict__ v_means = nullptr,
+                                                          float *__restrict__ v_campos = nullptr) {
     constexpr int NB = (DEG + 1) * (DEG + 1), NBC = NB * 3, PITCH = NBC | 1;
     __shared__ float s_rows[SH_BLOCK * PITCH];
+    __shared__ float s_cam[SH_BLOCK / 64][3];
     const int64_t g0 = (int64_t)blockIdx.x * SH_BLOCK;
     const int rows = (int)min((int64_t)SH_BLOCK, N - g0);
     sh_stage_in<DEG>(coeffs, g0, rows, Kc, s_rows);
@@ -152,11 +163,15 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(const float *__restric
     float co[NBC], vco[NBC];
 #pragma unroll
     for (int k = 0; k < NBC; ++k) { co[k] = s_rows[threadIdx.x * PITCH + k]; vco[k] = 0.f; }
-    for (int c = 0; c < C && g < N; ++c) {
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, vm0 = 0.f, vm1 = 0.f, vm2 = 0.f;
+    if (campos && g < N) { m0 = dirs[3 * g]; m1 = dirs[3 * g + 1]; m2 = dirs[3 * g + 2]; }
+    for (int c = 0; c < C; ++c) {
         const int64_t idx = (int64_t)c * N + g;
         float vdx = 0.f, vdy = 0.f, vdz = 0.f;
-        if (!radii || radii[idx] > 0) {
-            const float dx_ = dirs[3 * idx], dy_ = dirs[3 * idx + 1], dz_ = dirs[3 * idx + 2];
+        if (g < N && (!radii || radii[idx] > 0)) {
+            float dx_, dy_, dz_;
+            if (campos) { dx_ = m0 - campos[3 * c]; dy_ = m1 - campos[3 * c + 1]; dz_ = m2 - campos[3 * c + 2]; }
+            else { dx_ = dirs[3 * idx]; dy_ = dirs[3 * idx + 1]; dz_ = dirs[3 * idx + 2]; }
             const float n = sqrtf(dx_ * dx_ + dy_ * dy_ + dz_ * dz_);
             const float inv = n > 0.f ? 1.0f / n : 0.f;
             const float x = dx_ * inv, y = dy_ * inv, z = dz_ * inv;
@@ -180,8 +195,25 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(const float *__restric
             const float dotp = vx * x + vy * y + vz * z;
             vdx = (vx - dotp * x) * inv; vdy = (vy - dotp * y) * inv; vdz = (vz - dotp * z) * inv;
         }
-        if (v_dirs) { v_dirs[3 * idx] = vdx; v_dirs[3 * idx + 1] = vdy; v_dirs[3 * idx + 2] = vdz; }
+        if (v_dirs && g < N) { v_dirs[3 * idx] = vdx; v_dirs[3 * idx + 1] = vdy; v_dirs[3 * idx + 2] = vdz; }
+        if (campos) {
+            // d dir / d mean = I, d dir / d campos = -I: the mean's gradient is the sum over cameras (registers), the camera
+            // centre's the negative sum over Gaussians (wave sum, workgroup sum, one atomic per component and workgroup)
+            vm0 += vdx; vm1 += vdy; vm2 += vdz;
+            if (v_campos) {
+                const float t0 = gsx_wave_sum(vdx), t1 = gsx_wave_sum(vdy), t2 = gsx_wave_sum(vdz);
+                __syncthreads();
+                if ((threadIdx.x & 63) == 0) { s_cam[threadIdx.x >> 6][0] = t0; s_cam[threadIdx.x >> 6][1] = t1; s_cam[threadIdx.x >> 6][2] = t2; }
+                __syncthreads();
+                if (threadIdx.x < 3) {
+                    float tot = 0.f;
+                    for (int w = 0; w < SH_BLOCK / 64; ++w) tot += s_cam[w][threadIdx.x];
+                    if (tot != 0.f) atomicAdd(&v_campos[3 * c + threadIdx.x], -tot);
+                }
+            }
+        }
     }
+    if (campos && v_means && g < N) { v_means[3 * g] = vm0; v_means[3 * g + 1] = vm1; v_means[3 * g + 2] = vm2; }
     __syncthreads();                                         // every lane has taken its row: reuse the block for output
 #pragma unroll
     for (int k = 0; k < NBC; ++k) s_rows[threadIdx.x * PITCH + k] = vco[k];
@@ -409,6 +441,45 @@ extern "C" int gsx_sh_bwd(int degree, const float *dirs, const float *coeffs, co
     default: GSX_SH_BWD(3); break;
     }
 #undef GSX_SH_BWD
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_sh_fwd_means(int degree, const float *means, const float *campos, const float *coeffs,
+                                const int32_t *radii, int64_t N, int64_t C, int Kc, float *colors, void *stream) {
+    GSX_CHECK_ARG(degree >= 0 && degree <= 3 && means && campos && coeffs && colors && N >= 0 && C >= 1);
+    GSX_CHECK_ARG((degree + 1) * (degree + 1) <= Kc);
+    if (N == 0) return GSX_OK;
+    const dim3 grid((unsigned)((N + SH_BLOCK - 1) / SH_BLOCK)), block(SH_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    switch (degree) {
+    case 0: hipLaunchKernelGGL(sh_fwd_kernel<0>, grid, block, 0, st, means, coeffs, radii, N, (int)C, Kc, colors, campos); break;
+    case 1: hipLaunchKernelGGL(sh_fwd_kernel<1>, grid, block, 0, st, means, coeffs, radii, N, (int)C, Kc, colors, campos); break;
+    case 2: hipLaunchKernelGGL(sh_fwd_kernel<2>, grid, block, 0, st, means, coeffs, radii, N, (int)C, Kc, colors, campos); break;
+    default: hipLaunchKernelGGL(sh_fwd_kernel<3>, grid, block, 0, st, means, coeffs, radii, N, (int)C, Kc, colors, campos); break;
+    }
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_sh_bwd_means(int degree, const float *means, const float *campos, const float *coeffs,
+                                const int32_t *radii, const float *v_colors, int64_t N, int64_t C, int Kc,
+                                float *v_coeffs, float *v_means, float *v_campos, void *stream) {
+    GSX_CHECK_ARG(degree >= 0 && degree <= 3 && means && campos && coeffs && v_colors && v_coeffs && N >= 0 && C >= 1);
+    GSX_CHECK_ARG((degree + 1) * (degree + 1) <= Kc);
+    if (N == 0) return GSX_OK;
+    const dim3 grid((unsigned)((N + SH_BLOCK - 1) / SH_BLOCK)), block(SH_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+#define GSX_SH_BWDM(D)                                                                                                 \
+    hipLaunchKernelGGL(sh_bwd_kernel<D>, grid, block, 0, st, means, coeffs, radii, v_colors, N, (int)C, Kc, v_coeffs,  \
+                       (float *)nullptr, campos, v_means, v_campos)
+    switch (degree) {
+    case 0: GSX_SH_BWDM(0); break;
+    case 1: GSX_SH_BWDM(1); break;
+    case 2: GSX_SH_BWDM(2); break;
+    default: GSX_SH_BWDM(3); break;
+    }
+#undef GSX_SH_BWDM
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }

@@ -468,6 +468,44 @@ class _SphericalHarmonics(torch.autograd.Function):
         return None, v_dirs, v_coeffs, None
 
 
+class _SphericalHarmonicsFromMeans(torch.autograd.Function):
+    """colours of (camera, Gaussian) pairs from the means and the camera centres: the view directions never exist as an array"""
+
+    @staticmethod
+    def forward(ctx, degree, means, campos, coeffs, radii):
+        means, campos, coeffs = _f32c(means, "means"), _f32c(campos, "campos"), _f32c(coeffs, "coeffs")
+        N, Cn, Kc = means.shape[0], campos.shape[0], coeffs.shape[1]
+        radii = None if radii is None else radii.contiguous()
+        colors = torch.empty(Cn, N, 3, dtype=torch.float32, device=means.device)
+        check(lib.gsx_sh_fwd_means(degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii), N, Cn, Kc, ptr(colors),
+                                   stream_ptr(means.device)), "gsx_sh_fwd_means")
+        ctx.save_for_backward(means, campos, coeffs, radii)
+        ctx.degree = degree
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        if v_colors is None:
+            return None, None, None, None, None
+        means, campos, coeffs, radii = ctx.saved_tensors
+        N, Cn, Kc = means.shape[0], campos.shape[0], coeffs.shape[1]
+        v_coeffs = torch.empty_like(coeffs)
+        v_means = torch.empty_like(means) if ctx.needs_input_grad[1] else None
+        v_campos = torch.zeros_like(campos) if ctx.needs_input_grad[2] else None
+        check(lib.gsx_sh_bwd_means(ctx.degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii), ptr(v_colors.contiguous()),
+                                   N, Cn, Kc, ptr(v_coeffs), ptr(v_means), ptr(v_campos), stream_ptr(means.device)),
+              "gsx_sh_bwd_means")
+        return None, v_means, v_campos, v_coeffs, None
+
+
+def spherical_harmonics_from_means(degrees_to_use: int, means: Tensor, campos: Tensor, coeffs: Tensor,
+                                   masks: Optional[Tensor] = None) -> Tensor:
+    """spherical_harmonics(degree, means[None] - campos[:, None], coeffs, masks) without the [C,N,3] direction array:
+    means [N,3], campos [C,3] (camera centres), coeffs [N,K,3] -> [C,N,3]; differentiable in all three"""
+    radii = None if masks is None else masks.to(torch.int32)
+    return _SphericalHarmonicsFromMeans.apply(int(degrees_to_use), means, campos, coeffs, radii)
+
+
 def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor] = None) -> Tensor:
     """gsplat spherical_harmonics: dirs [C,N,3] (un-normalised), coeffs [N,K,3] -> [C,N,3] = max(0, SH + 0.5).
     ``masks`` may be a bool [C,N] or the int32 radii (evaluated where > 0)."""

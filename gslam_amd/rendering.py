@@ -52,11 +52,12 @@ def rasterization(
         c2 = torch.cross(A[:, 0], A[:, 1], dim=-1)
         det = (A[:, 0] * c0).sum(-1, keepdim=True)
         campos = -(c0 * tv[:, 0:1] + c1 * tv[:, 1:2] + c2 * tv[:, 2:3]) / det         # [C,3]
-        dirs = means[None, :, :] - campos[:, None, :]                     # [C,N,3]
         coeffs = colors if colors.dim() == 3 else None
         if coeffs is None:
             raise ValueError("sh_degree given: colors must be SH coefficients [N,K,3]")
-        cols = ops.spherical_harmonics(sh_degree, dirs, coeffs, masks=radii)
+        # view directions means - campos are formed inside the SH kernels (no [C,N,3] array: 120 MB written and read back
+        # at 5 M Gaussians); gradients reach the means directly and the view matrices through campos
+        cols = ops.spherical_harmonics_from_means(sh_degree, means, campos, coeffs, masks=radii)
 
     if render_mode in ("RGB+D", "RGB+ED"):
         cols = torch.cat((cols, depths[..., None]), dim=-1)

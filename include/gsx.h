@@ -259,6 +259,15 @@ int gsx_sh_fwd(int degree, const float *dirs /*[C,N,3]*/, const float *coeffs /*
 int gsx_sh_bwd(int degree, const float *dirs, const float *coeffs, const int32_t *radii, const float *v_colors,
                int64_t N, int64_t C, int Kc, float *v_coeffs /*[N,Kc,3] overwritten*/, float *v_dirs /*[C,N,3] nullable*/,
                void *stream);
+/* The same with the view directions formed in registers: dir(c, g) = means[g] - campos[c] (campos [C,3] = inverse view
+ * matrices' translation column), so no [C,N,3] direction array is written and read back.  Backward: v_coeffs as above,
+ * v_means [N,3] = sum over cameras of d loss / d dir (written, nullable), v_campos [C,3] -= sum over Gaussians (ADDED:
+ * zero it first; nullable). */
+int gsx_sh_fwd_means(int degree, const float *means, const float *campos, const float *coeffs, const int32_t *radii,
+                     int64_t N, int64_t C, int Kc, float *colors, void *stream);
+int gsx_sh_bwd_means(int degree, const float *means, const float *campos, const float *coeffs, const int32_t *radii,
+                     const float *v_colors, int64_t N, int64_t C, int Kc, float *v_coeffs, float *v_means,
+                     float *v_campos, void *stream);
 
 /* ---- K11/K12: fused_ssim (gslam/backend.py:303-307).  strides: HOST int64[4] in floats (sB,sC,sH,sW) ------------------------
  * fwd: out_sum[0] = sum of the SSIM map over the crop (crop = 5 for 'valid', 0 for 'same'); the mean is

@@ -721,3 +721,31 @@ def test_gslam_rasterization_packed_default(dev, oracle32):
     for k in names:
         a, b = pp[k].grad, pd[k].grad
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9, k
+
+
+def test_sh_from_means_equals_direction_form(dev, oracle32):
+    """the SH kernels that form the view directions in registers (means - camera centre) against the direction-array form
+    and the oracle: colours bit-exact, gradients of coefficients / means / camera centres equal"""
+    from gslam_amd import ops
+    g = torch.Generator().manual_seed(3)
+    c, n = 3, 4000
+    means = torch.randn(n, 3, generator=g) * 2.0
+    campos = torch.randn(c, 3, generator=g)
+    coeffs = torch.randn(n, 16, 3, generator=g) * 0.3
+    radii = (torch.rand(c, n, generator=g) > 0.25).to(torch.int32)
+    w = torch.randn(c, n, 3, generator=g)
+    for deg in (0, 2, 3):
+        ma, ca, coa = (t.clone().to(dev).requires_grad_(True) for t in (means, campos, coeffs))
+        col_a = ops.spherical_harmonics_from_means(deg, ma, ca, coa, masks=radii.to(dev))
+        (col_a * w.to(dev)).sum().backward()
+        mb, cb, cob = (t.clone().to(dev).requires_grad_(True) for t in (means, campos, coeffs))
+        col_b = ops.spherical_harmonics(deg, mb[None] - cb[:, None], cob, masks=radii.to(dev))
+        (col_b * w.to(dev)).sum().backward()
+        assert torch.equal(col_a, col_b)
+        ocol = oracle32.sh_fwd(deg, _np(means[None] - campos[:, None]), _np(coeffs), _np(radii))
+        assert np.abs(_np(col_a) - ocol).max() < 2e-6
+        assert float((coa.grad - cob.grad).abs().max()) <= 1e-6 * float(cob.grad.abs().max()) + 1e-9
+        assert float((ma.grad - mb.grad).abs().max()) <= 1e-5 * float(mb.grad.abs().max()) + 1e-9
+        if deg > 0:
+            assert float(cb.grad.abs().max()) > 0
+        assert float((ca.grad - cb.grad).abs().max()) <= 2e-4 * float(cb.grad.abs().max()) + 1e-7
