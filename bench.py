@@ -237,17 +237,18 @@ def render_bytes(N, C, M, P, CH, T):
 
 
 def traffic_for(kernel_hint, N):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic_r02.json), or None"""
-    for name in ("traffic_r02.json",):
+    """(HBM bytes per launch, limiter record) of the dominant kernel from the committed counter passes
+    (profiles/traffic_r03.json, written by tools/distill_profiles.py from separate --pmc runs), or (None, None)"""
+    for name in ("traffic_r03.json", "traffic_r02.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
                 tj = json.load(open(path))
                 if tj.get("workload_gaussians") == N and tj.get("stage") == kernel_hint:
-                    return tj.get("hbm_bytes_per_launch")
+                    return tj.get("hbm_bytes_per_launch"), tj.get("limiter")
             except Exception:
                 pass
-    return None
+    return None, None
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -452,8 +453,13 @@ def run_headline(args, dev):
         M1 = int(sum(Ms) / len(Ms))
         algo = algorithmic_bytes(N, 1, M1, P, 4, T)
         achieved = algo[dom] / (dom_us * 1e-6) / 1e9
+        traffic, limiter = traffic_for(dom, N)
         line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for(dom, N),
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                            # counted HBM traffic / measured time / peak: what the memory system actually carries - the
+                            # contract's "bound: hbm" is the path's label, `limiter` says what bounds THIS kernel
+                            "counter_frac": None if not traffic else round(traffic / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                            "limiter": limiter,
                             "algorithmic_bytes": int(algo[dom]), "avg_launch_us": round(dom_us, 2), "n_isects": M1,
                             "timing": "HIP events on the launch stream around frames of 36 graph replays, with and without "
                                       "the launch duplicated in the captured closure; difference per closure",
