@@ -35,7 +35,18 @@ __global__ __launch_bounds__(LB) void map_loss_kernel(LossArgs A) {
     __shared__ float s_part[LB / GSX_WAVE][NPART];
     const int c = blockIdx.y;
     const int HW = A.H * A.W;
-    const int i = blockIdx.x * LB + threadIdx.x;
+    // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs, each with its own L2; the workgroups of one
+    // XCD take one contiguous eighth of the image's 256-pixel blocks, so that the rows above and below a block (the
+    // edge-aware TV reads all four neighbours) are in THIS XCD's L2 instead of being fetched again through the fabric:
+    // FETCH_SIZE showed 2.0x the algorithmic bytes with the natural order (tools/ubench/fetch_calib.hip `read_loss_shape`
+    // reproduces it: the x2 correction of the counter holds, the re-fetch is real).  A speed assumption only.
+    int lb;
+    {
+        const int total = (int)gridDim.x, b = (int)blockIdx.x, xcd = b % 8, k = b / 8;
+        const int qn = total / 8, rn = total % 8;
+        lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + k;
+    }
+    const int i = lb * LB + threadIdx.x;
     float part[NPART] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < HW) {
         const int y = i / A.W, x = i - y * A.W;

@@ -7,6 +7,10 @@
 //   read_nhwc3of5    3 adjacent dwords out of every 20-byte pixel  (SSIM / loss reading the colours of a CH = 5 render)
 //   read_b96_aos    12 B per lane from 12-byte rows                (means / scales in the projection)
 //   gather_b128x3   48-byte records gathered by a random index      (rasteriser record gather)
+//   read_b160_aos   20 B per lane from 20-byte rows                (the CH = 5 render / its gradient in the loss kernel)
+//   read_loss_shape the mapping loss kernel's reads of a 640-wide image: the pixel's 20-byte row, its right and lower
+//                   neighbours' rows (edge-aware TV), a 4-byte alpha, a 12-byte gt row and 3 planar ssim-gradient values;
+//                   bytes it touches = 20 + 4 + 12 + 12 per pixel (the neighbours are re-reads of other lanes' rows)
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/fetch_calib tools/ubench/fetch_calib.hip
 // run  : rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -o c -- tools/ubench/fetch_calib
 #include <hip/hip_runtime.h>
@@ -51,6 +55,25 @@ __global__ void gather_b128x3(const float4 *p, int64_t nrec, float *out) {
     if (acc == 123.456f) out[0] = acc;
 }
 
+__global__ void read_b160_aos(const float *p, int64_t nrow, float *out) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += (int64_t)gridDim.x * blockDim.x)
+        acc += p[5 * i] + p[5 * i + 1] + p[5 * i + 2] + p[5 * i + 3] + p[5 * i + 4];
+    if (acc == 123.456f) out[0] = acc;
+}
+// one block of 256 consecutive pixels per trip, like map_loss_kernel; W = 640
+__global__ void read_loss_shape(const float *render, const float *alphas, const float *gt, const float *sg, int64_t npix,
+                                float *out) {
+    const int W = 640;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix - W - 1; i += (int64_t)gridDim.x * blockDim.x) {
+        const float *r = render + 5 * i, *rx = render + 5 * (i + 1), *ry = render + 5 * (i + W);
+        acc += r[0] + r[1] + r[2] + r[3] + r[4] + rx[0] + rx[1] + rx[2] + rx[3] + ry[0] + ry[1] + ry[2] + ry[3];
+        acc += alphas[i] + gt[3 * i] + gt[3 * i + 1] + gt[3 * i + 2] + sg[i] + sg[npix + i] + sg[2 * npix + i];
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
 int main() {
     const int64_t bytes = 512ll << 20;
     float *buf, *out;
@@ -65,6 +88,10 @@ int main() {
         hipLaunchKernelGGL(read_nhwc3of5, grid, block, 0, 0, buf, n / 5, out);
         hipLaunchKernelGGL(read_b96_aos, grid, block, 0, 0, buf, n / 3, out);
         hipLaunchKernelGGL(gather_b128x3, grid, block, 0, 0, (const float4 *)buf, n / 12, out);
+        hipLaunchKernelGGL(read_b160_aos, grid, block, 0, 0, buf, n / 5, out);
+        // the loss shape over one 512 MiB buffer cut into render (20 B/px) | alphas (4) | gt (12) | ssim gradient (12) = 48 B/px
+        const int64_t npix = bytes / 48;
+        hipLaunchKernelGGL(read_loss_shape, grid, block, 0, 0, buf, buf + 5 * npix, buf + 6 * npix, buf + 9 * npix, npix, out);
     }
     CHECK(hipDeviceSynchronize());
     printf("buffer_bytes %lld (every kernel touches all of its lines once)\n", (long long)bytes);
