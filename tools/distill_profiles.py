@@ -86,8 +86,13 @@ if os.path.isdir(g(f"pmc_sq1_{tag}")):
         if m.get("SQ_WAVE_CYCLES"):
             m["wait_any_frac_of_wave_cycles"] = m.get("SQ_WAIT_ANY", 0.0) / m["SQ_WAVE_CYCLES"]
             m["wait_inst_frac_of_wave_cycles"] = m.get("SQ_WAIT_INST_ANY", 0.0) / m["SQ_WAVE_CYCLES"]
-        if m.get("SQ_BUSY_CYCLES"):
-            m["valu_active_frac_of_busy_cycles"] = m.get("SQ_ACTIVE_INST_VALU", 0.0) / (4.0 * m["SQ_BUSY_CYCLES"])
+        if m.get("SQ_INSTS_VALU"):
+            # SQ_ACTIVE_INST_VALU counts quad-cycles (4 clocks) a SIMD spends issuing VALU work: ~1.05 per wave64 instruction
+            m["valu_quad_cycles_per_inst"] = m.get("SQ_ACTIVE_INST_VALU", 0.0) / m["SQ_INSTS_VALU"]
+        if m.get("SQ_WAVE_CYCLES") and waves > 0:
+            m["wave_lifetime_quad_cycles"] = m["SQ_WAVE_CYCLES"] / waves
+            # share of a wavefront's lifetime in which it is issuing VALU work: the rest is waiting or other pipes
+            m["valu_issue_frac_of_wave_lifetime"] = m.get("SQ_ACTIVE_INST_VALU", 0.0) / m["SQ_WAVE_CYCLES"]
         sq[k.replace("(anonymous namespace)::", "")[:100]] = {c: round(v, 4) for c, v in sorted(m.items())}
     with open(out(f"{tag}_sq_counters.json"), "w") as f:
         json.dump({"method": "rocprofv3 --pmc, two passes of 8 SQ counters over tools/prof_closure.py --frames 1 --eager (the 36 "
@@ -116,7 +121,8 @@ if hit:
             tj["limiter"] = {
                 "kind": "VALU issue / dependent-issue latency (not HBM: see the counter traffic)",
                 "valu_insts_per_wave": v.get("valu_insts_per_wave"),
-                "valu_active_frac_of_busy_cycles": v.get("valu_active_frac_of_busy_cycles"),
+                "valu_quad_cycles_per_inst": v.get("valu_quad_cycles_per_inst"),
+                "valu_issue_frac_of_wave_lifetime": v.get("valu_issue_frac_of_wave_lifetime"),
                 "wait_any_frac_of_wave_cycles": v.get("wait_any_frac_of_wave_cycles"),
                 "lds_insts_per_wave": v.get("lds_insts_per_wave"), "source": f"profiles/{tag}_sq_counters.json"}
     with open(out(f"traffic_{rnd}.json"), "w") as f:
