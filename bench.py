@@ -595,8 +595,9 @@ def run_full_cycle(dev, N, W, H, steps=60, warmup=10):
             state["recaptures"] += 1
 
     take_sync(to_frontend.get())
-    counters = {"cycles": 0, "ba_iters": 0, "kf_tests": 0, "pruned": 0, "errors": []}
-    be_stream = torch.cuda.Stream()
+    counters = {"cycles": 0, "ba_iters": 0, "kf_tests": 0, "pruned": 0, "errors": [], "t_kf": 0.0, "t_cycle": 0.0, "t_fe": 0.0,
+                "t_parts": [0.0, 0.0, 0.0, 0.0]}
+    be_stream = torch.cuda.Stream(priority=int(os.environ.get("GSX_BE_PRIO", "0")))
 
     def backend_thread():
         try:
@@ -606,19 +607,22 @@ def run_full_cycle(dev, N, W, H, steps=60, warmup=10):
                     tok = to_backend.get()
                     if tok is None:
                         return
+                    tb = time.perf_counter()
                     with capture_lock:
                         if tok[0] == "frame":
                             torch.cuda.current_stream().wait_event(tok[2])      # the frontend's copy of the frame is complete
                             last = be.keyframes[sorted(be.keyframes)[-1]]
                             be.to_insert_keyframe(last, tok[1])
                             counters["kf_tests"] += 1
+                            counters["t_kf"] += time.perf_counter() - tb
                         else:
                             n0, s0 = int(be.splats.means.shape[0]), be.total_step
                             be.pause_map_optim = False
-                            be.optimize_map()
-                            be.run_pruning()
-                            be.optimize_poses_lbfgs()
-                            be.sync()
+                            for k, part in enumerate((be.optimize_map, be.run_pruning, be.optimize_poses_lbfgs, be.sync)):
+                                tp = time.perf_counter()
+                                part()
+                                counters["t_parts"][k] += time.perf_counter() - tp
+                            counters["t_cycle"] += time.perf_counter() - tb
                             counters["cycles"] += 1
                             counters["ba_iters"] += be.total_step - s0
                             counters["pruned"] += n0 - int(be.splats.means.shape[0])
@@ -640,6 +644,7 @@ def run_full_cycle(dev, N, W, H, steps=60, warmup=10):
             while not to_frontend.empty():
                 take_sync(to_frontend.get())
             tr = state["tracker"]
+            tf = time.perf_counter()
             tr.track(f, sync=False)
             r, g, captured = state["out"]
             r.viewmats.copy_(tr.plan.r.viewmats)
@@ -656,6 +661,7 @@ def run_full_cycle(dev, N, W, H, steps=60, warmup=10):
             ev = torch.cuda.Event()
             ev.record()
             to_backend.put(("frame", shipped, ev))
+            counters["t_fe"] += time.perf_counter() - tf
             if (i - warmup) % KF_EVERY == 1:
                 to_backend.put(("cycle",))
         to_backend.join()
@@ -666,6 +672,7 @@ def run_full_cycle(dev, N, W, H, steps=60, warmup=10):
     with torch.cuda.stream(track_stream):
         run(0, warmup)
         base = dict(counters)
+        base["t_parts"] = list(counters["t_parts"])
         rec0 = state["recaptures"]
         t0 = time.perf_counter()
         run(warmup, steps)
@@ -683,6 +690,14 @@ def run_full_cycle(dev, N, W, H, steps=60, warmup=10):
             "gaussians_pruned_in_timed_region": counters["pruned"] - base["pruned"],
             "gaussians_at_end": int(be.splats.means.shape[0]),
             "tracker_recaptures_in_timed_region": state["recaptures"] - rec0,
+            # host wall time of the two threads inside the timed region (they overlap; the longer one bounds the rate)
+            "host_ms": {"elapsed": round(elapsed * 1e3, 1),
+                        "frontend_frames": round((counters["t_fe"] - base["t_fe"]) * 1e3, 1),
+                        "backend_keyframe_tests": round((counters["t_kf"] - base["t_kf"]) * 1e3, 1),
+                        "backend_cycles": round((counters["t_cycle"] - base["t_cycle"]) * 1e3, 1),
+                        "backend_cycle_parts": dict(zip(("optimize_map", "run_pruning", "optimize_poses_lbfgs", "sync"),
+                                                        [round((x - y) * 1e3, 1)
+                                                         for x, y in zip(counters["t_parts"], base["t_parts"])]))},
             "tile_lists_ok": bool(ok), "errors": counters["errors"]}
 
 

@@ -205,15 +205,19 @@ def rasterization(
         raise NotImplementedError("only rasterize_mode='classic', camera_model='pinhole', sparse_grad=False")
     if logit_colors.dim() != 2 or logit_colors.shape != (N, 3):
         raise NotImplementedError("logit_colors must be [N,3] (the reference never passes per-camera colours)")
-    if render_mode in ("D", "ED"):
-        raise NotImplementedError("depth-only modes are not used by gslam (map.py:83: 'RGB' or 'RGB+D')")
+    # depth-only modes (rasterization.py:242-246; no caller in gslam, map.py:83 passes 'RGB' or 'RGB+D'): the depth channel of
+    # the RGB+D render IS the 'D' render - every channel is composited with the same weights - so these modes go through
+    # the RGB+D kernels, return ``rgbs=None`` and a zero colour background (:244-245) keeps the unused channels inert
+    depth_only = render_mode in ("D", "ED")
+    if depth_only and backgrounds is not None:
+        backgrounds = torch.zeros(C, 3, dtype=torch.float32, device=means.device)
     if tile_size != 16:
         raise NotImplementedError("tile_size must be 16")
 
     flags = PROJ_LOG_SCALES
     ch = 3
     depth_index = betas_index = None
-    if render_mode in ("RGB+D", "RGB+ED"):
+    if render_mode in ("RGB+D", "RGB+ED", "D", "ED"):
         flags |= PROJ_RENDER_DEPTH
         depth_index = ch
         ch += 1
@@ -290,7 +294,7 @@ def rasterization(
         bool(absgrad), has_end, bool(need_n_touched), v_rec_buf, tile_order, geom_only)
 
     out = RasterizationOutput(
-        rgbs=render[..., :3],
+        rgbs=None if depth_only else render[..., :3],
         alphas=alphas,
         tile_width=tile_width, tile_height=tile_height, tiles_per_gauss=tiles_per_gauss, isect_ids=isect_ids,
         flatten_ids=flatten_ids, isect_offsets=isect_offsets, width=width, height=height, tile_size=tile_size,
@@ -300,7 +304,7 @@ def rasterization(
     out._lazy = lazy
     if depth_index is not None:
         out.depthmaps = render[..., depth_index]
-        if render_mode == "RGB+ED":
+        if render_mode in ("RGB+ED", "ED"):
             out.depthmaps = out.depthmaps / alphas[..., 0].clamp(min=1e-10)
     if betas_index is not None:
         out.betas = render[..., betas_index]

@@ -304,6 +304,10 @@ class Oracle:
                    backgrounds_packed=bg)
         if depth_index is not None:
             out["depthmaps"] = render[..., depth_index]
+            if render_mode in ("ED", "RGB+ED"):
+                # :342-344 raises KeyError('depthaps') in the reference; this is the intent its comment documents
+                # ("normalize the accumulated depth to get the expected depth"), which the HIP path implements
+                out["depthmaps"] = out["depthmaps"] / np.maximum(alphas[..., 0], dt.type(1e-10))
         if betas_index is not None:
             out["betas"] = render[..., betas_index]
         out["rgbs"] = render[..., :3] if render_mode not in ("D", "ED") else None
