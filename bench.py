@@ -336,7 +336,16 @@ def run_headline(args, dev):
             # every KF_EVERY-th frame is a keyframe; the phase puts the keyframes of the timed region at its frames 1, 6, 11, ...
             # so that a region of K frames holds exactly K / KF_EVERY BA rounds and each of them has frames to run beside, as
             # in the steady state (with the keyframe on the region's LAST frame a short run ends on a BA round running alone)
-            if (i - warmup) % KF_EVERY == 1 and "no-ba" not in diag:
+            if "spread" in diag:
+                # (tuning run) the same BA_ITERS iterations per keyframe interval, dealt evenly over its frames
+                with torch.cuda.stream(map_stream):
+                    for _ in range(BA_ITERS // KF_EVERY):
+                        plan.step()
+                        n_ba += 1
+                    if (i - warmup) % KF_EVERY == 0:
+                        payload = mailbox.publish(backend_map)
+                        pending = (payload, payload._mail_event)
+            elif (i - warmup) % KF_EVERY == 1 and "no-ba" not in diag:
                 # the backend's map is its own copy; its BA round only waits for the previous one and overlaps the
                 # tracking of the following frames
                 with torch.cuda.stream(map_stream):
