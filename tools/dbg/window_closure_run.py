@@ -23,6 +23,14 @@ def main():
     for i, f in enumerate(frames):
         f.index = i
         f.exposure_params = f.exposure_params.detach()
+    if os.environ.get("FRONT"):                         # force the fused front (default: generic path when C * N >= 2^20)
+        import gslam_amd.plan as P
+        orig = P.RenderPlan.__init__
+
+        def patched(self, *a, **k):
+            k["front"] = bool(int(os.environ["FRONT"]))
+            orig(self, *a, **k)
+        P.RenderPlan.__init__ = patched
     ref = GraphedPoseRefiner(splats, frames)
     ref.capture()
     for _ in range(2):
