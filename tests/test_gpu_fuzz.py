@@ -209,3 +209,76 @@ def test_rasterization_gradients_vs_autograd_of_second_restatement(dev, k):
         # bounded loosely, the bulk tightly (same bars as tests/test_gpu_parity.py)
         assert worst < 1e-3 and bulk < 1e-4, (k, name, worst, bulk)          # measured: <= 1.4e-5 / 8.6e-6
     print("grad fuzz", {kk: k[kk] for kk in ("n", "c", "W", "H")}, [(nm, f"{a:.1e}", f"{b:.1e}") for nm, a, b in report])
+
+
+def _gsplat_case(seed):
+    rng = np.random.default_rng(2000 + seed)
+    return dict(seed=seed, n=int(rng.choice([1, 64, 500, 3000])), c=int(rng.integers(1, 4)),
+                W=int(rng.choice([31, 100, 320, 333])), H=int(rng.choice([17, 90, 240, 251])),
+                mode=str(rng.choice(["RGB", "RGB+D", "D", "ED", "RGB+ED"])),
+                sh=[None, 0, 1, 2, 3][int(rng.integers(0, 5))], aa=bool(rng.integers(0, 2)),
+                per_cam=bool(rng.integers(0, 2)), with_bg=bool(rng.integers(0, 2)), fat=float(rng.choice([0.0, 0.7])))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_gsplat_shaped_rendering_random_case_vs_oracle(dev, oracle32, seed):
+    """surface (ii) of SURVEY 8b - ``gsplat.rendering.rasterization`` as pipeline.py:106-116 calls it (post-activation inputs) -
+    over random shapes: SH degree None / 0..3, per-camera colours, antialiased compensation, every render mode; the oracle
+    side is composed here from its kernels (projection, SH, binning, rasteriser) exactly as SURVEY 9.7 describes upstream"""
+    from gslam_amd.rendering import rasterization
+    from gslam_amd.synthetic import make_cameras, make_scene
+    k = _gsplat_case(seed)
+    n, c, W, H, mode = k["n"], k["c"], k["W"], k["H"], k["mode"]
+    gen = torch.Generator().manual_seed(seed)
+    sc = make_scene(n, 70 + seed)
+    means, quats = sc["means"], sc["quats"]
+    scales, opac = torch.exp(sc["scales"] + k["fat"]), torch.sigmoid(sc["opacities"])
+    viewmats, Ks = make_cameras(c, W, H)
+    if k["sh"] is not None:
+        colors = torch.randn(n, 16, 3, generator=gen) * 0.3
+    elif k["per_cam"]:
+        colors = torch.rand(c, n, 3, generator=gen)
+    else:
+        colors = torch.rand(n, 3, generator=gen)
+    n_bg = 0 if mode in ("D", "ED") else 3
+    bg = torch.rand(c, max(n_bg, 1), generator=gen) if k["with_bg"] else None
+    d = lambda t: t.to(dev)
+    render, alphas, meta = rasterization(d(means), d(quats), d(scales), d(opac), d(colors), d(viewmats), d(Ks), W, H,
+                                         sh_degree=k["sh"], packed=False, backgrounds=None if bg is None else d(bg),
+                                         render_mode=mode, rasterize_mode="antialiased" if k["aa"] else "classic")
+    # ---- oracle composition ----
+    o = oracle32
+    scales_gpu = _np(d(scales))                                            # same bits (no exp on this surface)
+    radii, m2d, dep, con, comp = o.project_fwd(_np(means), _np(quats), scales_gpu, _np(viewmats), _np(Ks), W, H,
+                                               calc_compensations=k["aa"])
+    op = np.broadcast_to(_np(opac)[None], (c, n)).astype(np.float32).copy()
+    if k["aa"]:
+        op = op * comp
+    if k["sh"] is not None:
+        campos = np.linalg.inv(_np(viewmats).astype(np.float64))[:, :3, 3].astype(np.float32)
+        dirs = _np(means)[None] - campos[:, None]
+        cols = o.sh_fwd(k["sh"], dirs, _np(colors), radii)
+    else:
+        cols = np.broadcast_to(_np(colors) if colors.dim() == 3 else _np(colors)[None], (c, n, 3)).astype(np.float32).copy()
+    obg = None if bg is None else _np(bg)
+    if mode in ("RGB+D", "RGB+ED"):
+        cols = np.concatenate([cols, dep[..., None]], -1)
+        obg = None if obg is None else np.concatenate([obg, np.zeros((c, 1), np.float32)], -1)
+    elif mode in ("D", "ED"):
+        cols = dep[..., None].copy()
+        obg = None if obg is None else np.zeros((c, 1), np.float32)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    tpg, ids, flat = o.isect_tiles(m2d, radii, dep, 16, tw, th)
+    off = o.isect_offset_encode(ids, c, tw, th)
+    o_render, o_alpha, _, o_nt = o.raster_fwd(m2d, con, np.ascontiguousarray(cols), op, obg, W, H, 16, off, flat)
+    if mode in ("ED", "RGB+ED"):
+        o_render = np.concatenate([o_render[..., :-1], o_render[..., -1:] / np.maximum(o_alpha, 1e-10)], -1)
+    for name, got, want in (("radii", meta["radii"], radii), ("tiles_per_gauss", meta["tiles_per_gauss"], tpg),
+                            ("isect_ids", meta["isect_ids"], ids), ("flatten_ids", meta["flatten_ids"], flat),
+                            ("isect_offsets", meta["isect_offsets"], off)):
+        assert np.array_equal(_np(got), want), (k, name)
+    assert tuple(render.shape) == o_render.shape, (k, tuple(render.shape), o_render.shape)
+    scale = max(1.0, float(np.abs(o_render).max()))
+    assert np.abs(_np(render) - o_render).mean() < 1e-5 * scale, (k, np.abs(_np(render) - o_render).mean())
+    assert np.abs(_np(render) - o_render).max() < 5e-3 * scale, (k, np.abs(_np(render) - o_render).max())
+    assert np.abs(_np(alphas) - o_alpha).max() < 5e-3 and np.abs(_np(alphas) - o_alpha).mean() < 1e-6, k
