@@ -224,7 +224,8 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     """gsplat isect_tiles (gslam/rasterization.py:261-272) -> (tiles_per_gauss[C,N] i32, isect_ids[M] i64,
     flatten_ids[M] i32).  One device->host read-back of M, like the reference."""
     if packed:
-        raise NotImplementedError("packed isect_tiles is not on the gslam hot path (map.py:99 passes packed=False)")
+        return _isect_tiles_packed(means2d, radii, depths, tile_size, tile_width, tile_height, sort, n_cameras,
+                                   camera_ids, gaussian_ids)
     if tile_size != TILE:
         raise NotImplementedError("tile_size must be 16 (the only value the reference uses, rasterization.py:59)")
     means2d, depths = _f32c(means2d.detach(), "means2d"), _f32c(depths.detach(), "depths")
@@ -265,6 +266,40 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
         check(lib.gsx_isect_emit(ptr(means2d), ptr(radii), ptr(depths), ptr(cum), N, Cn, tile_width, tile_height, M,
                                  ptr(isect_ids), ptr(flatten_ids), st), "gsx_isect_emit")
     return tiles_per_gauss, isect_ids, flatten_ids
+
+
+@torch.no_grad()
+def _isect_tiles_packed(means2d, radii, depths, tile_size, tile_width, tile_height, sort, n_cameras, camera_ids,
+                        gaussian_ids):
+    """packed=True (gslam/rasterization.py:261-272 with the [nnz] arrays of the packed projection, :174-182): per-row camera
+    ids instead of a [C,N] layout; ``flatten_ids`` index the packed rows.  Not on gslam's live path (map.py:99 passes
+    packed=False): served by the dense kernels over a [C, max rows per camera] layout that keeps every camera's rows in
+    their packed order - the sort key (camera, tile, depth bits) and the tie order (ascending row) are the same, so the
+    outputs equal gsplat's packed ones entry for entry.  One extra read-back (rows per camera)."""
+    if n_cameras is None or camera_ids is None or gaussian_ids is None:
+        raise ValueError("packed isect_tiles needs n_cameras, camera_ids and gaussian_ids")
+    nnz = int(radii.shape[0])
+    assert means2d.shape == (nnz, 2) and depths.shape == (nnz,) and camera_ids.shape == (nnz,)
+    dev = means2d.device
+    Cn = int(n_cameras)
+    if nnz == 0:
+        e = lambda dt: torch.empty(0, dtype=dt, device=dev)
+        return e(torch.int32), e(torch.int64), e(torch.int32)
+    cam = camera_ids.long()
+    cnt = torch.bincount(cam, minlength=Cn)
+    start = torch.cumsum(cnt, 0) - cnt
+    order = torch.argsort(cam, stable=True)                    # rows grouped by camera, packed order kept inside a camera
+    j = torch.empty(nnz, dtype=torch.int64, device=dev)
+    j[order] = torch.arange(nnz, device=dev) - start[cam[order]]
+    Np = int(cnt.max().item())
+    dense = lambda t, tail=(): torch.zeros((Cn, Np) + tuple(tail), dtype=t.dtype, device=dev).index_put((cam, j), t)
+    tpg_d, isect_ids, flat_d = isect_tiles(dense(_f32c(means2d.detach(), "means2d"), (2,)), dense(radii.to(torch.int32)),
+                                           dense(_f32c(depths.detach(), "depths")), tile_size, tile_width, tile_height,
+                                           sort=sort, n_cameras=Cn)
+    row_of = torch.full((Cn * Np,), -1, dtype=torch.int64, device=dev)
+    row_of[cam * Np + j] = torch.arange(nnz, device=dev)
+    flatten_ids = row_of[flat_d.long()].to(torch.int32)
+    return tpg_d[cam, j].contiguous(), isect_ids, flatten_ids
 
 
 @torch.no_grad()
@@ -415,7 +450,25 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
     offsets_have_end (extension, sync-free callers): ``isect_offsets`` is the flat int32 [T+1] array of isect_bin_sort and
     ``flatten_ids`` a capacity-sized buffer - tile ranges are clamped to it, nothing is read back."""
     if packed:
-        raise NotImplementedError("packed rasterize_to_pixels is not on the gslam hot path")
+        # packed=True (gslam/rasterization.py:336): [nnz, ...] arrays indexed by flatten_ids.  The kernels index rows by
+        # flatten id only (the camera comes from the tile), so the packed rows, padded to a multiple of C, ARE a [C, N']
+        # layout with the same row numbers; n_touched comes back per packed row.
+        Cn = int(isect_offsets.shape[0]) if not offsets_have_end else None
+        if Cn is None:
+            raise NotImplementedError("packed rasterize_to_pixels with flat offsets")
+        nnz = int(means2d.shape[0])
+        Np = max(1, -(-nnz // Cn))
+        pad = Cn * Np - nnz
+
+        def as_dense(t):
+            if pad:
+                t = torch.cat([t, torch.zeros((pad,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)], 0)
+            return t.reshape((Cn, Np) + tuple(t.shape[1:]))
+        render, alphas, nt = rasterize_to_pixels(as_dense(means2d), as_dense(conics), as_dense(colors), as_dense(opacities),
+                                                 image_width, image_height, tile_size, isect_offsets, flatten_ids,
+                                                 backgrounds=backgrounds, masks=masks, packed=False, absgrad=absgrad,
+                                                 visibility_min_T=visibility_min_T, tile_order=tile_order)
+        return render, alphas, nt.reshape(-1)[:nnz]
     if masks is not None:
         raise NotImplementedError("tile masks are never passed by the reference")
     if tile_size != TILE:

@@ -749,3 +749,53 @@ def test_sh_from_means_equals_direction_form(dev, oracle32):
         if deg > 0:
             assert float(cb.grad.abs().max()) > 0
         assert float((ca.grad - cb.grad).abs().max()) <= 2e-4 * float(cb.grad.abs().max()) + 1e-7
+
+
+def test_packed_operator_pipeline_equals_dense(dev):
+    """SURVEY 8b surface (i) with packed=True end to end (gslam/rasterization.py:174-182, :261-272, :325-339): packed projection ->
+    isect_tiles(packed, camera_ids, gaussian_ids) -> isect_offset_encode -> rasterize_to_pixels(packed) against the dense
+    pipeline on the same scene: the same keys, the same lists (flatten ids name packed rows), bit-equal images and per-row
+    touched counts, and the same gradients on the packed arrays' rows"""
+    from gslam_amd import ops
+    n, c, W, H = 3000, 3, 320, 240
+    sc, viewmats, Ks = _scene(n, 21, c, W, H, dev)
+    scales = torch.exp(sc["scales"] + 0.5)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    g = torch.Generator().manual_seed(3)
+    colors = torch.rand(c, n, 4, generator=g).to(dev)
+    opac = torch.rand(c, n, generator=g).to(dev) * 0.9 + 0.05
+    bg = torch.rand(c, 4, generator=g).to(dev)
+    # dense
+    radii, m2d, dep, con, _ = ops.fully_fused_projection(sc["means"], None, sc["quats"], scales, viewmats, Ks, W, H)
+    tpg, ids, flat = ops.isect_tiles(m2d, radii, dep, 16, tw, th, n_cameras=c)
+    off = ops.isect_offset_encode(ids, c, tw, th)
+    dm, dc, dcol, dop = (t.clone().requires_grad_(True) for t in (m2d, con, colors, opac))
+    r_d, a_d, nt_d = ops.rasterize_to_pixels(dm, dc, dcol, dop, W, H, 16, off, flat, backgrounds=bg)
+    # packed
+    cam, gid, pr, pm, pd, pc, _ = ops.fully_fused_projection(sc["means"], None, sc["quats"], scales, viewmats, Ks, W, H,
+                                                             packed=True)
+    nnz = cam.numel()
+    assert 0 < nnz < c * n
+    ptpg, pids, pflat = ops.isect_tiles(pm, pr, pd, 16, tw, th, packed=True, n_cameras=c, camera_ids=cam, gaussian_ids=gid)
+    poff = ops.isect_offset_encode(pids, c, tw, th)
+    assert torch.equal(pids, ids) and torch.equal(poff, off)
+    assert torch.equal(ptpg, tpg[cam, gid])
+    assert torch.equal((cam * n + gid)[pflat.long()], flat.long())       # the packed rows the lists name are the same pairs
+    pmr, pcr = pm.clone().requires_grad_(True), pc.clone().requires_grad_(True)
+    pcol, pop = colors[cam, gid].clone().requires_grad_(True), opac[cam, gid].clone().requires_grad_(True)
+    r_p, a_p, nt_p = ops.rasterize_to_pixels(pmr, pcr, pcol, pop, W, H, 16, poff, pflat, backgrounds=bg, packed=True)
+    assert torch.equal(r_p, r_d) and torch.equal(a_p, a_d)
+    assert torch.equal(nt_p, nt_d[cam, gid]) and tuple(nt_p.shape) == (nnz,)
+    w = torch.randn(r_d.shape, generator=g).to(dev)
+    (r_d * w).sum().backward()
+    (r_p * w).sum().backward()
+    for a, b in ((pmr.grad, dm.grad[cam, gid]), (pcr.grad, dc.grad[cam, gid]), (pcol.grad, dcol.grad[cam, gid]),
+                 (pop.grad, dop.grad[cam, gid])):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7 * float(b.abs().max()))
+    # unsorted camera ids (rows of two cameras interleaved) keep each camera's row order: same keys, lists name the same pairs
+    rows = torch.argsort((torch.arange(nnz, device=dev) % 7) * nnz + torch.arange(nnz, device=dev), stable=True)
+    _, sids, sflat = ops.isect_tiles(pm[rows], pr[rows], pd[rows], 16, tw, th, packed=True, n_cameras=c,
+                                     camera_ids=cam[rows], gaussian_ids=gid[rows])
+    assert torch.equal(sids, ids)
+    same_depth_tie_free = (cam[rows] * n + gid[rows])[sflat.long()]
+    assert torch.equal(torch.sort(same_depth_tie_free)[0], torch.sort(flat.long())[0])
