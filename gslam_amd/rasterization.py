@@ -6,6 +6,10 @@ build must not copy: the ``ED`` / ``RGB+ED`` post-processing (KeyError 'depthaps
 implemented as the documented intent (depth / alpha), the >32-channel chunk loop (wrong variable at :323) and the
 ``covars`` path (:129-134 vs :147) are rejected explicitly.
 
+The live argument set (map.py:88-103: [N,3] colours, 'classic', 'RGB' / 'RGB+D') runs on the fused kernels; the depth-only
+modes ride on them; everything else the signature admits - per-camera colours, other colour widths, 'antialiased' - is
+composed from the operator-level entry points (``_rasterization_composed``).
+
 Sizes: by default M is read back once per render, like the reference's ``isect_tiles`` (exact arrays).  With
 ``capacity=IsectCapacity(...)`` the render is sync-free: the tile-binned sort keeps every size on the device and writes
 into capacity-sized buffers; ``isect_ids`` / ``flatten_ids`` are trimmed lazily (first access) and overflow is read from
@@ -201,10 +205,19 @@ def rasterization(
     assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
     if covars is not None:
         raise NotImplementedError("covars= is a dead branch in the reference (rasterization.py:129-134 vs :147)")
-    if rasterize_mode != "classic" or camera_model != "pinhole" or sparse_grad:
-        raise NotImplementedError("only rasterize_mode='classic', camera_model='pinhole', sparse_grad=False")
-    if logit_colors.dim() != 2 or logit_colors.shape != (N, 3):
-        raise NotImplementedError("logit_colors must be [N,3] (the reference never passes per-camera colours)")
+    if camera_model != "pinhole" or sparse_grad:
+        raise NotImplementedError("only camera_model='pinhole', sparse_grad=False")
+    assert rasterize_mode in ("classic", "antialiased"), rasterize_mode
+    assert (logit_colors.dim() == 2 and logit_colors.shape[0] == N) or (
+        logit_colors.dim() == 3 and logit_colors.shape[:2] == (C, N)), logit_colors.shape       # rasterization.py:141-143
+    if rasterize_mode != "classic" or logit_colors.dim() != 2 or logit_colors.shape != (N, 3):
+        # argument sets no caller in gslam uses (map.py:88-103 passes [N,3] colours, 'classic'): per-camera colours, colour
+        # widths other than 3, antialiased opacity compensation - composed from the operators, not the fused kernels
+        if tile_size != 16:
+            raise NotImplementedError("tile_size must be 16")
+        return _rasterization_composed(means, quats, log_scales, logit_opacities, logit_colors, viewmats, Ks, width, height,
+                                       near_plane, far_plane, radius_clip, eps2d, packed, backgrounds, render_mode, absgrad,
+                                       rasterize_mode, log_uncertainties, visibility_min_T)
     # depth-only modes (rasterization.py:242-246; no caller in gslam, map.py:83 passes 'RGB' or 'RGB+D'): the depth channel of
     # the RGB+D render IS the 'D' render - every channel is composited with the same weights - so these modes go through
     # the RGB+D kernels, return ``rgbs=None`` and a zero colour background (:244-245) keeps the unused channels inert
@@ -310,6 +323,78 @@ def rasterization(
         out.betas = render[..., betas_index]
     # private extras for the fused loss (gslam_amd.losses): the un-split render and per-Gaussian visibility counts
     out._render, out._depth_index, out._betas_index, out._vis_count = render, depth_index, betas_index, vis_count
+    if packed:
+        _pack_output(out, N, C, packed_sel, packed_means2d)
+    return out
+
+
+def _rasterization_composed(means, quats, log_scales, logit_opacities, logit_colors, viewmats, Ks, width, height, near_plane,
+                            far_plane, radius_clip, eps2d, packed, backgrounds, render_mode, absgrad, rasterize_mode,
+                            log_uncertainties, visibility_min_T) -> RasterizationOutput:
+    """gslam/rasterization.py:145-360 step by step over the operator-level entry points (torch activations, projection,
+    channel packing, binning, rasteriser with its 5-channel chunks): every argument set the signature admits and the fused
+    kernels do not specialise for.  Same outputs, same autograd contract (``means2d`` is a graph node)."""
+    N, C = means.shape[0], viewmats.shape[0]
+    opac = torch.sigmoid(logit_opacities)                                           # :145-149
+    colors = torch.sigmoid(logit_colors)
+    scales = torch.exp(log_scales)
+    betas = torch.exp(log_uncertainties).clamp(min=0.01) if log_uncertainties is not None else None
+    radii, means2d, depths, conics, comps = ops.fully_fused_projection(
+        means, None, quats, scales, viewmats, Ks, int(width), int(height), eps2d=eps2d, packed=False,
+        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,
+        calc_compensations=(rasterize_mode == "antialiased"))                       # :153-170
+    opacities = opac.repeat(C, 1)                                                   # :187
+    if comps is not None:
+        opacities = opacities * comps                                               # :190-191
+    packed_means2d = packed_sel = None
+    if packed:
+        packed_sel = torch.nonzero((radii > 0).reshape(-1)).squeeze(1)
+        packed_means2d = means2d.reshape(-1, 2)[packed_sel]
+        means2d = torch.zeros(C * N, 2, dtype=means2d.dtype, device=means2d.device).index_put(
+            (packed_sel,), packed_means2d).view(C, N, 2)
+    cols = colors if colors.dim() == 3 else colors.unsqueeze(0).expand(C, -1, -1)    # :222-228
+    depth_only = render_mode in ("D", "ED")
+    depth_index = betas_index = None
+    if render_mode in ("RGB+D", "RGB+ED"):                                          # :234-240
+        cols = torch.cat((cols, depths[..., None]), dim=-1)
+        if backgrounds is not None:
+            backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=backgrounds.device)], dim=-1)
+        depth_index = cols.shape[-1] - 1
+    elif depth_only:                                                                # :241-246
+        cols = depths[..., None]
+        if backgrounds is not None:
+            backgrounds = torch.zeros(C, 1, device=backgrounds.device)
+        depth_index = 0
+    if betas is not None:                                                           # :249-256
+        cols = torch.cat((cols, betas[None, :, None].expand(C, -1, -1)), dim=-1)
+        if backgrounds is not None:
+            backgrounds = torch.cat([backgrounds, torch.full((C, 1), math.e, device=backgrounds.device)], dim=-1)
+        betas_index = cols.shape[-1] - 1
+    tile_width, tile_height = math.ceil(width / 16.0), math.ceil(height / 16.0)
+    tiles_per_gauss, isect_ids, flatten_ids = ops.isect_tiles(means2d, radii, depths, 16, tile_width, tile_height,
+                                                              packed=False, n_cameras=C)
+    isect_offsets = ops.isect_offset_encode(isect_ids, C, tile_width, tile_height)
+    render, alphas, n_touched = ops.rasterize_to_pixels(means2d, conics, cols.contiguous(), opacities.contiguous(),
+                                                        int(width), int(height), 16, isect_offsets, flatten_ids,
+                                                        backgrounds=backgrounds, packed=False, absgrad=absgrad,
+                                                        visibility_min_T=visibility_min_T)
+    out = RasterizationOutput(
+        rgbs=None if depth_only else render[..., :3],                               # :347-348 keeps the first three channels
+        alphas=alphas,
+        tile_width=tile_width, tile_height=tile_height, tiles_per_gauss=tiles_per_gauss, isect_ids=isect_ids,
+        flatten_ids=flatten_ids, isect_offsets=isect_offsets, width=width, height=height, tile_size=16,
+        n_cameras=C, camera_ids=None, gaussian_ids=None, radii=radii, means2d=means2d, depths=depths, conics=conics,
+        opacities=opacities, n_touched=n_touched,
+    )
+    out._lazy = None
+    if depth_index is not None:
+        out.depthmaps = render[..., depth_index]
+        if render_mode in ("RGB+ED", "ED"):
+            out.depthmaps = out.depthmaps / alphas[..., 0].clamp(min=1e-10)
+    if betas_index is not None:
+        out.betas = render[..., betas_index]
+    out._render, out._depth_index, out._betas_index = render, depth_index, betas_index
+    out._vis_count = (radii > 0).sum(0).to(torch.int32)
     if packed:
         _pack_output(out, N, C, packed_sel, packed_means2d)
     return out

@@ -282,3 +282,79 @@ def test_gsplat_shaped_rendering_random_case_vs_oracle(dev, oracle32, seed):
     assert np.abs(_np(render) - o_render).mean() < 1e-5 * scale, (k, np.abs(_np(render) - o_render).mean())
     assert np.abs(_np(render) - o_render).max() < 5e-3 * scale, (k, np.abs(_np(render) - o_render).max())
     assert np.abs(_np(alphas) - o_alpha).max() < 5e-3 and np.abs(_np(alphas) - o_alpha).mean() < 1e-6, k
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_gslam_rasterization_composed_argument_sets_vs_oracle(dev, oracle32, seed):
+    """argument sets of gslam/rasterization.py:44-71 that no caller in gslam uses and the fused kernels do not specialise for -
+    per-camera colours [C,N,D], colour widths other than 3 (D = 1..7: two channel chunks), rasterize_mode='antialiased'
+    (opacity x compensation, :190-191) - served by the operator composition; against the oracle's kernels composed the same way"""
+    from gslam_amd.rasterization import rasterization
+    from gslam_amd.synthetic import make_cameras, make_scene
+    rng = np.random.default_rng(3000 + seed)
+    n, c = int(rng.choice([5, 300, 2000])), int(rng.integers(1, 4))
+    W, H = int(rng.choice([64, 161, 320])), int(rng.choice([48, 120, 240]))
+    D = int(rng.choice([1, 3, 4, 7]))
+    per_cam, aa = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    mode = str(rng.choice(["RGB", "RGB+D", "RGB+ED"]))
+    with_unc = bool(rng.integers(0, 2))
+    if D == 3 and not per_cam:
+        aa = True                                                # [N,3] + classic is the fused path: not what this test is for
+    k = dict(seed=seed, n=n, c=c, W=W, H=H, D=D, per_cam=per_cam, aa=aa, mode=mode, with_unc=with_unc)
+    gen = torch.Generator().manual_seed(seed)
+    sc = make_scene(n, 90 + seed)
+    sc["scales"] = sc["scales"] + 0.5
+    viewmats, Ks = make_cameras(c, W, H)
+    logit_colors = torch.randn((c, n, D) if per_cam else (n, D), generator=gen)
+    unc = torch.linspace(-6.0, 1.0, n) if with_unc else None
+    bg = torch.rand(c, D, generator=gen)
+    d = lambda t: None if t is None else t.to(dev)
+    leaves = [d(sc["means"]).requires_grad_(True), d(logit_colors).requires_grad_(True)]
+    out = rasterization(leaves[0], d(sc["quats"]), d(sc["scales"]), d(sc["opacities"]), leaves[1], d(viewmats), d(Ks), W, H,
+                        packed=False, render_mode=mode, log_uncertainties=d(unc), backgrounds=d(bg),
+                        rasterize_mode="antialiased" if aa else "classic")
+    o = oracle32
+    sig = lambda x: (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
+    scales_gpu = _np(torch.exp(d(sc["scales"])))
+    radii, m2d, dep, con, comp = o.project_fwd(_np(sc["means"]), _np(sc["quats"]), scales_gpu, _np(viewmats), _np(Ks), W, H,
+                                               calc_compensations=aa)
+    op = np.broadcast_to(sig(_np(sc["opacities"]))[None], (c, n)).copy()
+    if aa:
+        op = op * comp
+    cols = sig(_np(logit_colors))
+    cols = np.broadcast_to(cols if per_cam else cols[None], (c, n, D)).copy()
+    obg = _np(bg)
+    if mode != "RGB":
+        cols = np.concatenate([cols, dep[..., None]], -1)
+        obg = np.concatenate([obg, np.zeros((c, 1), np.float32)], -1)
+    if with_unc:
+        betas = np.maximum(np.exp(_np(unc)), np.float32(0.01))
+        cols = np.concatenate([cols, np.broadcast_to(betas[None, :, None], (c, n, 1))], -1)
+        obg = np.concatenate([obg, np.full((c, 1), math.e, np.float32)], -1)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    tpg, ids, flat = o.isect_tiles(m2d, radii, dep, 16, tw, th)
+    off = o.isect_offset_encode(ids, c, tw, th)
+    CH = cols.shape[-1]
+    parts = [o.raster_fwd(m2d, con, np.ascontiguousarray(cols[..., a:a + 5]), op, np.ascontiguousarray(obg[..., a:a + 5]),
+                          W, H, 16, off, flat) for a in range(0, CH, 5)]
+    o_render = np.concatenate([p[0] for p in parts], -1)
+    o_alpha = parts[0][1]
+    assert np.array_equal(_np(out.radii), radii) and np.array_equal(_np(out.flatten_ids), flat), k
+    assert np.array_equal(_np(out.isect_ids), ids) and np.array_equal(_np(out.isect_offsets), off), k
+    np.testing.assert_allclose(_np(out.opacities), op, atol=2e-6)
+    assert np.abs(_np(out.alphas) - o_alpha).max() < 5e-3 and np.abs(_np(out.alphas) - o_alpha).mean() < 1e-6, k
+    want_rgb = o_render[..., :3]                                 # rasterization.py:347-348 keeps render_colors[..., :3]
+    assert tuple(out.rgbs.shape) == want_rgb.shape, (k, tuple(out.rgbs.shape), want_rgb.shape)
+    assert np.abs(_np(out.rgbs) - want_rgb).mean() < 1e-5 * max(1.0, float(np.abs(want_rgb).max())), k
+    if mode != "RGB":
+        want = o_render[..., D]
+        if mode == "RGB+ED":
+            want = want / np.maximum(o_alpha[..., 0], 1e-10)
+        assert np.abs(_np(out.depthmaps) - want).mean() < 1e-5 * max(1.0, float(np.abs(want).max())), k
+    if with_unc:
+        assert np.abs(_np(out.betas) - o_render[..., -1]).mean() < 1e-5, k
+    if out.rgbs.requires_grad:
+        out.means2d.retain_grad()
+        (out.rgbs.sum() + out.alphas.sum()).backward()
+        assert bool(torch.isfinite(leaves[0].grad).all()) and bool(torch.isfinite(leaves[1].grad).all())
+        assert tuple(out.means2d.grad.shape) == (c, n, 2)
