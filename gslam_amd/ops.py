@@ -202,14 +202,17 @@ def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optio
 def quat_scale_to_covar_preci(quats: Tensor, scales: Tensor, compute_covar: bool = True, compute_preci: bool = True,
                               triu: bool = False):
     """gsplat.quat_scale_to_covar_preci as used (under no_grad) at gslam/insertion.py:88-91."""
-    if triu:
-        raise NotImplementedError("triu=True is not used by the reference")
     quats, scales = _f32c(quats, "quats"), _f32c(scales, "scales")
     n = quats.shape[0]
     covars = torch.empty(n, 3, 3, dtype=torch.float32, device=quats.device)
     precis = torch.empty(n, 3, 3, dtype=torch.float32, device=quats.device) if compute_preci else None
     check(lib.gsx_quat_scale_to_covar_preci(ptr(quats.detach()), ptr(scales.detach()), n, ptr(covars), ptr(precis),
                                             stream_ptr(quats.device)), "gsx_quat_scale_to_covar_preci")
+    if triu:
+        # upper-triangular 6-vectors (xx, xy, xz, yy, yz, zz), the order of gslam/rasterization.py:133-134; unused by gslam
+        iu = ([0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2])
+        covars = covars[..., iu[0], iu[1]]
+        precis = None if precis is None else precis[..., iu[0], iu[1]]
     return (covars if compute_covar else None), precis
 
 

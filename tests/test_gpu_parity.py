@@ -480,6 +480,12 @@ def test_quat_scale_to_covar_preci(dev, oracle32):
     cov, pre = ops.quat_scale_to_covar_preci(q.to(dev), s.to(dev))
     oc, op = oracle32.quat_scale_to_covar_preci(_np(q), _np(s))
     assert np.array_equal(_np(cov), oc) and np.array_equal(_np(pre), op)
+    cov6, pre6 = ops.quat_scale_to_covar_preci(q.to(dev), s.to(dev), triu=True)      # (xx, xy, xz, yy, yz, zz)
+    iu = ([0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2])
+    assert tuple(cov6.shape) == (1000, 6) and np.array_equal(_np(cov6), oc[:, iu[0], iu[1]])
+    assert np.array_equal(_np(pre6), op[:, iu[0], iu[1]])
+    only_p = ops.quat_scale_to_covar_preci(q.to(dev), s.to(dev), compute_covar=False)
+    assert only_p[0] is None and np.array_equal(_np(only_p[1]), op)
 
 
 def test_adam_matches_torch_and_oracle(dev, oracle32):
