@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--gaussians", type=int, default=500_000)
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--ba", type=int, default=0, help="BA iterations over an 8-keyframe window after the tracking")
+    ap.add_argument("--ba-window", type=int, default=8, help="keyframes in the BA window (1 = BASELINE.json configs[1])")
     ap.add_argument("--eager", action="store_true", help="issue the launches eagerly (counter passes cannot attribute graph nodes)")
     ap.add_argument("--front", type=int, default=-1, help="1 / 0 force the fused front on / off")
     ap.add_argument("--ba-front", type=int, default=-1, help="1 / 0 force the fused front of the BA plan on / off")
@@ -71,7 +72,7 @@ def main():
                 k["front"] = bool(args.ba_front)
                 orig(self, *a, **k)
             P.RenderPlan.__init__ = patched
-        plan = ba.plan(frames[:8])
+        plan = ba.plan(frames[:args.ba_window])
         plan.prepare()
         for _ in range(args.ba):
             plan.step(graphed=not args.eager)
