@@ -18,12 +18,16 @@ ARCH = "gfx950"
 
 # -ffp-contract=off: integer outputs (radii, tile rectangles, sort keys) must match the CPU oracle bit for bit.
 SOURCES = {
-    "project.hip": ["-ffp-contract=off"],
+    "project.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],     # (SLP: see raster.hip; BA iteration -1.1 % at 500 k x 8)
     "isect.hip": ["-ffp-contract=off"],
     "isect_bin.hip": ["-ffp-contract=off"],
-    "raster.hip": [],
-    "ssim.hip": [],
-    "loss.hip": [],
+    # -fno-slp-vectorize: LLVM's SLP pass pairs scalar fp32 operations of the rasteriser loops into v_pk_*_f32 and pays for every
+    # pair with register moves (fused tracking kernel: 808 -> 761 VALU instructions, 147 -> 88 moves, 66 -> 62 VGPRs without it);
+    # same-box A/B (tools/dbg/ab_flags.sh): tracking alone 150.3 -> 155.4 frames/s, headline 116.9 -> 120.1.  The packed colour
+    # accumulation the kernels ask for explicitly (ext_vector types) is not affected.
+    "raster.hip": ["-fno-slp-vectorize"],
+    "ssim.hip": ["-fno-slp-vectorize"],                             # (-0.7 %)
+    "loss.hip": ["-fno-slp-vectorize"],                             # (-0.5 %)
     "warp.hip": [],
     "pose.hip": [],
     "misc.hip": [],
