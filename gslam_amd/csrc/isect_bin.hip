@@ -1216,45 +1216,54 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
         pm[it][2] = active ? a.means[3 * g + 2] : 0.f;
         psm[it] = active ? fmaxf(a.scales[3 * g], fmaxf(a.scales[3 * g + 1], a.scales[3 * g + 2])) : 0.f;
     }
+    // camera constants once per camera (not per item): the loop over the thread's items is the inner one
+    bool survive[ITEMS];
+    float smax2[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-        const int loc = it * FRONT_THREADS + threadIdx.x;
-        const int64_t g = g0 + loc;
-        const bool active = g < a.N;
-        bool survive = false;
-        if (active) {
-            const float mean[3] = {pm[it][0], pm[it][1], pm[it][2]};
-            float sm = psm[it];
+        survive[it] = false;
+        float sm = psm[it];
 #if GSX_FAST_CULL
-            if (a.flags & GSX_PROJ_LOG_SCALES) sm = __builtin_amdgcn_exp2f(sm * 1.4426950408889634f) * 1.00001f;
+        if (a.flags & GSX_PROJ_LOG_SCALES) sm = __builtin_amdgcn_exp2f(sm * 1.4426950408889634f) * 1.00001f;
 #else
-            if (a.flags & GSX_PROJ_LOG_SCALES) sm = expf(sm);
+        if (a.flags & GSX_PROJ_LOG_SCALES) sm = expf(sm);
 #endif
-            const float smax2 = sm * sm;
-            for (int c = 0; c < C; ++c) {
-                Cam cam;
-                load_cam(a.viewmats, a.Ks, c, cam);
-                const float *R = cam.R;
-                const float RF = ((R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) + (R[3] * R[3] + R[4] * R[4] + R[5] * R[5])) +
-                                 (R[6] * R[6] + R[7] * R[7] + R[8] * R[8]);
-                const float tanx = 0.5f * (float)a.W / cam.fx, tany = 0.5f * (float)a.H / cam.fy;
-                const float lx = fmaxf(((float)a.W - cam.cx) / cam.fx, cam.cx / cam.fx) + GSX_FOV_SLACK * tanx;
-                const float ly = fmaxf(((float)a.H - cam.cy) / cam.fy, cam.cy / cam.fy) + GSX_FOV_SLACK * tany;
-                const float KJ = cam.fx * cam.fx * (1.0f + lx * lx) + cam.fy * cam.fy * (1.0f + ly * ly);
-                const bool out = surely_culled(mean, smax2, cam, RF, KJ, a.W, a.H, a.eps2d, a.near_p, a.far_p);
-                if (!out) survive = true;
-                else if (!skip_culled) survive = true;      // rows of culled instances are wanted as zeros: full path writes them
+        smax2[it] = sm * sm;
+    }
+    for (int c = 0; c < C; ++c) {
+        Cam cam;
+        load_cam(a.viewmats, a.Ks, c, cam);
+        const float *R = cam.R;
+        const float RF = ((R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) + (R[3] * R[3] + R[4] * R[4] + R[5] * R[5])) +
+                         (R[6] * R[6] + R[7] * R[7] + R[8] * R[8]);
+        const float tanx = 0.5f * (float)a.W / cam.fx, tany = 0.5f * (float)a.H / cam.fy;
+        const float lx = fmaxf(((float)a.W - cam.cx) / cam.fx, cam.cx / cam.fx) + GSX_FOV_SLACK * tanx;
+        const float ly = fmaxf(((float)a.H - cam.cy) / cam.fy, cam.cy / cam.fy) + GSX_FOV_SLACK * tany;
+        const float KJ = cam.fx * cam.fx * (1.0f + lx * lx) + cam.fy * cam.fy * (1.0f + ly * ly);
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int64_t g = g0 + it * FRONT_THREADS + threadIdx.x;
+            if (g < a.N) {
+                const float mean[3] = {pm[it][0], pm[it][1], pm[it][2]};
+                const bool out = surely_culled(mean, smax2[it], cam, RF, KJ, a.W, a.H, a.eps2d, a.near_p, a.far_p);
+                if (!out) survive[it] = true;
+                else if (!skip_culled) survive[it] = true;   // rows of culled instances are wanted as zeros: full path writes them
                 else {
                     const int64_t idx = (int64_t)c * a.N + g;
                     if (a.radii) a.radii[idx] = 0;
                     if (a.tiles) a.tiles[idx] = 0;
                 }
             }
-            if (!survive && a.vis_count) a.vis_count[g] = 0;
         }
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int loc = it * FRONT_THREADS + threadIdx.x;
+        const int64_t g = g0 + loc;
+        if (g < a.N && !survive[it] && a.vis_count) a.vis_count[g] = 0;
         int tot;
-        const int pos = ordered_position(survive, s_wcnt, tot);
-        if (survive) s_list[n_surv + pos] = (unsigned short)loc;
+        const int pos = ordered_position(survive[it], s_wcnt, tot);
+        if (survive[it]) s_list[n_surv + pos] = (unsigned short)loc;
         n_surv += tot;
     }
     }   // !use_cand
