@@ -533,7 +533,8 @@ __device__ __forceinline__ unsigned long long *lds_sort(const unsigned long long
 //     dependent binary searches through L2: 6.1 ms of a 13 ms render at 5M Gaussians / 1080p.)
 // A tile whose keys pile up in one bucket (same depth everywhere) falls back to the merge sort inside the same LDS.
 // After the scatter a bucket's cursor is its end, which is the next bucket's start: no separate start array, and the
-// kernel stays at 36 KiB of LDS (4 workgroups of 8 wavefronts per CU).
+// key buffers stay at 36 KiB (+ 16 KiB of parked output, below: 52 KiB, three workgroups of 8 wavefronts per CU; at 36 KiB
+// and four per CU the launch measured 14.8 against 15.0 us - the longest tiles set its duration, not the occupancy).
 constexpr int CNT_NB = 1024;          // buckets, keys staged in LDS
 constexpr int CNT_MAXN = 2048;        // largest tile of the LDS regime = LDS window of the streaming regime
 constexpr int CNT_MAX_BUCKET = 96;    // largest bucket the quadratic step 3 accepts (LDS regime)
