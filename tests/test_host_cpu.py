@@ -237,3 +237,32 @@ def test_keyframe_sharded_ba_collectives_gloo_world2():
         assert p.exitcode == 0
     for rank, ok, vis, mx, t, numel in res:
         assert ok and vis == 5 and mx == 1 and t == 1.0 and numel == 760          # six arrays of 50 rows, each padded to 16 bytes, in 2 chunks of 380 floats
+
+
+def test_step_bucket_layout_partitions_the_map_for_every_world_size():
+    """the sharded update's layout (gslam_amd.dist.bucket_layout / StepBucket.pieces) for the rank counts the scaling runs use
+    and a few awkward ones: equal 16-byte-aligned chunks, every element of every per-Gaussian array in exactly one rank's
+    pieces, pieces inside their chunk - no process group needed (the collectives themselves: the gloo test below)"""
+    import torch
+    from gslam_amd import dist as gdist
+    for n in (1, 7, 50, 1001, 4096):
+        shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 3), (n,)]
+        for world in (1, 2, 3, 4, 5, 8):
+            offs, numels, s_pad, L = gdist.bucket_layout(shapes, world)
+            assert numels == [3 * n, 4 * n, 3 * n, n, 3 * n, n]
+            assert s_pad == world * L and L % 4 == 0 and all(o % 4 == 0 for o in offs)
+            assert s_pad >= offs[-1] + numels[-1] and s_pad - (offs[-1] + (numels[-1] + 3) // 4 * 4) < 4 * world
+            cover = [torch.zeros(k, dtype=torch.int32) for k in numels]
+            for r in range(world):
+                b = gdist.StepBucket(shapes, 8, "cpu", world=world, rank=r)
+                assert b.flat.numel() == s_pad and b.chunk_range() == (r * L, (r + 1) * L)
+                assert (b.gchunk is None) if world == 1 else (b.gchunk.numel() == L)
+                assert b.head.numel() == n + 8 * 9 + 4
+                last_end = 0
+                for k, a, ln, c_off in b.pieces():
+                    cover[k][a:a + ln] += 1
+                    assert ln > 0 and a % 4 == 0 and c_off % 4 == 0 and c_off >= last_end and c_off + ln <= L
+                    last_end = c_off + ln
+                    # the slice of the flat buffer IS the slice of the tensor's view
+                    assert b.views[k].reshape(-1)[a:a + ln].data_ptr() == b.flat[r * L + c_off:].data_ptr()
+            assert all(bool((c == 1).all()) for c in cover), (n, world)

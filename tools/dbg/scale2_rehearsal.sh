@@ -1,11 +1,12 @@
 #!/bin/bash
-# Two-rank rehearsal of the keyframe-sharded BA bench on the ONE GPU of a gpurun box (both ranks on cuda:0, gloo between them;
-# the driver's scaling runs use one rank per GPU over RCCL).  Checks that `bench.py --gpus 2` runs green; its numbers say
+# G-rank (default two; at most 4 here: a box allows 6 GPU processes) rehearsal of the keyframe-sharded BA bench on the ONE GPU of a gpurun box (both ranks on cuda:0, gloo between them;
+# the driver's scaling runs use one rank per GPU over RCCL).  Checks that `bench.py --gpus $G` runs green; its numbers say
 # nothing about xGMI.
 cd $GRAFT_REPO_ROOT
 export GSX_FORCE_DEVICE=0 GSX_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
 N=${1:-500000}
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 3 --gaussians $N > gpurun_out/r03_scale2.json 2> gpurun_out/r03_scale2.err
+G=${2:-2}
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $G --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus $G --steps 10 --warmup 3 --gaussians $N > gpurun_out/r03_scale$G.json 2> gpurun_out/r03_scale$G.err
 echo rc=$?
-tail -c 2500 gpurun_out/r03_scale2.json
-grep -v "amdgpu.ids\|Gloo" gpurun_out/r03_scale2.err | tail -8
+tail -c 2500 gpurun_out/r03_scale$G.json
+grep -v "amdgpu.ids\|Gloo" gpurun_out/r03_scale$G.err | tail -8
