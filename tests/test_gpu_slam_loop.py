@@ -145,3 +145,82 @@ def test_map_mailbox_double_buffer_and_in_place_receive(dev):
     d = box.publish(bigger)                                 # grown map: the slot is re-allocated, the receiver replaces
     mine3, replaced = receive(mine, d)
     assert replaced and mine3.means.shape[0] == 7000 and torch.equal(mine3.quats, bigger.quats)
+
+
+def test_slam_loop_from_a_tum_directory(dev, tmp_path):
+    """SURVEY 8f rank 4 consumed on the GPU: a synthetic sequence WRITTEN in the TUM RGB-D layout (rgb / depth PNGs, rgb.txt,
+    depth.txt, groundtruth.txt with camera-to-world poses as tx ty tz qx qy qz qw at 90 Hz) -> gslam_amd.data.TumRGB (nearest
+    pose in time, freiburg3 intrinsics, valid-pixel rectangle 639x479: image sizes that are not multiples of the tile) ->
+    Frontend / Backend over the message API -> trajectory against the file's ground truth (camera centres, similarity-aligned:
+    the map starts from a mock depth, scale is free)."""
+    import numpy as np
+    from PIL import Image
+    from scipy.spatial.transform import Rotation
+    from gslam_amd.backend import Backend, MapConfig
+    from gslam_amd.data import TumRGB, tum_intrinsics_params
+    from gslam_amd.frontend import Frontend
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.primitives import Camera, PoseZhou
+    from gslam_amd.synthetic import make_scene, make_viewmat
+    from gslam_amd.tracking import TrackingConfig
+    from gslam_amd.trajectory import average_translation_error
+    torch.manual_seed(0)
+    n_frames, W, H = 9, 640, 480
+    fx, fy, cx, cy, *dist = tum_intrinsics_params["freiburg3"]
+    assert not any(dist)
+    K = torch.tensor([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=torch.float32, device=dev)
+    cam = Camera(K, H, W)
+    sc = make_scene(30000, 3)
+    sc["scales"] = sc["scales"] + 0.6
+    world = GaussianSplattingData.from_dict(sc, dev)
+    d = tmp_path / "rgbd_dataset_freiburg3_synthetic"
+    (d / "rgb").mkdir(parents=True)
+    (d / "depth").mkdir()
+    rgb_lines, depth_lines, gt_lines, centres = ["# colour"], ["# depth"], ["# ground truth"], []
+    for i in range(n_frames):
+        V = make_viewmat(i).to(dev)
+        V[:3, 3] *= 0.5
+        with torch.no_grad():
+            out = world([cam], [PoseZhou(V, is_learnable=False).to(dev)], render_depth=True)
+        img = (out.rgbs[0].clamp(0, 1) * 255.0).round().to(torch.uint8).cpu().numpy()
+        dep = (out.depthmaps[0].clamp(0, 13.0) * 5000.0).round().to(torch.int32).cpu().numpy().astype(np.uint16)
+        t = 200.0 + i / 30.0
+        Image.fromarray(img).save(d / "rgb" / f"{t:.6f}.png")
+        Image.fromarray(dep).save(d / "depth" / f"{t:.6f}.png")
+        rgb_lines.append(f"{t:.6f} rgb/{t:.6f}.png")
+        depth_lines.append(f"{t:.6f} depth/{t:.6f}.png")
+        c2w = torch.linalg.inv(V.cpu().double()).numpy()
+        q = Rotation.from_matrix(c2w[:3, :3]).as_quat()                       # x y z w, the TUM order
+        centres.append(c2w[:3, 3])
+        for dt in (-1.0 / 90.0, 0.0, 1.0 / 90.0):                             # 90 Hz ground truth; the reader takes the nearest
+            p = c2w[:3, 3] + (0.0 if dt == 0.0 else 0.5)                       # (the off-time samples are decoys)
+            gt_lines.append(f"{t + dt:.6f} {p[0]:.6f} {p[1]:.6f} {p[2]:.6f} {q[0]:.8f} {q[1]:.8f} {q[2]:.8f} {q[3]:.8f}")
+    (d / "rgb.txt").write_text("\n".join(rgb_lines) + "\n")
+    (d / "depth.txt").write_text("\n".join(depth_lines) + "\n")
+    (d / "groundtruth.txt").write_text("\n".join(gt_lines) + "\n")
+
+    seq = TumRGB(d, device=dev)
+    assert len(seq) == n_frames and seq.roi == (0, 0, 639, 479)
+    to_backend, to_frontend, sensor = queue.Queue(), queue.Queue(), queue.Queue()
+    be = Backend(MapConfig(num_iters_initialization=60, num_iters_mapping=5, kf_m=0.02), to_backend, to_frontend)
+    fe = Frontend(TrackingConfig(), to_backend, to_frontend, sensor)
+    for i in range(n_frames):
+        f = seq[i]
+        assert tuple(f.img.shape) == (479, 639, 3) and f.img.is_cuda
+        np.testing.assert_allclose(f.gt_pose[:3, 3].cpu().numpy(), centres[i], atol=1e-5)
+        fe.track(f)
+        while not to_backend.empty():
+            assert be.handle(to_backend.get())
+        if i:
+            be.idle_step()
+        while not to_frontend.empty():
+            fe.handle_message_from_backend(to_frontend.get())
+    torch.cuda.synchronize()
+    assert len(fe.frames) == n_frames and len(be.keyframes) >= 2
+    est = np.array([np.linalg.inv(fr.pose().detach().cpu().double().numpy())[:3, 3] for fr in fe.frames])
+    gt = np.array([fr.gt_pose[:3, 3].cpu().double().numpy() for fr in fe.frames])
+    ate = average_translation_error(gt, est)
+    path = float(np.linalg.norm(np.diff(gt, axis=0), axis=1).sum())
+    print(f"TUM-directory loop: {n_frames} frames of 639x479, path {path * 100:.1f} cm, ATE (camera centres) {ate * 100:.2f} cm, "
+          f"{be.splats.means.shape[0]} Gaussians, {len(be.keyframes)} keyframes")
+    assert np.isfinite(ate) and ate < ATE_BOUND_M
