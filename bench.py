@@ -23,7 +23,7 @@ gradient bucket, Adam on each rank's chunk, all-gather of the parameters) over R
 iterations / s.  The 1-GPU value of the SAME workload is measured by the --gpus 1 run as well and reported there as
 ``extra.ba_2m_window8`` so that the scaling curve has its 1-GPU point next to the headline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]           (N > 1: starts its own N ranks as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 from __future__ import annotations
@@ -875,14 +875,29 @@ def cpu_baseline_tracking(N, W, H, budget_s=25.0):
                       f"{BA_ITERS}*{WINDOW}/{KF_EVERY}) closures x that), a BA camera counted as one closure (lower bound)"}
 
 
+def launch_ranks(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run this file again under torch.distributed.run, one rank per GPU, as
+    a CHILD process and pass its exit code on.  Nothing in this process has touched the GPU yet (no HIP call, no
+    torch.cuda.is_available()), and nothing is exec'ed: the parent only waits and relays rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world == 1 and args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-        sys.exit(2)
+        sys.exit(launch_ranks(args.gpus))          # plain `python bench.py --gpus N`: start the N ranks ourselves
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
     # rehearsal knobs (1-GPU box): GSX_FORCE_DEVICE=0 puts every rank on cuda:0, GSX_DIST_BACKEND=gloo avoids RCCL's
     # duplicate-GPU check.  The driver's multi-GPU runs use neither: one rank per GPU over RCCL/xGMI.

@@ -245,9 +245,12 @@ class Backend:
                 rows = list(range(min(k, radii.shape[0]))) if widx is None else [j for j, i in enumerate(widx) if i < k]
                 rows_t = torch.tensor(rows, dtype=torch.long, device=dev)
                 bad_views = ((radii[rows_t] > 0) & (nt[rows_t][:, :n] == 0)).sum(dim=0).to(torch.int32)
+                replicated = widx is None          # run_pruning(): every rank rendered the SAME camera (no window shard)
             else:
                 bad_views = torch.zeros(n, dtype=torch.int32, device=dev)
-            shard.all_reduce_sum(bad_views)
+                replicated = False
+            if not replicated:                     # a replicated render is already the whole camera set: summing it over the
+                shard.all_reduce_sum(bad_views)    # ranks would count every bad view G times (threshold G times tighter)
             remove |= bad_views > self.pruning_conditioning.max_frames_thing      # = PruneIllConditionedGaussians.step
         self.ba.sync_moments()                      # (multi-GPU: whole moments on every rank before the rows move)
         remove |= self.pruning_size.step(self.splats, self.splat_optimizers, max_radii)

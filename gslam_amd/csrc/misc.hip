@@ -390,8 +390,10 @@ __global__ void counters_add_kernel(CounterArgs a) {
 __global__ void status_flag_kernel(const int32_t *__restrict__ status, int n, int mask, float *__restrict__ flag) {
     int any = 0;
     for (int i = threadIdx.x; i < n; i += 64) any |= status[i] & mask;
-    const unsigned long long b = __ballot(any != 0);
-    if (threadIdx.x == 0) flag[0] = b ? 1.0f : 0.0f;
+    // bit 2 (clamped, corrupt tile counts) weighs 1024: after the sum over <= 1023 ranks the host still tells "some rank's
+    // lists overflowed" (0 < flag < 1024: grow and redo) from "some rank's counts are corrupt" (flag >= 1024: every rank raises)
+    const unsigned long long over = __ballot((any & ~2) != 0), bad = __ballot((any & 2) != 0);
+    if (threadIdx.x == 0) flag[0] = (over ? 1.0f : 0.0f) + (bad ? 1024.0f : 0.0f);
 }
 
 // ---- self test ------------------------------------------------------------------------------------------------------

@@ -16,6 +16,8 @@
 // parity tests check these kernels against the CPU oracle.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gsx_common.h"
 
 
@@ -443,7 +445,7 @@ extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds
                                backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas,  \
                                last_ids, v_render, v_alphas, v_rec, v_abs);                                          \
         else if (geom_only)                                                                                          \
-            hipLaunchKernelGGL((raster_bwd_kernel4q<ch, rs, 64, true>), dim3((unsigned)T), dim3(256), 0, st, rec,    \
+            hipLaunchKernelGGL((raster_bwd_geom_kernel<ch, rs>), dim3((unsigned)T), dim3(256), 0, st, rec,           \
                                backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas,  \
                                last_ids, v_render, v_alphas, v_rec, tile_order);                                     \
         else if (T >= GSX_BWD_FULLCHIP_TILES)                                                                        \

@@ -384,8 +384,10 @@ class GraphedBundleAdjuster:
     on the host.  Multi-GPU: two graphs (render + loss + backward | isotropic + Adam + decay) around the one eager
     all-reduce.  Needs a BundleAdjuster built with capturable=True; the window's poses are updated in place, its images
     and exposure parameters are constants of the plan (``plan.refresh_inputs()`` after changing them).
-    ``warmup`` plan iterations run eagerly (real updates) before the capture; ``capacity_ok()`` must be polled by the
-    caller now and then: the tile-list capacity is baked into the graph."""
+    ``warmup`` plan iterations run eagerly (real updates) before the capture.  The tile-list capacity is baked into the graph
+    and the update is gated on the device by the render's overflow status: after an overflow every further ``step()``
+    applies NOTHING until ``capacity_ok()`` has been polled (it grows the lists; the next step re-captures) - poll it after
+    every step, or after every short run of steps and redo that run when it returns False (``step_checked()`` does both)."""
 
     def __init__(self, ba: BundleAdjuster, window: List[Frame], warmup: int = 0, regularize: bool = True,
                  decay_opacity: bool = True):
@@ -403,6 +405,17 @@ class GraphedBundleAdjuster:
         self.plan.step()
         self.ba.total_step += 1
         return self.total, self.photometric
+
+    def step_checked(self, max_attempts: int = 4):
+        """step() + the read-back of loss and overflow flag (the reference's loss.item(), backend.py:351), redone while the
+        tile lists overflow -> (total, photometric) as floats"""
+        for _ in range(max_attempts):
+            self.plan.step()
+            total, pm, ok = self.plan.finish_step()
+            if ok:
+                self.ba.total_step += 1
+                return total, pm
+        raise RuntimeError(f"BA iteration still overflows its tile lists after {max_attempts} attempts")
 
     def capacity_ok(self) -> bool:
         return self.plan.capacity_ok()

@@ -140,38 +140,51 @@ def _map_tensors(splats):
 
 
 _PLACEMENT: Dict[tuple, tuple] = {}
+_PLACEMENT_FAILS: Dict[tuple, int] = {}
+PLACEMENT_RETRIES = 3       # a failed probe is repeated by later plans this many times before the verdict sticks
 
 
 def placement_ok(dev, n_wgs: int, n_cus: int, lds_bytes: int = 25 * 1024):
     """Does workgroup i of an ``n_wgs``-workgroup launch (256 threads, the rasteriser's LDS footprint, all resident at once)
     share its compute unit with workgroups i + G, i + 2 G, ... on this device?  The CU-balanced launch order
     (csrc/tile_balance.h) deals the tiles into G groups on that assumption - an undocumented property of the dispatcher,
-    traced on MI355X / ROCm 7.2.  Probed ONCE per (device, shape) on a drained chip (gsx_probe_wg_placement,
-    ~50 us); on a mismatch the plans keep the identity / heaviest-first order and the reason is logged.  -> (ok, note)"""
+    traced on MI355X / ROCm 7.2.  Probed on a drained chip (gsx_probe_wg_placement, ~50 us).  A POSITIVE result
+    is cached per (device, shape).  A negative one is not trusted at once: the probe needs the chip to itself and
+    ``torch.cuda.synchronize`` drains it only for an instant - another host thread (the backend's BA stream) can enqueue work
+    before the probe's workgroups are placed - so the probe is repeated twice on the spot and, if it still fails, by the next
+    ``PLACEMENT_RETRIES`` plans that ask; only then does the identity / heaviest-first order stick (logged).  -> (ok, note)"""
     key = (str(dev), int(n_wgs), int(n_cus), int(lds_bytes))
     hit = _PLACEMENT.get(key)
     if hit is not None:
         return hit
     if torch.cuda.is_current_stream_capturing():
         return False, "placement probe skipped (stream is capturing)"
-    torch.cuda.synchronize(dev)
-    keys = torch.full((n_wgs,), -1, dtype=torch.int32, device=dev)
-    check(lib.gsx_probe_wg_placement(int(n_wgs), int(lds_bytes), 30, _p(keys), current_stream_ptr(dev)),
-          "gsx_probe_wg_placement")
-    k = keys.cpu()
-    first = k[:n_cus]
-    distinct = int(torch.unique(first).numel())
-    same = bool((k == first[torch.arange(n_wgs) % n_cus]).all())
-    if distinct == n_cus and same:
-        res = (True, f"cu-balanced (placement probe ok: {n_wgs} workgroups on {n_cus} compute units, i and i + {n_cus} "
-                     "share one)")
-    else:
-        bad = int((k != first[torch.arange(n_wgs) % n_cus]).sum())
+    idx = torch.arange(n_wgs) % n_cus
+    res = None
+    for _attempt in range(3):
+        torch.cuda.synchronize(dev)
+        keys = torch.full((n_wgs,), -1, dtype=torch.int32, device=dev)
+        check(lib.gsx_probe_wg_placement(int(n_wgs), int(lds_bytes), 30, _p(keys), current_stream_ptr(dev)),
+              "gsx_probe_wg_placement")
+        k = keys.cpu()
+        first = k[:n_cus]
+        distinct = int(torch.unique(first).numel())
+        if distinct == n_cus and bool((k == first[idx]).all()):
+            res = (True, f"cu-balanced (placement probe ok: {n_wgs} workgroups on {n_cus} compute units, i and i + {n_cus} "
+                         "share one)")
+            break
+        bad = int((k != first[idx]).sum())
         res = (False, f"identity order (placement probe FAILED: {distinct} distinct compute units among the first {n_cus} "
                       f"workgroups, {bad} of {n_wgs} workgroups off the i mod {n_cus} pattern)")
+    if res[0]:
+        _PLACEMENT[key] = res
+        return res
+    fails = _PLACEMENT_FAILS.get(key, 0) + 1
+    _PLACEMENT_FAILS[key] = fails
+    if fails > PLACEMENT_RETRIES:
+        _PLACEMENT[key] = res
         import warnings
         warnings.warn("gslam_amd: " + res[1])
-    _PLACEMENT[key] = res
     return res
 
 
@@ -1135,8 +1148,9 @@ class MappingStep:
         check(lib.gsx_loss_finish(_p(self.map_ws), Cl, H, W, _p(self.ssim_ws) if n_ssim else None, n_ssim, _p(iso_ws),
                                   n_iso, c0, c1, w_ssim if n_ssim else 0.0, 0.0, None, _p(self.g_exposure),
                                   _p(self.out2), st), "gsx_loss_finish")
-        # this rank's share of the overflow flag: 1.0 if the render above truncated a tile list (sticky status bit 1)
-        check(lib.gsx_status_flag(_p(r.status), 1, 1, _p(self.overflow), st), "gsx_status_flag")
+        # this rank's share of the overflow flag: 1.0 if the render above truncated a tile list (sticky status bit 1), 1024.0 if
+        # its tile counts were clamped as corrupt (bit 2): either gates the update on every rank (finish_step tells them apart)
+        check(lib.gsx_status_flag(_p(r.status), 1, 3, _p(self.overflow), st), "gsx_status_flag")
 
     def reduce(self):
         """the gradient exchange of an iteration (eager, on torch's current stream, between the two graphs): all-reduce of the
@@ -1203,7 +1217,13 @@ class MappingStep:
 
     def step(self, graphed: bool = True):
         """one iteration on torch's current stream; returns (total, photometric) as views of the bucket's loss slots -
-        device values, valid once the stream has run (multi-rank: window-wide sums after the reduction)"""
+        device values, valid once the stream has run (multi-rank: window-wide sums after the reduction).
+
+        CONTRACT: the update is gated ON THE DEVICE by the sticky overflow status of the render: once a tile
+        list of this plan has overflowed, every further step() computes gradients and applies NOTHING until the host has
+        settled it.  So follow every step() - or every short run of them - with ``finish_step()`` (one read-back of loss and
+        flag, grows the lists, tells the caller to redo) or at least ``capacity_ok()``; the host-side step counters assume
+        the update happened and are corrected by ``finish_step()`` / ``capacity_ok()`` when it did not."""
         if graphed and (not self.graph.captured or (self.r is not None and self.r.stale)):
             self.prepare()
         st = current_stream_ptr(self.dev)
@@ -1263,7 +1283,9 @@ class MappingStep:
                                     float(self.conf.opacity_decay), current_stream_ptr(self.dev)), "gsx_opacity_decay")
 
     def capacity_ok(self) -> bool:
-        """LOCAL check of this rank's sticky overflow status (grows the lists and marks the plan stale on overflow)"""
+        """LOCAL check of this rank's sticky overflow status (grows the lists and marks the plan stale on overflow).  For
+        callers that poll instead of calling finish_step() after every step(): on False, the steps since the overflow
+        applied no update (device gate) - how many is not known to the host, the caller redoes its iterations."""
         return True if self.r is None else self.r.check_capacity()
 
     def finish_step(self):
@@ -1274,9 +1296,15 @@ class MappingStep:
         the caller redoes the iteration - on all ranks, or the collectives go out of step."""
         total, pm, flag, _ = self.out4.tolist()
         if flag > 0.0:
-            self.capacity_ok()
-            # host bookkeeping of the skipped update
+            # host bookkeeping of the skipped update (step() counted it)
             self.adam.note_steps(-1)
+            self.steps -= 1
+            self.capacity_ok()          # grows this rank's lists on overflow; RAISES on the rank whose tile counts are corrupt
+            if flag >= 1024.0:
+                # some OTHER rank built its lists from corrupt counts (it has raised above): no rank may go on - a redo would
+                # leave the collectives of the surviving ranks waiting for it
+                raise RuntimeError("corrupt tile counts in a render plan of another rank (overflow flag "
+                                   f"{flag:g}): the iteration applied no update; aborting on every rank")
             return total, pm, False
         return total, pm, True
 

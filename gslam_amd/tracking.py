@@ -168,9 +168,16 @@ class GraphedTracker:
     def load(self, frame: Frame, prev_exposure: Optional[torch.Tensor] = None):
         exposure = frame.exposure_params if prev_exposure is None else prev_exposure
         pose = frame.pose
-        if all(hasattr(pose, k) for k in ("Rt", "dR", "dt")) and pose.Rt.is_cuda and frame.img.is_contiguous():
+        dev = self.plan.dev
+
+        def raw_ok(t, shape=None):              # what the row kernels read through a raw pointer
+            return (torch.is_tensor(t) and t.device == dev and t.dtype == torch.float32 and t.is_contiguous()
+                    and (shape is None or tuple(t.shape) == shape))
+
+        if (all(hasattr(pose, k) for k in ("Rt", "dR", "dt")) and raw_ok(pose.Rt, (4, 4)) and raw_ok(pose.dR)
+                and raw_ok(pose.dt) and raw_ok(frame.img, tuple(self.img.shape[-3:])) and raw_ok(exposure)):
             self.plan.load_frame(pose, frame.img, exposure)         # three launches, no torch PoseZhou forward
-        else:
+        else:                                                       # anything else is converted by copy_ (dtype, layout, device)
             self.plan.load(frame.pose().detach(), frame.img, exposure.detach())
 
     def capture(self):

@@ -372,7 +372,9 @@ int gsx_adam_multi_steps(int n_tensors, float *const *params, const float *const
 int gsx_counters_add(int n, int64_t *const *counters, int64_t delta, void *stream);
 /* The update behind a DEVICE-SIDE GATE: gsx_adam_multi_steps_decay / gsx_counters_add that do nothing when
  * skip_if_positive[0] > 0 (nullable: no gate).  The mapping plans set that float from the sticky overflow status of the
- * iteration's render (gsx_status_flag: flag = any(status[i] & mask) ? 1 : 0) - summed over ranks by the iteration's one
+ * iteration's render (gsx_status_flag: flag = (any(status[i] & mask & ~2) ? 1 : 0) + (any(status[i] & mask & 2) ? 1024 : 0):
+ * status bit 2 - clamped, corrupt tile counts - weighs 1024, so the sum over <= 1023 ranks still tells it from a plain
+ * overflow) - summed over ranks by the iteration's one
  * all-reduce - so an iteration whose tile lists were truncated on ANY rank applies no update on EVERY rank (no roll-back
  * needed, the replicas stay identical); the host reads the flag with the loss value it reads anyway (the reference's
  * loss.item(), gslam/backend.py:351), grows the lists and redoes the iteration. */

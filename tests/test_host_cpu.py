@@ -266,3 +266,31 @@ def test_step_bucket_layout_partitions_the_map_for_every_world_size():
                     # the slice of the flat buffer IS the slice of the tensor's view
                     assert b.views[k].reshape(-1)[a:a + ln].data_ptr() == b.flat[r * L + c_off:].data_ptr()
             assert all(bool((c == 1).all()) for c in cover), (n, world)
+
+
+def test_bench_gpus_n_starts_its_own_ranks_as_a_child(monkeypatch):
+    """`python bench.py --gpus N` run plainly (no launcher) must start N ranks under torch.distributed.run itself - as a child
+    process, before anything touches the GPU - and hand the child's exit code on."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("GPU touched before the launch")))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
