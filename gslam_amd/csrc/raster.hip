@@ -331,8 +331,34 @@ struct WgTrace {
     }
 };
 #define GSX_WG_TRACE_SCOPE(w) WgTrace _wg_trace(w);
+// Phase attribution inside the fused tracking kernel (tools/dbg/phase_trace.py): GSX_PT(k) books the shader cycles since the
+// previous stamp of this wavefront under category k; 16 counters per wavefront.
+__device__ unsigned long long *g_phase_trace = nullptr;
+struct PhaseTrace {
+    unsigned long long last, acc[16];
+    __device__ PhaseTrace() : last(__builtin_amdgcn_s_memtime()) {
+        for (int k = 0; k < 16; ++k) acc[k] = 0;
+    }
+    __device__ __forceinline__ void stamp(int k) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        acc[k] += now - last;
+        last = now;
+    }
+    __device__ ~PhaseTrace() {
+        if (g_phase_trace && (threadIdx.x & 63) == 0) {
+            const size_t i = ((size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 16;
+            for (int k = 0; k < 16; ++k) g_phase_trace[i + k] = acc[k];
+        }
+    }
+};
+#define GSX_PT_SCOPE PhaseTrace _pt;
+#define GSX_PT(k) _pt.stamp(k);
+#define GSX_PT_COUNT(k, n) _pt.acc[k] += (unsigned long long)(n);
 #else
 #define GSX_WG_TRACE_SCOPE(w)
+#define GSX_PT_SCOPE
+#define GSX_PT(k)
+#define GSX_PT_COUNT(k, n)
 #endif
 #include "raster_v4.inc"
 
@@ -494,6 +520,9 @@ extern "C" int gsx_tile_balance(const int32_t *tile_work, int64_t T, float chunk
 }
 
 #ifdef GSX_WG_TRACE
+extern "C" int gsx_debug_phase_trace(void *buffer) {           // diagnostic build only; not part of include/gsx.h
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_trace), &buffer, sizeof(buffer)) == hipSuccess ? 0 : 1;
+}
 extern "C" int gsx_debug_wg_trace(int which, void *buffer) {   // diagnostic build only; not part of include/gsx.h
     return hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace), &buffer, sizeof(buffer), (size_t)(which & 1) * sizeof(buffer)) ==
                    hipSuccess ? 0 : 1;
