@@ -85,7 +85,8 @@ class StageTimer:
     """Times every C-ABI launch with HIP events on the stream the kernels are launched on (torch's current stream: the
     instrumented passes issue their plans' launches there)."""
     STAGES = ("gsx_pose_zhou_fwd", "gsx_project_fwd", "gsx_isect_bin_sort", "gsx_front_fwd", "gsx_front_pose_bwd",
-              "gsx_raster_fwd", "gsx_raster_fwd_track_loss", "gsx_raster_track_fused", "gsx_ssim_fwd",
+              "gsx_raster_fwd", "gsx_raster_fwd_track_loss", "gsx_raster_track_fused", "gsx_raster_track_fused_sorting",
+              "gsx_ssim_fwd",
               "gsx_ssim_bwd", "gsx_map_loss", "gsx_raster_bwd", "gsx_project_bwd", "gsx_pose_zhou_bwd_partials",
               "gsx_isotropic_loss_acc", "gsx_loss_finish", "gsx_counters_add", "gsx_adam_multi_steps",
               "gsx_adam_multi_steps_decay", "gsx_track_opt_tail")
@@ -160,7 +161,8 @@ def in_graph_launch_us(plan, stage, resets, n_closures, frames=3):
     from gslam_amd.plan import HipGraph
     lib = _lib.lib
     fn = getattr(lib, stage)
-    scratch = torch.zeros_like(plan.r.v_rec) if stage in ("gsx_raster_bwd", "gsx_raster_track_fused") else None
+    scratch = torch.zeros_like(plan.r.v_rec) if stage in ("gsx_raster_bwd", "gsx_raster_track_fused",
+                                                          "gsx_raster_track_fused_sorting") else None
     torch.cuda.synchronize()
 
     def twice(*a):
@@ -221,6 +223,9 @@ def algorithmic_bytes(N, C, M, P, CH, T):
         # per-intersection gather (id + record) is counted ONCE ("every array touched once": the backward re-reads it from
         # the caches of the CU that ran the tile's forward)
         "gsx_raster_track_fused": M * (28 + 4 * CH) + P * 12 + C * N * 4 + C * N * (24 + 4 * CH),
+        # the same launch with the tile sort inside (the front stopped after the placement): every tile's 8-byte keys are read
+        # once more; the ids / sorted keys it writes for the part it sorts (a quarter of M) are not counted
+        "gsx_raster_track_fused_sorting": M * (28 + 4 * CH) + P * 12 + C * N * 4 + C * N * (24 + 4 * CH) + M * 8,
         "gsx_project_bwd": C * N * (40 + 28 + 24) + N * 40 + C * 64,
         "gsx_ssim_fwd": 72 * P,
         "gsx_ssim_bwd": 72 * P,
@@ -237,18 +242,23 @@ def render_bytes(N, C, M, P, CH, T):
 
 
 def traffic_for(kernel_hint, N):
-    """(HBM bytes per launch, limiter record) of the dominant kernel from the committed counter passes
-    (profiles/traffic_r03.json, written by tools/distill_profiles.py from separate --pmc runs), or (None, None)"""
-    for name in ("traffic_r03.json", "traffic_r02.json"):
+    """(HBM bytes per launch, limiter record, trace record) of the dominant kernel from the committed profile of the latest
+    round (profiles/traffic_rNN.json, written by tools/distill_profiles.py from rocprofv3 --kernel-trace --stats of this
+    bench and from separate --pmc passes), or (None, None, None)"""
+    for name in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
                 tj = json.load(open(path))
                 if tj.get("workload_gaussians") == N and tj.get("stage") == kernel_hint:
-                    return tj.get("hbm_bytes_per_launch"), tj.get("limiter")
+                    trace = None
+                    if tj.get("trace_avg_launch_us"):
+                        trace = {"avg_launch_us": tj["trace_avg_launch_us"], "calls": tj.get("trace_calls"),
+                                 "source": tj.get("trace_source")}
+                    return tj.get("hbm_bytes_per_launch"), tj.get("limiter"), trace
             except Exception:
                 pass
-    return None, None
+    return None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -462,9 +472,15 @@ def run_headline(args, dev):
         M1 = int(sum(Ms) / len(Ms))
         algo = algorithmic_bytes(N, 1, M1, P, 4, T)
         achieved = algo[dom] / (dom_us * 1e-6) / 1e9
-        traffic, limiter = traffic_for(dom, N)
+        traffic, limiter, trace = traffic_for(dom, N)
         line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                            # the same kernel's average in the committed rocprofv3 trace of this bench (profiles/), and the
+                            # fraction that follows from it: the live figure above comes from this run's own HIP events
+                            "avg_launch_us_trace": None if not trace else trace["avg_launch_us"],
+                            "frac_trace": None if not trace else round(
+                                algo[dom] / (trace["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                            "trace_source": None if not trace else trace["source"],
                             # counted HBM traffic / measured time / peak: what the memory system actually carries - the
                             # contract's "bound: hbm" is the path's label, `limiter` says what bounds THIS kernel
                             "counter_frac": None if not traffic else round(traffic / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
@@ -822,6 +838,11 @@ def cpu_baseline_tracking(N, W, H, budget_s=25.0):
     from oracle.oracle import Oracle
     from gslam_amd.synthetic import make_cameras, make_scene
     o = Oracle(np.float32, threads=True)
+    all_threads = o.threads
+    try:
+        torch.set_num_threads(1)                              # torch's own pools stay out of the way of the OpenMP team
+    except Exception:
+        pass
     viewmats, Ks = make_cameras(1, W, H)
     viewmats, Ks = viewmats.numpy(), Ks.numpy()
 
@@ -830,15 +851,19 @@ def cpu_baseline_tracking(N, W, H, budget_s=25.0):
                                      W, H, render_mode="RGB", log_uncertainties=sc["log_uncertainties"],
                                      backgrounds=np.zeros((1, 3), np.float32))
 
-    # (i) configs[0]
+    # (i) configs[0]: 10 k Gaussians do not feed every core of the host (with 128 threads the same code read 4.4, 35, 56 and
+    # 89 ms on four boxes: fork / join and false sharing, not work) - a team of <= 16 threads, stated in the line
+    small_team = o.set_threads(min(16, all_threads))
     sc10 = {k: v.numpy() for k, v in make_scene(10_000, 0).items()}
-    forward(sc10)
+    for _ in range(3):
+        forward(sc10)
     t10 = []
-    for _ in range(7):
+    for _ in range(15):
         t0 = time.perf_counter()
         forward(sc10)
         t10.append(time.perf_counter() - t0)
     t10.sort()
+    o.set_threads(all_threads)
     # (ii) the headline's closure
     sc = {k: v.numpy() for k, v in make_scene(N, 0).items()}
     gt = np.random.default_rng(1).uniform(0, 1, (1, H, W, 3)).astype(np.float32)
@@ -866,11 +891,12 @@ def cpu_baseline_tracking(N, W, H, budget_s=25.0):
     per_frame = (N_ADAM + MAX_EVAL + 1) * t_c + t_c + (BA_ITERS * WINDOW / KF_EVERY) * t_c
     return {"value": round(1.0 / per_frame, 5), "unit": "frames/s", "cores": o.threads, "kind": "port",
             "cpu_model": cpu_model(),
-            "config0_10k_forward_ms": round(t10[len(t10) // 2] * 1e3, 2),
+            "config0_10k_forward_ms": round(t10[len(t10) // 2] * 1e3, 2), "config0_threads": small_team,
+            "config0_spread_ms": [round(t10[0] * 1e3, 2), round(t10[-1] * 1e3, 2)],
             "closure_500k_s": round(t_c, 4),
             "sample": f"oracle/gsx_oracle.c built with OpenMP on {o.threads} host threads ({cpu_model()}): (i) BASELINE.json "
-                      f"configs[0], 10 k Gaussians, one {W}x{H} frame, forward only: median of {len(t10)} runs after 1 warm-up "
-                      f"= {t10[len(t10) // 2] * 1e3:.1f} ms; (ii) {len(times)} tracking closures (render fwd + bwd to the pose, "
+                      f"configs[0], 10 k Gaussians, one {W}x{H} frame, forward only, {small_team} threads: median of {len(t10)} runs "
+                      f"after 3 warm-ups = {t10[len(t10) // 2] * 1e3:.1f} ms; (ii) {len(times)} tracking closures (render fwd + bwd to the pose, "
                       f"{N} Gaussians, {W}x{H}, C=1), median {t_c:.3f} s/closure; frames/s = 1 / ((36 + 1 + "
                       f"{BA_ITERS}*{WINDOW}/{KF_EVERY}) closures x that), a BA camera counted as one closure (lower bound)"}
 

@@ -1801,10 +1801,19 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
                        a.recs, a.n_inst, L.R, FRONT_THREADS * L.items, (int)C, tile_w, tile_h, stripes, rps, M_cap,
                        col_out, tile_order ? 1 : 0, a.cnt, offsets, M_dev, status, entries, compact);
     GSX_CHECK_LAUNCH();
+    if (flags & GSX_PROJ_DEFER_SORT) return GSX_OK;     // the consumer sorts each tile's keys itself (gsx_raster_track_fused_sorting)
     const uint32_t id_max = compact ? (uint32_t)(C * (int64_t)L.R * FRONT_THREADS * L.items - 1) : (uint32_t)(C * N - 1);
     hipLaunchKernelGGL(tile_sort_count_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, scratch, offsets,
                        (int)n_tiles, bit_length((uint32_t)n_tiles), M_cap, id_max, (int64_t *)nullptr, flatten_ids);
     GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_front_keys(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int flags, int64_t *out3) {
+    GSX_CHECK_ARG(out3 && N >= 1 && C >= 1 && M_cap >= 1);
+    const FrontLayout L = front_layout(N, C, tile_w, tile_h, M_cap);
+    out3[0] = L.entries_off; out3[1] = L.scratch_off;
+    out3[2] = (flags & GSX_PROJ_COMPACT) ? (C * (int64_t)L.R * FRONT_THREADS * L.items - 1) : (C * N - 1);   // largest valid id
     return GSX_OK;
 }
 

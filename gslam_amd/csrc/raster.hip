@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "gsx_common.h"
+#include "tile_sort_lds.h"
 
 
 namespace {
@@ -433,8 +434,35 @@ extern "C" int gsx_raster_track_fused(const float *rec, const float *backgrounds
     TrackLossArgs la;
     la.gt = gt; la.exposure = exposure; la.w_photo = w_photo; la.v_render = v_render; la.rows = loss_rows;
     la.tile_work = tile_work;
-    hipLaunchKernelGGL((raster_track_fused_kernel<12>), dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, rec, backgrounds,
-                       offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas, last_ids, v_rec, tile_order, la);
+    hipLaunchKernelGGL((raster_track_fused_kernel<12, false>), dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, rec,
+                       backgrounds, offsets, const_cast<int32_t *>(flatten_ids), M, offsets_has_end, W, H, tile_w, tile_h, alphas,
+                       last_ids, v_rec, tile_order, la, TileSortArgs{});
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
+extern "C" int gsx_raster_track_fused_sorting(const float *rec, const float *backgrounds, const int32_t *offsets,
+                                              int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
+                                              const float *gt, const float *exposure, float w_photo, float *alphas,
+                                              int32_t *last_ids, float *v_render, float *loss_rows, float *v_rec,
+                                              const int32_t *tile_order, int32_t *tile_work, uint64_t *keys,
+                                              uint64_t *keys_sorted, uint32_t id_max, uint32_t *tile_cut, float cut_margin,
+                                              int32_t *tile_near, int32_t *sort_stats, void *stream) {
+    GSX_CHECK_ARG(offsets && gt && exposure && loss_rows && v_rec && C >= 1 && W > 0 && H > 0);
+    GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31) && (M == 0 || (rec && flatten_ids && keys && keys_sorted)));
+    GSX_CHECK_ARG(tile_cut && cut_margin >= 0.f && cut_margin < 16.f && offsets_has_end == 1);
+    const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
+    const int64_t T = C * tile_w * tile_h;
+    GSX_CHECK_ARG(T < ((int64_t)1 << 31));
+    TrackLossArgs la;
+    la.gt = gt; la.exposure = exposure; la.w_photo = w_photo; la.v_render = v_render; la.rows = loss_rows;
+    la.tile_work = tile_work;
+    TileSortArgs ts;
+    ts.keys = (unsigned long long *)keys; ts.sorted = (unsigned long long *)keys_sorted; ts.tile_cut = tile_cut;
+    ts.tile_near = tile_near; ts.stats = sort_stats; ts.id_max = id_max; ts.margin = cut_margin;
+    hipLaunchKernelGGL((raster_track_fused_kernel<12, true>), dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, rec,
+                       backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas, last_ids, v_rec,
+                       tile_order, la, ts);
     GSX_CHECK_LAUNCH();
     return GSX_OK;
 }

@@ -1,0 +1,288 @@
+// tile_sort_lds.h - depth sort of ONE tile's intersection keys by the 256-thread workgroup that rasterises the tile
+// (device code for raster.hip; the stand-alone launch of the same sort is tile_sort_count_kernel in isect_bin.hip).
+//
+// Why it lives inside the rasteriser (round 4).  In a pose-only closure only the front of a tile's list is
+// ever composited - ~240 of ~1100 entries at 500 k Gaussians before every pixel of the tile has saturated - yet the sort
+// launch between the placement and the rasteriser sorted all of them and cost 15 us of a chain on which every launch is
+// latency-bound.  Here the tile's workgroup sorts only the keys up to a depth CUT-OFF - the depth of the deepest entry the
+// previous closure of the same tile composited, with a margin - in LDS, right before it composites them; the keys behind the
+// cut-off stay as the placement left them.  Depth order is a total order on (depth bits, id) keys, and "depth <= cut" is a
+// prefix of it: the sorted near keys ARE the first n_near entries of the fully sorted list, bit for bit.  If a pixel of the
+// tile is still live when the near list ends (the cut-off was too tight: the pose moved, a surface left the tile), the
+// workgroup sorts the next slab of depths behind it the same way and continues, slab after slab - each slab is the next stretch
+// of the list the stand-alone sort would have produced.  Nothing is ever sorted through memory on the way: a tile that needed
+// a second slab costs one more LDS sort, not a merge sort of its whole segment (the first version did that: the 3 % of the
+// tiles whose cut-off had been too tight became the critical path of the whole launch, 104 us against 71).
+//
+// Keys: float_bits(depth) << 32 | id with depth > 0, so unsigned order of the high word = depth order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gsx_tsort {
+constexpr int THREADS = 256;
+constexpr int CAPK = 1152;                 // keys the LDS counting sort takes (18 runs of 64)
+constexpr int NB = 512;                    // depth buckets of the counting sort
+constexpr int MAX_BUCKET = 96;             // largest bucket the quadratic in-bucket ranking accepts
+constexpr int MERGE_CAP = 1024;            // LDS window of the generic path (chunks sorted in LDS, merged through memory)
+constexpr int POOL_BYTES = 2 * CAPK * 8 + NB * 4;    // 20480: two key buffers + the bucket cursors
+constexpr int CTL_WORDS = 16;              // small control block in LDS
+constexpr uint32_t CUT_NONE = 0x7f800000u; // +inf: no cut-off, sort everything
+
+typedef unsigned long long u64;
+
+// one rank-merge level: runs of length `run` in src[0..n) -> runs of 2 * run in dst (stable; LDS or global pointers)
+template <typename Ptr>
+__device__ __forceinline__ void merge_level(Ptr src, Ptr dst, int n, int run) {
+    for (int i = threadIdx.x; i < n; i += THREADS) {
+        const u64 k = src[i];
+        const int r = i / run;
+        const int own = r * run, pair = (r & ~1) * run;
+        const int pb = (r ^ 1) * run;                          // partner run
+        const int plen = max(0, min(run, n - pb));
+        const bool right = (r & 1) != 0;
+        int lo = 0, hi = plen;                                  // left run: #partner < k ; right run: #partner <= k
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const u64 v = src[pb + mid];
+            const bool before = right ? (v <= k) : (v < k);
+            if (before) lo = mid + 1; else hi = mid;
+        }
+        dst[pair + (i - own) + lo] = k;
+    }
+}
+
+// rank-merge sort of n <= cap keys already in bufA (padding to a multiple of 64 written here); returns the buffer that holds
+// the sorted keys.  Runs of 64 by counting ranks, then log2(n / 64) merge levels (one barrier each).
+__device__ __forceinline__ u64 *lds_rank_sort(u64 *bufA, u64 *bufB, int n) {
+    const u64 INF = ~0ull >> 1;
+    const int n_pad = (n + 63) / 64 * 64;
+    for (int i = n + threadIdx.x; i < n_pad; i += THREADS) bufA[i] = INF;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += THREADS) {
+        const u64 k = bufA[i];
+        const int cb = i & ~63;
+        unsigned int rank = 0;
+#pragma unroll 8
+        for (int m = 0; m < 64; ++m) rank += (unsigned int)((bufA[cb + m] - k) >> 63);
+        bufB[cb + rank] = k;
+    }
+    __syncthreads();
+    u64 *src = bufB, *dst = bufA;
+    for (int run = 64; run < n; run <<= 1) {
+        merge_level(src, dst, n, run);
+        __syncthreads();
+        u64 *t = src; src = dst; dst = t;
+    }
+    return src;
+}
+
+// exclusive scan of s_cur[0..NB) in place; returns true if some bucket holds more than `limit` keys.  s_w: 8 ints of LDS.
+__device__ __forceinline__ bool bucket_scan(int *s_cur, int *s_w, int limit) {
+    constexpr int PER = NB / THREADS;
+    const int t = threadIdx.x;
+    int cnt[PER];
+    int v = 0, big = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { cnt[j] = s_cur[PER * t + j]; v += cnt[j]; big = max(big, cnt[j]); }
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(incl, off, 64);
+        if ((t & 63) >= off) incl += u;
+    }
+    if ((t & 63) == 63) s_w[t >> 6] = incl;
+    const int any_big = __syncthreads_or(big > limit);
+    int run = incl - v;
+    for (int w = 0; w < (t >> 6); ++w) run += s_w[w];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { s_cur[PER * t + j] = run; run += cnt[j]; }
+    __syncthreads();
+    return any_big != 0;
+}
+
+// Sorts the keys of keys[0..n) whose depth bits lie in (lo_bits, hi_bits] in LDS - the next SLAB of the tile's list behind the
+// entries sorted so far - and writes their ids to flat[0..m) and the sorted keys to sorted[0..m) (the caller passes the
+// pointers advanced to where the slab goes).  If more than CAPK keys fall into the window, the window is cut down to its
+// nearest buckets of a monotone depth histogram that hold at most CAPK keys (two more passes over the segment, which sits
+// in L2): the slab is then (lo_bits, hi'] with hi' = the largest depth it took - returned in s_ctl[3], the lower bound of
+// the NEXT slab.  Returns m >= 0, or -1 if even one bucket of the histogram holds more than CAPK keys (a pile of equal
+// depths: nothing written, take sort_all).  Every thread of the workgroup must call it; `pool` = POOL_BYTES of LDS nobody
+// else uses meanwhile, s_ctl = CTL_WORDS ints.
+__device__ __forceinline__ int sort_window(const u64 *__restrict__ keys, u64 *__restrict__ sorted, int32_t *__restrict__ flat,
+                                           int n, uint32_t lo_bits, uint32_t hi_bits, uint32_t id_max, void *pool,
+                                           int *s_ctl) {
+    u64 *s_a = reinterpret_cast<u64 *>(pool), *s_b = s_a + CAPK;
+    int *s_cur = reinterpret_cast<int *>(s_b + CAPK);
+    const int t = threadIdx.x;
+    __syncthreads();                                           // the pool may still be in use as something else
+    if (t == 0) { s_ctl[0] = 0; s_ctl[1] = 0x7fffffff; s_ctl[2] = 0; s_ctl[3] = (int)hi_bits; }
+    for (int i = t; i < NB; i += THREADS) s_cur[i] = 0;
+    __syncthreads();
+    // a. the keys of the window, compacted into LDS in any order; range of their depths
+    auto filter = [&](uint32_t hi, bool store) {
+        unsigned int dmin = 0x7fffffffu, dmax = 0u;
+        for (int i0 = 0; i0 < n; i0 += 4 * THREADS) {          // four loads in flight per thread
+            u64 kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * THREADS + t;
+                kk[u] = (i < n) ? keys[i] : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned int d = (unsigned int)(kk[u] >> 32);
+                if (d > lo_bits && d <= hi) {                  // (the padding's high word is 0xffffffff: never passes)
+                    if (store) {
+                        const int p = atomicAdd(&s_ctl[0], 1);
+                        if (p < CAPK) s_a[p] = kk[u];
+                    }
+                    dmin = min(dmin, d); dmax = max(dmax, d);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            dmin = min(dmin, (unsigned int)__shfl_xor((int)dmin, off, 64));
+            dmax = max(dmax, (unsigned int)__shfl_xor((int)dmax, off, 64));
+        }
+        if ((t & 63) == 0) { atomicMin(&s_ctl[1], (int)dmin); atomicMax(&s_ctl[2], (int)dmax); }
+    };
+    filter(hi_bits, true);
+    __syncthreads();
+    int m = s_ctl[0];
+    if (m == 0) return 0;
+    float fmin_ = __uint_as_float((unsigned int)s_ctl[1]), fmax_ = __uint_as_float((unsigned int)s_ctl[2]);
+    float range = fmax_ - fmin_;
+    float scale = (range > 0.0f) ? (float)(NB - 1) / range : 0.0f;
+    auto bucket_of_d = [&](unsigned int dbits) -> int {
+        const int b = (int)((__uint_as_float(dbits) - fmin_) * scale);
+        return min(max(b, 0), NB - 1);
+    };
+    if (m > CAPK) {
+        // a'. too many: histogram of the window's keys straight from memory, the nearest buckets that fit, and their largest depth
+        for (int i0 = 0; i0 < n; i0 += 4 * THREADS) {
+            u64 kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * THREADS + t;
+                kk[u] = (i < n) ? keys[i] : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned int d = (unsigned int)(kk[u] >> 32);
+                if (d > lo_bits && d <= hi_bits) atomicAdd(&s_cur[bucket_of_d(d)], 1);
+            }
+        }
+        __syncthreads();
+        bucket_scan(s_cur, s_ctl + 4, CAPK);                   // exclusive: s_cur[b] = keys in the buckets before b
+        if (t == 0) { s_ctl[8] = -1; }
+        __syncthreads();
+        // the last bucket b with (keys before b) + (keys in b) <= CAPK: exclusive prefix of b + 1 (or m for the last bucket)
+        for (int b = t; b < NB; b += THREADS) {
+            const int upto = (b + 1 < NB) ? s_cur[b + 1] : m;
+            if (upto <= CAPK) atomicMax(&s_ctl[8], b);
+        }
+        __syncthreads();
+        const int bstar = s_ctl[8];
+        if (bstar < 0) return -1;                              // the nearest bucket alone does not fit: equal depths piled up
+        __syncthreads();
+        if (t == 0) { s_ctl[0] = 0; s_ctl[9] = 0; }
+        for (int i = t; i < NB; i += THREADS) s_cur[i] = 0;
+        __syncthreads();
+        // the slab = the window's keys in buckets <= bstar; its largest depth is the exact threshold that describes it
+        unsigned int hmax = 0u;
+        for (int i0 = 0; i0 < n; i0 += 4 * THREADS) {
+            u64 kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * THREADS + t;
+                kk[u] = (i < n) ? keys[i] : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned int d = (unsigned int)(kk[u] >> 32);
+                if (d > lo_bits && d <= hi_bits && bucket_of_d(d) <= bstar) {
+                    const int p = atomicAdd(&s_ctl[0], 1);
+                    if (p < CAPK) s_a[p] = kk[u];
+                    hmax = max(hmax, d);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) hmax = max(hmax, (unsigned int)__shfl_xor((int)hmax, off, 64));
+        if ((t & 63) == 0) atomicMax(&s_ctl[9], (int)hmax);
+        __syncthreads();
+        m = s_ctl[0];                                          // <= CAPK by construction
+        if (m == 0) return -1;
+        if (t == 0) { s_ctl[2] = s_ctl[9]; s_ctl[3] = s_ctl[9]; }
+        __syncthreads();
+        fmax_ = __uint_as_float((unsigned int)s_ctl[2]);
+        range = fmax_ - fmin_;
+        scale = (range > 0.0f) ? (float)(NB - 1) / range : 0.0f;
+    }
+    auto bucket_of = [&](u64 k) -> int { return bucket_of_d((unsigned int)(k >> 32)); };
+    // b. histogram, scan, scatter by bucket, exact rank inside the bucket
+    for (int i = t; i < m; i += THREADS) atomicAdd(&s_cur[bucket_of(s_a[i])], 1);
+    __syncthreads();
+    const bool degenerate = bucket_scan(s_cur, s_ctl + 4, MAX_BUCKET);
+    const u64 *res;
+    if (degenerate) {
+        res = lds_rank_sort(s_a, s_b, m);
+    } else {
+        for (int i = t; i < m; i += THREADS) {
+            const u64 k = s_a[i];
+            s_b[atomicAdd(&s_cur[bucket_of(k)], 1)] = k;
+        }
+        __syncthreads();
+        for (int i = t; i < m; i += THREADS) {
+            const u64 k = s_b[i];
+            const int b = bucket_of(k);
+            const int bs = b ? s_cur[b - 1] : 0, be = s_cur[b];   // after the scatter a bucket's cursor is its end
+            int rank = 0;
+            for (int j = bs; j < be; ++j) rank += (s_b[j] < k) ? 1 : 0;
+            s_a[bs + rank] = k;
+        }
+        __syncthreads();
+        res = s_a;
+    }
+    // c. out: ids for the rasteriser, the sorted keys for the next cut-off
+    for (int i = t; i < m; i += THREADS) {
+        const u64 k = res[i];
+        flat[i] = (int32_t)min((uint32_t)k, id_max);            // never hand an out-of-range gather index on
+        sorted[i] = k;
+    }
+    __syncthreads();
+    return m;
+}
+
+// Sorts ALL n keys of the segment, any n: chunks of MERGE_CAP keys rank-sorted in LDS and written back in place, the remaining
+// merge levels through memory (L2), ping-ponging between the segment and `sorted`.  Ids to flat[0..n), keys to sorted[0..n).
+// The slow, rare path (a near list that does not fit LDS, or a tile whose cut-off failed with more than CAPK keys).
+__device__ __forceinline__ void sort_all(u64 *__restrict__ keys, u64 *__restrict__ sorted, int32_t *__restrict__ flat, int n,
+                                         uint32_t id_max, void *pool) {
+    u64 *s_a = reinterpret_cast<u64 *>(pool), *s_b = s_a + CAPK;
+    const int t = threadIdx.x;
+    __syncthreads();
+    for (int cb = 0; cb < n; cb += MERGE_CAP) {
+        const int len = min(MERGE_CAP, n - cb);
+        for (int i = t; i < len; i += THREADS) s_a[i] = keys[cb + i];
+        __syncthreads();
+        const u64 *res = lds_rank_sort(s_a, s_b, len);
+        for (int i = t; i < len; i += THREADS) keys[cb + i] = res[i];
+        __syncthreads();
+    }
+    u64 *src = keys, *dst = sorted;
+    for (int run = MERGE_CAP; run < n; run <<= 1) {
+        merge_level(src, dst, n, run);
+        __syncthreads();                                       // (global writes of the workgroup are visible to it behind the barrier)
+        u64 *x = src; src = dst; dst = x;
+    }
+    for (int i = t; i < n; i += THREADS) {
+        const u64 k = src[i];
+        flat[i] = (int32_t)min((uint32_t)k, id_max);
+        if (src != sorted) sorted[i] = k;
+    }
+    __syncthreads();
+}
+}  // namespace gsx_tsort

@@ -34,6 +34,7 @@ _RESET_V_REC = 64       # GSX_PROJ_RESET_V_REC
 _SKIP_CULLED = 16       # GSX_PROJ_SKIP_CULLED
 _COMPACT = 32           # GSX_PROJ_COMPACT
 _CANDIDATES = 128       # GSX_PROJ_CANDIDATES
+_DEFER_SORT = 256       # GSX_PROJ_DEFER_SORT
 
 
 def _arr(ptrs: Sequence[Optional[int]]):
@@ -290,6 +291,10 @@ class RenderPlan:
         # and at most five per CU) runs as long as its most loaded CU; enable_balance() makes the rasteriser launches follow
         # an order computed from the work the tiles took in an earlier closure
         self.tile_work = self.balanced_order = None
+        # tile sort inside the fused tracking rasteriser (gsx_raster_track_fused_sorting): enable_defer_sort()
+        self.defer_sort = False
+        self.cut_margin = self.CUT_MARGIN
+        self.tile_cut = self.tile_near = self.sort_stats = None
         self.balance_note = "identity / heaviest-first order (shape does not qualify for the balanced order)"
         self.n_cus = int(torch.cuda.get_device_properties(dev).multi_processor_count) if dev.type == 'cuda' else 0
         self.last_M = 0
@@ -479,11 +484,11 @@ class RenderPlan:
                                   self.tile_h, _p(m[3]), _p(m[4]), _p(m[5]), _p(self.rec), _p(self.vis_count),
                                   self._clear_ptr(), st), "gsx_project_fwd")
 
-    def _front(self, st: int):
+    def _front(self, st: int, defer_sort: bool = False):
         m = self.map
         lean = self.lean
         flags = self.flags | (_SKIP_CULLED if lean else 0) | (_COMPACT if self.compact else 0) | (
-            _CANDIDATES if self.candidates else 0)
+            _CANDIDATES if self.candidates else 0) | (_DEFER_SORT if defer_sort else 0)
         check(lib.gsx_front_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                 self.H, self.eps2d, self.near, self.far, flags,
                                 _p(m[3]), _p(m[4]), _p(m[5]), None if self.compact else _p(self.radii),
@@ -494,6 +499,30 @@ class RenderPlan:
                                 _p(self.M_dev), _p(self.status), _p(self.flat), _p(self.tile_order),
                                 _p(self.tile_work), _p(self.balanced_order), self.CHUNK_COST, self.LIGHT_RATE, self.n_cus,
                                 _p(self.isect_ws), self.isect_ws.numel(), st), "gsx_front_fwd")
+
+    CUT_MARGIN = 0.05       # next closure's depth cut-off of a tile = depth of its deepest composited entry * (1 + this)
+
+    def enable_defer_sort(self, margin: Optional[float] = None) -> bool:
+        """Pose-only plans on the fused front whose closure runs gsx_raster_track_fused: the front stops after the placement and
+        the rasteriser's tile workgroups sort what they composite (the keys up to the tile's depth cut-off of the previous
+        closure; the whole segment if a pixel outlives that) - one launch less on the closure's chain, identical lists.  After a
+        closure ``self.flat`` holds sorted ids only for the first ``self.tile_near[t]`` entries of tile t.
+        -> whether this plan's shape qualifies."""
+        if not (self.front and self.compact and self.CH == 4 and self.geom_only):
+            return False
+        if margin is not None:
+            self.cut_margin = float(margin)
+        if not self.defer_sort:
+            self.defer_sort = True
+            self.tile_cut = torch.full((self.T,), 0x7f800000, dtype=torch.int32, device=self.dev)     # +inf: no cut-off yet
+            self.tile_near = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
+            self.sort_stats = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        return True
+
+    def reset_cuts(self):
+        """forget the tiles' depth cut-offs (the next closure sorts every tile's whole segment)"""
+        if self.tile_cut is not None:
+            self.tile_cut.fill_(0x7f800000)
 
     CHUNK_COST = 3.0        # weight of a 64-entry chunk (gather + cull) in compositing trips (tools/dbg/wg_trace.py)
     LIGHT_RATE = 0.92       # a CU with 4 workgroups gets through 0.92 of the work of one with 5 in the same time (same trace)
@@ -525,6 +554,19 @@ class RenderPlan:
         """front + gsx_raster_track_fused: the forward rasteriser, the tracking loss and the geometry-only rasteriser backward
         of every tile in one launch (pose-only CH = 4 plans); follow with backward(st, rasterised=True)"""
         assert self.CH == 4 and self.geom_only and self.n_touched is None and self.capacity > 0
+        gt, exposure, w_photo, rows = track_loss
+        if self.front and self.defer_sort:
+            self._front(st, defer_sort=True)
+            lay = (C.c_int64 * 3)()
+            check(lib.gsx_front_keys(self.N, self.C, self.tile_w, self.tile_h, self.capacity,
+                                     _COMPACT if self.compact else 0, lay), "gsx_front_keys")
+            base = self.isect_ws.data_ptr()
+            check(lib.gsx_raster_track_fused_sorting(
+                _p(self.rec), _p(self.backgrounds), _p(self.offsets), _p(self.flat), self.capacity, 1, self.C, self.W, self.H,
+                _p(gt), _p(exposure), float(w_photo), None, None, None, _p(rows), _p(self.v_rec), _p(self.launch_order),
+                _p(self.tile_work), base + int(lay[0]), base + int(lay[1]), int(lay[2]), _p(self.tile_cut),
+                float(self.cut_margin), _p(self.tile_near), _p(self.sort_stats), st), "gsx_raster_track_fused_sorting")
+            return
         if self.front:
             self._front(st)
         else:
@@ -533,7 +575,6 @@ class RenderPlan:
                                          self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status),
                                          None, _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
                                          self.isect_ws.numel(), st), "gsx_isect_bin_sort")
-        gt, exposure, w_photo, rows = track_loss
         check(lib.gsx_raster_track_fused(_p(self.rec), _p(self.backgrounds), _p(self.offsets), _p(self.flat), self.capacity,
                                          1, self.C, self.W, self.H, _p(gt), _p(exposure), float(w_photo), None, None, None,
                                          _p(rows), _p(self.v_rec), _p(self.launch_order), _p(self.tile_work), st),
@@ -675,14 +716,16 @@ class TrackClosure:
     CAND_MARGINS = (0.02, 0.02)    # |R R0^T - I|_F (~0.8 degrees) and metres the closures of a frame may move from its first pose
 
     def __init__(self, splats, camera, tail: str = 'fused', fuse_raster: bool = True, front: Optional[bool] = None,
-                 candidates: bool = False):
+                 candidates: bool = False, defer_sort: Optional[bool] = None):
         """fuse_raster (fused tail only): forward rasteriser, loss and rasteriser backward as ONE launch
         (gsx_raster_track_fused); False keeps them as two (the independent path the tests compare against).
         candidates: per-frame candidate set for the closures' projection (gsx_front_candidates).  OFF by default - measured
         on the headline sequence: the 36 evaluation points of a frame spread over up to ~0.1 rad / 0.1 m (Adam's
         lr-sized steps, the line search's trial points); margins that cover them make the candidate set as large as what
         the per-closure cull keeps (334 k of 500 k at 0.06 / 0.06 against ~170 k visible), and tighter ones send most
-        closures to the full path.  Results are identical either way."""
+        closures to the full path.  Results are identical either way.
+        defer_sort: the tile sort moves into the fused rasteriser launch (RenderPlan.enable_defer_sort); None = where it
+        applies (fused tail + fused rasteriser + fused front)."""
         assert tail in ('fused', 'split', 'host')
         self.tail = tail
         self.fuse_raster = bool(fuse_raster) and tail == 'fused'
@@ -710,6 +753,8 @@ class TrackClosure:
         # ONCE per frame, with margins (gsx_front_candidates), and the closures read that candidate set
         if candidates:
             self.r.enable_candidates(*self.CAND_MARGINS)
+        if (defer_sort is None or defer_sort) and self.fuse_raster:
+            self.r.enable_defer_sort()
         self.stream = torch.cuda.Stream(device=dev)
         self.graph = HipGraph()
         self._chains: Dict[int, HipGraph] = {}

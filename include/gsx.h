@@ -59,6 +59,9 @@ extern "C" {
                                      so (depth, slot) sorts exactly like (depth, flatten id); record s of the front's workspace
                                      holds the flatten id of slot s.  radii / tiles_per_gauss become nullable. */
 #define GSX_PROJ_BETAS 4          /* gslam record: append beta=clamp(exp(log_unc),0.01) (rasterization.py:149,249-256) */
+#define GSX_PROJ_DEFER_SORT 256   /* gsx_front_fwd only: stop after the placement - every tile's segment of the key buffer holds its
+                                   * (depth bits << 32 | id) keys UNSORTED, flatten_ids is not written; the consumer
+                                   * (gsx_raster_track_fused_sorting) sorts what it composites.  gsx_front_keys tells where the keys are */
 #define GSX_PROJ_CANDIDATES 128   /* gsx_front_fwd / gsx_front_pose_bwd (with GSX_PROJ_COMPACT): the workspace carries the per-frame
                                      candidate set of gsx_front_candidates; closures whose poses stay within its margins project
                                      the candidates' pose-independent records instead of culling all N Gaussians again - same
@@ -233,6 +236,22 @@ int gsx_raster_track_fused(const float *rec, const float *backgrounds, const int
                            int64_t M, int offsets_has_end, int64_t C, int W, int H, const float *gt, const float *exposure,
                            float w_photo, float *alphas, int32_t *last_ids, float *v_render, float *loss_rows, float *v_rec,
                            const int32_t *tile_order, int32_t *tile_work, void *stream);
+/* The same launch for a front that stopped after the placement (GSX_PROJ_DEFER_SORT): every tile's workgroup first sorts the keys
+ * of its segment up to the tile's depth cut-off in LDS - tile_cut [T], depth bits, in / out: 0x7f800000 = no cut-off (initial
+ * value); the launch leaves depth of the deepest composited entry * (1 + cut_margin) for the NEXT closure of the same view - writes
+ * their ids to flatten_ids and composites them; a tile whose pixels outlive its near list sorts its whole segment and goes on
+ * (slower, same result).  "depth <= cut" is a prefix of the (depth, id) order, so what is composited is the reference's list, entry
+ * for entry.  keys / keys_sorted: the key buffer of gsx_front_fwd's workspace and its scratch copy (gsx_front_keys: byte offsets
+ * [0], [1] and the largest valid id [2]); tile_near [T] (nullable): how many entries of each tile ended up sorted (= valid in
+ * flatten_ids); sort_stats [4] (nullable, accumulating): tiles that fell back to their whole segment, tiles that took the
+ * through-memory merge sort.  offsets must carry its end ([T + 1] entries). */
+int gsx_raster_track_fused_sorting(const float *rec, const float *backgrounds, const int32_t *offsets, int32_t *flatten_ids,
+                                   int64_t M, int offsets_has_end, int64_t C, int W, int H, const float *gt,
+                                   const float *exposure, float w_photo, float *alphas, int32_t *last_ids, float *v_render,
+                                   float *loss_rows, float *v_rec, const int32_t *tile_order, int32_t *tile_work,
+                                   uint64_t *keys, uint64_t *keys_sorted, uint32_t id_max, uint32_t *tile_cut,
+                                   float cut_margin, int32_t *tile_near, int32_t *sort_stats, void *stream);
+int gsx_front_keys(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int flags, int64_t *out3);
 /* Launch order for the rasteriser kernels of a render whose T workgroups are all resident at once (T <= 2048): deals the
  * tiles into n_cus groups of near-equal weight (weight = trips + chunk_cost * chunks of tile_work, as measured by an earlier
  * gsx_raster_fwd_track_loss of a nearby pose) and writes tile_order [T] so that the workgroups i, i + n_cus, i + 2 n_cus, ...

@@ -40,8 +40,12 @@
 #ifdef _OPENMP
 #include <omp.h>
 int gsxo_omp_threads(void) { return omp_get_max_threads(); }
+/* bench.py's cpu_baseline: a 10 k-Gaussian problem does not feed 128 threads (its time moved 20x from run to run with all of
+ * them: fork / join and cache-line ping-pong, not work) - the caller sets how many the next calls use and says so */
+void gsxo_omp_set_threads(int n) { if (n >= 1) omp_set_num_threads(n); }
 #else
 int gsxo_omp_threads(void) { return 1; }
+void gsxo_omp_set_threads(int n) { (void)n; }
 #endif
 
 #ifdef GSXO_DOUBLE

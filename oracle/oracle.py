@@ -45,6 +45,12 @@ class Oracle:
         assert self.lib.gsxo_sizeof_real() == self.dtype.itemsize
         self.threads = int(self.lib.gsxo_omp_threads())
 
+    def set_threads(self, n: int) -> int:
+        """OpenMP build only: threads the next calls use (-> the number in effect)"""
+        self.lib.gsxo_omp_set_threads(int(n))
+        self.threads = int(self.lib.gsxo_omp_threads())
+        return self.threads
+
     # -- helpers -----------------------------------------------------------
     def r(self, a, shape=None):
         a = np.ascontiguousarray(a, dtype=self.dtype)

@@ -533,7 +533,9 @@ def _track_closure(dev, n, seed, candidates, W=640, H=480, scale_shift=0.0):
     sc["scales"] = sc["scales"] + scale_shift
     splats = GaussianSplattingData.from_dict(sc, dev)
     cam = Camera(make_intrinsics(W, H).to(dev), H, W)
-    return splats, TrackClosure(splats, cam, tail='fused', candidates=candidates)
+    # (full sorted lists are compared below: the stand-alone tile sort, not the one inside the rasteriser that sorts what it
+    # composites - tested on its own in test_tile_sort_inside_the_rasteriser_equals_the_sort_launch)
+    return splats, TrackClosure(splats, cam, tail='fused', candidates=candidates, defer_sort=False)
 
 
 @pytest.mark.parametrize("n,W,H,shift", [(60000, 640, 480, 0.3), (500000, 640, 480, 0.0), (9000, 320, 240, 0.8)])
@@ -613,3 +615,84 @@ def test_balanced_order_placement_probe(dev):
         assert any(k[1:3] == (1200, n_cus + 37) for k in _PLACEMENT)          # now cached
         placement_ok(dev, 1200, n_cus + 37)
         assert len(w) == 1
+
+
+def _fused_closure_outputs(c, st, H, W):
+    tl = (c.img, c.exposure, 1.0 / (H * W), c.loss_rows)
+    c.r.v_rec.zero_()
+    c.r.forward_track_fused(st, tl)
+    torch.cuda.synchronize()
+    v_rec = c.r.v_rec.clone()
+    c.r.backward(st, rasterised=True)
+    torch.cuda.synchronize()
+    assert c.r.check_capacity()
+    return (c.loss_rows.clone(), c.r.tile_work.clone(), v_rec, c.r.flat[:c.r.last_M].clone(),
+            c.r.offsets[:c.r.T + 1].clone())
+
+
+@pytest.mark.parametrize("n_gauss,scale_up", [(80000, 0.4), (300000, 0.9)])
+def test_tile_sort_inside_the_rasteriser_equals_the_sort_launch(dev, n_gauss, scale_up):
+    """gsx_raster_track_fused_sorting (the front stops after the placement; every tile's workgroup sorts its keys slab by slab
+    of depth in LDS - first up to the tile's cut-off of the previous closure - and composites each slab before the next is
+    sorted) against the stand-alone tile sort + gsx_raster_track_fused: whatever part of a tile's list ended up sorted equals
+    the full list's prefix entry for entry, and loss rows / gradient records are those of the full sort - in the first closure
+    (no cut-off yet: the nearest keys that fit LDS, then more while pixels live), in the second (cut-offs of the first: one
+    slab almost everywhere, most keys never sorted) and with cut-offs forced far too tight (an empty first slab everywhere).
+    The second scene has tiles of several thousand keys: windows that have to be cut down to what the LDS sort takes."""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.plan import TrackClosure, current_stream_ptr
+    from gslam_amd.primitives import Camera
+    from gslam_amd.synthetic import make_intrinsics, make_scene, make_viewmat
+    W, H = 640, 480
+    sc = make_scene(n_gauss, 6)
+    sc["scales"] = sc["scales"] + scale_up
+    splats = GaussianSplattingData.from_dict(sc, dev)
+    cam = Camera(make_intrinsics(W, H).to(dev), H, W)
+    img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(8)).to(dev)
+    st = current_stream_ptr(dev)
+    ref = TrackClosure(splats, cam, defer_sort=False)
+    new = TrackClosure(splats, cam, defer_sort=True)
+    assert new.r.defer_sort and not ref.r.defer_sort
+    for c in (ref, new):
+        c.load(make_viewmat(2.0).to(dev), img, torch.tensor([0.02, -0.01], device=dev))
+        c.r.probe()
+    a = _fused_closure_outputs(ref, st, H, W)
+    off = a[4].cpu().numpy()
+    sizes = off[1:] - off[:-1]
+    if n_gauss >= 300000:
+        assert sizes.max() > 1152, "the second scene must have segments that do not fit the LDS sort"
+
+    def compare(b, what):
+        assert torch.equal(a[4], b[4]), what                                          # same offsets
+        near = new.r.tile_near.cpu().numpy()
+        fa, fb = a[3].cpu().numpy(), b[3].cpu().numpy()
+        for t in range(new.r.T):
+            lo, n = int(off[t]), int(near[t])
+            assert 0 <= n <= sizes[t], (what, t, n, sizes[t])
+            assert (fa[lo:lo + n] == fb[lo:lo + n]).all(), f"{what}: tile {t}: sorted near part differs from the full list"
+        if what == "first closure":
+            assert torch.equal(a[1], b[1]), what                                      # same chunks / trips per tile
+        # (later closures: the work counters - weights of the launch order, not results - count the survivors of whole 64-entry
+        # chunks; a near list that ends inside a chunk, or a fall-back that starts a chunk of its own, shifts them)
+        assert float((a[0] - b[0]).abs().max()) <= 2e-6 * float(a[0].abs().max()), what
+        assert float(a[2].abs().max()) > 0
+        assert float((a[2] - b[2]).abs().max()) < 1e-4 * float(a[2].abs().max()), what
+        return near
+
+    near1 = compare(_fused_closure_outputs(new, st, H, W), "first closure")
+    assert (near1 <= sizes).all() and near1.max() > 0
+    cuts = new.r.tile_cut.clone()
+    assert int((cuts != 0x7f800000).sum()) > new.r.T // 2                             # cut-offs left for the next closure
+    new.r.sort_stats.zero_()
+    near2 = compare(_fused_closure_outputs(new, st, H, W), "second closure")
+    stats = new.r.sort_stats.cpu().tolist()
+    assert near2.sum() < 0.8 * sizes.sum(), (near2.sum(), sizes.sum())                # most keys stay unsorted
+    assert stats[0] <= new.r.T // 20, stats                                           # same pose: the cut-offs hold
+    # cut-offs far too tight: the first slab of every tile is empty, the tiles whose pixels composite anything take a second
+    new.r.tile_cut.copy_(torch.full_like(cuts, 0x3a83126f))                           # depth 0.001
+    new.r.sort_stats.zero_()
+    near3 = compare(_fused_closure_outputs(new, st, H, W), "cut-offs too tight")
+    stats = new.r.sort_stats.cpu().tolist()
+    assert stats[0] >= int((near2 > 0).sum()) * 0.9, stats
+    assert (near3 > 0).sum() >= (near2 > 0).sum() * 0.9
+    assert stats[1] == 0, stats                                                       # nothing went through memory

@@ -101,7 +101,7 @@ if os.path.isdir(g(f"pmc_sq1_{tag}")):
                    "kernels": sq}, f, indent=1)
 bench = json.loads(line)
 if dom is None:
-    dom = {"gsx_raster_track_fused": "raster_track_fused", "gsx_raster_bwd": "raster_bwd",
+    dom = {"gsx_raster_track_fused": "raster_track_fused", "gsx_raster_track_fused_sorting": "raster_track_fused", "gsx_raster_bwd": "raster_bwd",
            "gsx_raster_fwd_track_loss": "raster_fwd"}.get(bench.get("roofline", {}).get("kernel", ""), "raster_bwd")
 hit = [r for r in rows if dom in r[0] and "4q<4" in r[0]] or [r for r in rows if dom in r[0]]
 if hit:
@@ -111,6 +111,15 @@ if hit:
           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/prof_closure.py --eager "
                     "(the tracking closures of one frame + 3 BA iterations, launched eagerly so that counters attribute per kernel); "
                     "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 reports half of wide coalesced reads); unit KB"}
+    # the rocprofv3 kernel-trace average of the same device kernel inside the bench's own loop (graph replay): the figure
+    # bench.py's roofline carries as avg_launch_us_trace, so that the line's fraction can be recomputed from profiles/
+    with open(out(f"{tag}_kernel_stats.csv")) as f:
+        for r in csv.DictReader(f):
+            if dom in r["Name"]:
+                tj["trace_avg_launch_us"] = round(float(r["AverageNs"]) / 1e3, 2)
+                tj["trace_calls"] = int(r["Calls"])
+                tj["trace_source"] = f"profiles/{tag}_kernel_stats.csv"
+                break
     rnd = tag.split("_")[0]
     sqp = out(f"{tag}_sq_counters.json")
     if os.path.exists(sqp):

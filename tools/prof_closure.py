@@ -23,11 +23,19 @@ def main():
     ap.add_argument("--ba-front", type=int, default=-1, help="1 / 0 force the fused front of the BA plan on / off")
     ap.add_argument("--no-balance", action="store_true", help="identity launch order of the rasteriser kernels (A/B)")
     ap.add_argument("--order-per-tile", type=int, default=None, help="RenderPlan.ORDER_MAX_PER_TILE (A/B)")
+    ap.add_argument("--cut-margin", type=float, default=None, help="RenderPlan.CUT_MARGIN of the in-rasteriser tile sort (A/B)")
+    ap.add_argument("--no-defer-sort", action="store_true", help="stand-alone tile sort launch (A/B)")
     args = ap.parse_args()
     import bench
     if args.order_per_tile is not None:
         import gslam_amd.plan as P2
         P2.RenderPlan.ORDER_MAX_PER_TILE = args.order_per_tile
+    if args.cut_margin is not None:
+        import gslam_amd.plan as P3
+        P3.RenderPlan.CUT_MARGIN = args.cut_margin
+    if args.no_defer_sort:
+        import gslam_amd.plan as P4
+        P4.RenderPlan.enable_defer_sort = lambda self, margin=None: False
     if args.no_balance:
         import gslam_amd.plan as P0
         P0.RenderPlan.enable_balance = lambda self: False
@@ -62,6 +70,14 @@ def main():
             tr.track(f, sync=False)
     torch.cuda.synchronize()
     assert tr.capacity_ok()
+    r = tr.plan.r
+    if getattr(r, "defer_sort", False):
+        st4 = r.sort_stats.cpu().tolist()
+        near, off = r.tile_near.cpu().numpy(), r.offsets.cpu().numpy()
+        sizes = off[1:r.T + 1] - off[:r.T]
+        print(f"tile sort inside the rasteriser: {st4[0]} tile fall-backs, {st4[1]} through-memory sorts over all closures so far "
+              f"({r.T} tiles per closure); last closure: {int(near.sum())} of {int(sizes.sum())} entries sorted, "
+              f"largest near list {int(near.max())}, largest segment {int(sizes.max())}, margin {r.cut_margin}")
     if args.ba:
         ba = BundleAdjuster(m, MapConfig(), capturable=True)
         if args.ba_front >= 0:
