@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--ba-front", type=int, default=-1, help="1 / 0 force the fused front of the BA plan on / off")
     ap.add_argument("--no-balance", action="store_true", help="identity launch order of the rasteriser kernels (A/B)")
     ap.add_argument("--order-per-tile", type=int, default=None, help="RenderPlan.ORDER_MAX_PER_TILE (A/B)")
+    ap.add_argument("--chunk-cost", type=float, default=None, help="RenderPlan.CHUNK_COST (A/B)")
+    ap.add_argument("--light-rate", type=float, default=None, help="RenderPlan.LIGHT_RATE (A/B)")
     ap.add_argument("--cut-margin", type=float, default=None, help="RenderPlan.CUT_MARGIN of the in-rasteriser tile sort (A/B)")
     ap.add_argument("--no-defer-sort", action="store_true", help="stand-alone tile sort launch (A/B)")
     args = ap.parse_args()
@@ -30,6 +32,12 @@ def main():
     if args.order_per_tile is not None:
         import gslam_amd.plan as P2
         P2.RenderPlan.ORDER_MAX_PER_TILE = args.order_per_tile
+    if args.chunk_cost is not None or args.light_rate is not None:
+        import gslam_amd.plan as P5
+        if args.chunk_cost is not None:
+            P5.RenderPlan.CHUNK_COST = args.chunk_cost
+        if args.light_rate is not None:
+            P5.RenderPlan.LIGHT_RATE = args.light_rate
     if args.cut_margin is not None:
         import gslam_amd.plan as P3
         P3.RenderPlan.CUT_MARGIN = args.cut_margin
