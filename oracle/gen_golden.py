@@ -180,12 +180,60 @@ def gen_rasterization_host_logic():
     np.savez_compressed(os.path.join(OUT, "rasterization_host_logic.npz"), **save)
 
 
+def gen_trajectory():
+    """gslam/trajectory.py:14-97 - kabsch_umeyama, average_translation_error, evaluate_trajectories (the figure is dropped) -
+    on seeded trajectories: a similarity-transformed noisy copy, a mirrored one (the determinant correction), a short one."""
+    sys.path.insert(0, REF)
+    sys.modules.setdefault("pypose", mock.MagicMock())
+    from gslam.trajectory import average_translation_error, evaluate_trajectories, kabsch_umeyama
+    rng = np.random.default_rng(40)
+    save = {}
+    cases = {}
+    n = 40
+    t_ = np.linspace(0, 1, n)
+    A = np.stack([np.sin(2 * t_), 0.3 * t_, np.cos(3 * t_) * 0.5], 1) + rng.normal(scale=0.002, size=(n, 3))
+    Rg = small_pose(rng, rot=0.8, trans=0.0)[:3, :3].astype(np.float64)
+    B = (A - 0.2) @ Rg.T * 1.7 + np.array([0.5, -0.1, 0.3]) + rng.normal(scale=0.004, size=(n, 3))
+    cases["similar"] = (A, B)
+    cases["mirrored"] = (A, B * np.array([1.0, 1.0, -1.0]))
+    cases["short"] = (A[:3], B[:3])
+    for name, (a, b) in cases.items():
+        R, c, t = kabsch_umeyama(a, b)
+        save[f"{name}__A"], save[f"{name}__B"] = a, b
+        save[f"{name}__R"], save[f"{name}__c"], save[f"{name}__t"] = R, np.float64(c), t
+        save[f"{name}__ate"] = np.float64(average_translation_error(a, b))
+
+    class F:                                            # what evaluate_trajectories reads of a Frame
+        def __init__(self, gt, est):
+            self.gt_pose, self._est = torch.from_numpy(gt), torch.from_numpy(est)
+
+        def pose(self):
+            return self._est
+
+    def frames(a, b):
+        out = []
+        for i in range(len(a)):
+            g, e = np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)
+            g[:3, 3], e[:3, 3] = a[i], b[i]
+            out.append(F(g, e))
+        return out
+    trajs = {"tracking": frames(*cases["similar"]), "keyframes": frames(cases["similar"][0][::5], cases["similar"][1][::5])}
+    fig, ates = evaluate_trajectories(trajs, keyframe_indices=[0, 5, 10])
+    for k, v in ates.items():
+        save[f"eval__{k}"] = np.float64(v)
+    np.savez_compressed(os.path.join(OUT, "trajectory.npz"), **save)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
+    if "--only-trajectory" in sys.argv:
+        gen_trajectory()
+        sys.exit(0)
     gen_warp()
     gen_utils()
     gen_pose()
     gen_rasterization_host_logic()
+    gen_trajectory()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

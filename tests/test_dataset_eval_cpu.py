@@ -125,3 +125,41 @@ def test_psnr_ssim_match_their_definitions():
                 acc.append(((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2)))
     assert abs(ssim_uint8(img, ref) - np.mean(acc)) < 1e-9
     assert to_uint8(torch.tensor([[[0.5, 1.2, -0.1]]])).tolist() == [[[127, 255, 0]]]
+
+
+def test_trajectory_evaluation_matches_reference_fixture():
+    """gslam_amd.trajectory against tests/golden/trajectory.npz, written by oracle/gen_golden.py from the IMPORTED reference
+    (gslam/trajectory.py:14-97: kabsch_umeyama, average_translation_error, evaluate_trajectories): a similarity-transformed
+    noisy trajectory, a mirrored one (the determinant correction of the SVD) and a three-point one."""
+    import os
+    import numpy as np
+    import torch
+    from gslam_amd.trajectory import average_translation_error, evaluate_trajectories, kabsch_umeyama
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "trajectory.npz"))
+    for name in ("similar", "mirrored", "short"):
+        A, B = g[f"{name}__A"], g[f"{name}__B"]
+        R, c, t = kabsch_umeyama(A, B)
+        np.testing.assert_allclose(R, g[f"{name}__R"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(c, float(g[f"{name}__c"]), rtol=1e-12)
+        np.testing.assert_allclose(t, g[f"{name}__t"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(average_translation_error(A, B), float(g[f"{name}__ate"]), rtol=1e-10, atol=1e-14)
+
+    class F:
+        def __init__(self, gt, est):
+            self.gt_pose, self._est = torch.from_numpy(gt), torch.from_numpy(est)
+
+        def pose(self):
+            return self._est
+
+    def frames(a, b):
+        out = []
+        for i in range(len(a)):
+            gt, e = np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)
+            gt[:3, 3], e[:3, 3] = a[i], b[i]
+            out.append(F(gt, e))
+        return out
+    A, B = g["similar__A"], g["similar__B"]
+    ates = evaluate_trajectories({"tracking": frames(A, B), "keyframes": frames(A[::5], B[::5])}, keyframe_indices=[0, 5, 10])
+    assert set(ates) == {"ate_tracking", "ate_keyframes"}
+    for k, v in ates.items():
+        np.testing.assert_allclose(v, float(g[f"eval__{k}"]), rtol=1e-6)

@@ -329,3 +329,66 @@ def test_ba_step_2m_window8_graph_equals_eager(dev):
         assert float((a - b).abs().mean()) < 2e-5, (k, float((a - b).abs().mean()))
         assert float((a - b).abs().max()) < 0.06, (k, float((a - b).abs().max()))
     assert float((wa[3].pose.dR - wb[3].pose.dR).abs().max()) < 2e-3
+
+
+def _crop_vs_oracle(out, sc, cam, tx0, ty0, oracle32, nt=4):
+    """A (16 nt)^2-pixel crop of camera ``cam`` of a gslam rasterization() output against the CPU oracle's rasteriser run over
+    the crop's nt x nt tiles only: the crop is posed as an image of its own (means2d shifted to the crop's origin, the tiles'
+    segments of the GPU's sorted list as its tile lists) - per-Gaussian inputs of the oracle are the GPU's projection outputs
+    (those are held to the oracle bit for bit at the baseline sizes, tests/test_gpu_baseline_sizes.py).  -> L1 per pixel."""
+    N = sc["means"].shape[0]
+    off = out.isect_offsets[cam].cpu().numpy()                     # [tile_h, tile_w]
+    flat = out.flatten_ids
+    M = int(flat.shape[0])
+    offs_flat = np.concatenate([out.isect_offsets.reshape(-1).cpu().numpy(), [M]])
+    th, tw = off.shape
+    segs, sub_off, run = [], np.zeros((1, nt, nt), np.int32), 0
+    for j in range(nt):
+        for i in range(nt):
+            t = (cam * th + ty0 + j) * tw + tx0 + i
+            lo, hi = int(offs_flat[t]), int(offs_flat[t + 1])
+            sub_off[0, j, i] = run
+            segs.append(flat[lo:hi].cpu().numpy().astype(np.int64) - cam * N)
+            run += hi - lo
+    ids = np.concatenate(segs).astype(np.int32)
+    assert ids.size > 0 and ids.min() >= 0 and ids.max() < N
+    used = np.unique(ids)                                           # compact the per-Gaussian inputs to the listed ones
+    remap = np.zeros(N, np.int32)
+    remap[used] = np.arange(used.size, dtype=np.int32)
+    ut = torch.from_numpy(used).to(out.means2d.device)
+    m2 = out.means2d[cam][ut].detach().cpu().numpy() - np.array([tx0 * 16.0, ty0 * 16.0], np.float32)
+    con = out.conics[cam][ut].detach().cpu().numpy()
+    op = out.opacities[cam][ut].detach().cpu().numpy() if out.opacities.dim() == 2 else torch.sigmoid(sc["opacities"][ut]).cpu().numpy()
+    cols = torch.sigmoid(sc["colors"][ut]).cpu().numpy()
+    depth = out.depths[cam][ut].detach().cpu().numpy()
+    betas = np.maximum(np.exp(sc["log_uncertainties"][ut].cpu().numpy()), np.float32(0.01))
+    packed = np.concatenate([cols, depth[:, None], betas[:, None]], -1)[None].astype(np.float32)
+    bg = np.array([[0.0, 0.0, 0.0, 0.0, np.e]], np.float32)
+    S = 16 * nt
+    ren, alp, _, _ = oracle32.raster_fwd(m2[None], con[None], packed, op[None], bg, S, S, 16, sub_off, remap[ids])
+    x0, y0 = tx0 * 16, ty0 * 16
+    got = out.rgbs[cam, y0:y0 + S, x0:x0 + S].detach().cpu().numpy()
+    l1 = float(np.abs(got - ren[0, ..., :3]).mean())
+    l1d = float(np.abs(out.depthmaps[cam, y0:y0 + S, x0:x0 + S].detach().cpu().numpy() - ren[0, ..., 3]).mean())
+    la = float(np.abs(out.alphas[cam, y0:y0 + S, x0:x0 + S, 0].detach().cpu().numpy() - alp[0, ..., 0]).mean())
+    return l1, l1d, la, ids.size
+
+
+def test_crops_of_the_two_largest_configs_against_the_live_oracle(dev, oracle32):
+    """the two largest BASELINE configs were only self-compared.  Here a 64x64-pixel crop of each - 5 M
+    Gaussians at 1920x1080 (configs[4]'s size through gslam's rasterization()), and one keyframe of 2 M x 8 at 640x480
+    (configs[3]) - is rendered again by the CPU oracle from the tiles' own lists: 1e-4 L1 per pixel, the bar of the path."""
+    from gslam_amd.rasterization import rasterization
+    from gslam_amd.synthetic import make_cameras, make_scene
+    for n, C, W, H, cam, tx0, ty0 in ((5_000_000, 1, 1920, 1080, 0, 58, 32), (2_000_000, 8, 640, 480, 5, 18, 13)):
+        sc = {k: v.to(dev) for k, v in make_scene(n, 0).items()}
+        viewmats, Ks = make_cameras(C, W, H)
+        out = rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], viewmats.to(dev),
+                            Ks.to(dev), W, H, packed=False, render_mode="RGB+D", log_uncertainties=sc["log_uncertainties"],
+                            backgrounds=torch.zeros(C, 3, device=dev))
+        l1, l1d, la, n_ent = _crop_vs_oracle(out, sc, cam, tx0, ty0, oracle32)
+        print(f"crop of {n} x {C} @ {W}x{H}: {n_ent} list entries in 16 tiles, L1 rgb {l1:.2e} depth {l1d:.2e} alpha {la:.2e}")
+        assert n_ent > 16 * 50
+        assert l1 < 1e-4 and la < 1e-4 and l1d < 1e-3, (n, l1, l1d, la)
+        del out, sc
+        torch.cuda.empty_cache()
