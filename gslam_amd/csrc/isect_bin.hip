@@ -938,13 +938,30 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
 // =====================================================================================================================
 #include "project_core.h"
 
+// DIAGNOSTIC build only (-DGSX_WG_TRACE, tools/dbg/front_trace.sh): thread 0 of every workgroup of the two front kernels stamps
+// s_memrealtime (100 MHz) at its phase boundaries.  Nothing of this is compiled into the product library.
+#ifdef GSX_WG_TRACE
+__device__ unsigned long long *g_front_trace = nullptr;        // [2 kernels][4096 workgroups][8 stamps]
+#define GSX_FT(kern, k)                                                                                                    \
+    if (g_front_trace && threadIdx.x == 0 && blockIdx.x < 4096)                                                            \
+        g_front_trace[((size_t)(kern) * 4096 + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();
+extern "C" int gsx_debug_front_trace(void *buffer) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_front_trace), &buffer, sizeof(buffer)) == hipSuccess ? 0 : 1;
+}
+#else
+#define GSX_FT(kern, k)
+#endif
+
 namespace {
 
 using namespace gsx_proj;
 
 constexpr int FRONT_THREADS = 1024;
 constexpr int FPLACE_THREADS = 256;
-constexpr int FRONT_STRIPES = 8;
+#ifndef GSX_FRONT_STRIPES
+#define GSX_FRONT_STRIPES 8
+#endif
+constexpr int FRONT_STRIPES = GSX_FRONT_STRIPES;
 
 struct FrontArgs {
     const float *means, *quats, *scales, *viewmats, *Ks, *logit_opac, *logit_colors, *log_unc;
@@ -963,6 +980,11 @@ struct FrontArgs {
     const struct CandRec *cand;   // [R][seg_cap] pose-independent records of the row's candidates, in Gaussian order
     const int32_t *cand_n;        // [R]
     float *cand_hdr;              // [CAND_HDR]: reference [R | t] of every camera, margins, mode word (see cand_valid)
+    // GSX_PROJ_MAP_RECORDS: the candidate area holds a record for EVERY Gaussian (slot = Gaussian index) and this array what
+    // the conservative cull reads of each, packed: (mean, largest scale squared).  Closures keep their own cull (one coalesced
+    // 16-byte load per Gaussian instead of two 12-byte-stride arrays) and read ONE 64-byte line per survivor instead of
+    // gathering 14 floats from five arrays and rebuilding the covariance (15 of the projection's 27 us at 500 k, traced)
+    const float4 *cull4;          // [R * seg_cap]
 };
 
 // What the projection needs of one Gaussian that does not depend on the pose: built once per frame for the Gaussians that
@@ -1032,10 +1054,30 @@ __device__ __forceinline__ int ordered_position(bool flag, int *s_wcnt, int &tot
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
+// Upper bound of |R|_2^2 = lambda_max(R R^T) by its largest absolute row sum (Gershgorin): 1 for a rotation - a third of
+// |R|_F^2, which the cull used until round 4 and which kept 260 k of a 500 k map for the exact projection where 170 k are
+// visible - and still an upper bound for whatever else the caller hands in as a view matrix.  0.1 % on top for the rounding
+// of the six products.
+__device__ __forceinline__ float rot_norm2_bound(const float *R) {
+    const float g00 = (R[0] * R[0] + R[1] * R[1]) + R[2] * R[2], g11 = (R[3] * R[3] + R[4] * R[4]) + R[5] * R[5];
+    const float g22 = (R[6] * R[6] + R[7] * R[7]) + R[8] * R[8];
+    const float g01 = fabsf((R[0] * R[3] + R[1] * R[4]) + R[2] * R[5]), g02 = fabsf((R[0] * R[6] + R[1] * R[7]) + R[2] * R[8]);
+    const float g12 = fabsf((R[3] * R[6] + R[4] * R[7]) + R[5] * R[8]);
+    return 1.001f * fmaxf(fmaxf((g00 + g01) + g02, (g01 + g11) + g12), (g02 + g12) + g22);
+}
+
+// Upper bound of z^2 |J|_2^2 = z^2 lambda_max(J J^T) over the frustum (J: the 2x3 perspective Jacobian with x / z, y / z clamped to
+// lx, ly): z^2 J J^T = [[fx^2 (1 + a^2), fx fy a b], [fx fy a b, fy^2 (1 + b^2)]], largest absolute row sum at a = lx, b = ly.
+// (Until round 4: the trace, |J|_F^2 - 1.5 times this at 640x480 / 525.)
+__device__ __forceinline__ float jac_norm2_bound(float fx, float fy, float lx, float ly) {
+    const float off = fabsf(fx * fy) * (lx * ly);
+    return 1.001f * fmaxf(fx * fx * (1.0f + lx * lx) + off, fy * fy * (1.0f + ly * ly) + off);
+}
+
 // Conservative screen-space cull of one Gaussian for one camera from its mean and its largest scale alone (no covariance
 // algebra): true only if the full projection is CERTAIN to cull it - same near / far comparison on the same expression, and
-// a bounding box test with an upper bound of the radius: trace(J Sc J^T) <= |J|_F^2 |R|_F^2 s_max^2 with
-// |J|_F^2 <= rz^2 (fx^2 (1 + lx^2) + fy^2 (1 + ly^2)) (lx, ly: the frustum clamp of tx / z, ty / z), v1 <= trace + 2 eps + 0.1,
+// a bounding box test with an upper bound of the radius: lambda_max(J Sc J^T) <= |J|_2^2 |R|_2^2 s_max^2 (KJ: jac_norm2_bound,
+// RF: rot_norm2_bound; lx, ly: the frustum clamp of tx / z, ty / z), v1 = lambda_max of the blurred covariance <= that + eps,
 // radius <= 3 sqrt(v1) + 1; one per cent and one pixel of slack on top cover the float rounding of this estimate.
 __device__ __forceinline__ bool surely_culled(const float mean[3], float smax2, const Cam &cam, float RF, float KJ,
                                               int W, int H, float eps2d, float near_p, float far_p) {
@@ -1102,12 +1144,14 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_candidates_kernel(FrontAr
         for (int i = threadIdx.x; i < CAND_HDR; i += FRONT_THREADS) {
             float v = 0.f;
             if (i < 12 * C) v = a.viewmats[16 * (i / 12) + (i % 12)];
-            else if (i == CAND_MAX_CAMS * 12) v = rot_max;
-            else if (i == CAND_MAX_CAMS * 12 + 1) v = trans_max;
+            else if (i == CAND_MAX_CAMS * 12) v = (a.flags & GSX_PROJ_MAP_RECORDS) ? __builtin_inff() : rot_max;
+            else if (i == CAND_MAX_CAMS * 12 + 1) v = (a.flags & GSX_PROJ_MAP_RECORDS) ? __builtin_inff() : trans_max;
             a.cand_hdr[i] = v;
         }
     }
     int n_surv = 0;
+    const bool map_recs = (a.flags & GSX_PROJ_MAP_RECORDS) != 0;
+    float4 *cull_out = const_cast<float4 *>(a.cull4);
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int64_t g = g0 + it * FRONT_THREADS + threadIdx.x;
@@ -1120,18 +1164,20 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_candidates_kernel(FrontAr
             if (a.flags & GSX_PROJ_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
             const float sm = fmaxf(s[0], fmaxf(s[1], s[2]));
             const float smax2 = sm * sm;
-            for (int c = 0; c < C; ++c) {
+            if (map_recs) {
+                survive = true;
+                cull_out[g] = make_float4(mean[0], mean[1], mean[2], smax2);
+            }
+            for (int c = 0; c < C && !map_recs; ++c) {
                 Cam cam;
                 load_cam(a.viewmats, a.Ks, c, cam);
                 const float *R = cam.R;
-                const float RF = ((R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) + (R[3] * R[3] + R[4] * R[4] + R[5] * R[5])) +
-                                 (R[6] * R[6] + R[7] * R[7] + R[8] * R[8]);
+                const float RF = rot_norm2_bound(R);
                 const float tanx = 0.5f * (float)a.W / cam.fx, tany = 0.5f * (float)a.H / cam.fy;
                 const float lx = fmaxf(((float)a.W - cam.cx) / cam.fx, cam.cx / cam.fx) + GSX_FOV_SLACK * tanx;
                 const float ly = fmaxf(((float)a.H - cam.cy) / cam.fy, cam.cy / cam.fy) + GSX_FOV_SLACK * tany;
-                const float KJ = cam.fx * cam.fx * (1.0f + lx * lx) + cam.fy * cam.fy * (1.0f + ly * ly);
-                // |R|_F^2 = 3 for every rotation; 1 % more covers a view matrix that is one only to float accuracy
-                if (!surely_culled_margin(mean, smax2, cam, 1.01f * fmaxf(RF, 3.0f), KJ, a.W, a.H, a.eps2d, a.near_p,
+                const float KJ = jac_norm2_bound(cam.fx, cam.fy, lx, ly);
+                if (!surely_culled_margin(mean, smax2, cam, 1.01f * RF, KJ, a.W, a.H, a.eps2d, a.near_p,
                                           a.far_p, rot_max, trans_max))
                     survive = true;
             }
@@ -1149,6 +1195,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_candidates_kernel(FrontAr
             base += (w < (int)(threadIdx.x >> 6)) ? cw : 0;
             tot += cw;
         }
+        // (map records: every Gaussian survives, so the ordered position IS the local index: slot = Gaussian index)
         const int pos = n_surv + base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
         if (survive) {
             CandRec rec;
@@ -1191,11 +1238,23 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
     int *s_wcnt = s_ninst + C;                                                     // [FRONT_THREADS / 64] scratch
     unsigned short *s_list = reinterpret_cast<unsigned short *>(s_wcnt + FRONT_THREADS / 64);   // [1024 * items] local indices
     int n_surv = 0;
-    for (int i = threadIdx.x; i < C * n_tiles + C; i += FRONT_THREADS) s_front[i] = 0;
-    __syncthreads();
+    GSX_FT(0, 0)
     const int seg_cap = FRONT_THREADS * ITEMS;
     const bool skip_culled = (a.flags & GSX_PROJ_SKIP_CULLED) != 0;
     const int64_t g0 = (int64_t)blockIdx.x * seg_cap;
+    // records of the whole map: the cull rows are requested before anything else (LDS clear, pose check) - used only if the
+    // pose check below agrees (it does unless a pose is NaN)
+    float4 cull_row[ITEMS];
+    if ((a.flags & GSX_PROJ_MAP_RECORDS) && a.cull4 != nullptr) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int64_t g = g0 + it * FRONT_THREADS + threadIdx.x;
+            cull_row[it] = g < a.N ? a.cull4[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    for (int i = threadIdx.x; i < C * n_tiles + C; i += FRONT_THREADS) s_front[i] = 0;
+    __syncthreads();
+    GSX_FT(0, 1)
     // per-frame candidate records (pose-only plans): valid while every camera stays within the margins they were built for;
     // otherwise this closure takes the full path below - same results either way, the candidates only save the cull
     const bool use_cand = a.cand != nullptr && cand_valid(a.viewmats, a.cand_hdr, C);
@@ -1203,19 +1262,26 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
         a.cand_hdr[CAND_MAX_CAMS * 12 + 4] = use_cand ? 1.0f : 0.0f;            // mode of this closure (front_pose_bwd reads it)
         if (!use_cand) a.cand_hdr[CAND_MAX_CAMS * 12 + 5] += 1.0f;              // closures that fell back (diagnostics)
     }
-    if (use_cand) n_surv = min(max(a.cand_n[blockIdx.x], 0), seg_cap);
+    // records of the whole map: this closure culls as ever (from the packed cull rows) and reads the survivors' records
+    const bool map_recs = use_cand && (a.flags & GSX_PROJ_MAP_RECORDS) != 0 && a.cull4 != nullptr;
+    if (use_cand && !map_recs) n_surv = min(max(a.cand_n[blockIdx.x], 0), seg_cap);
     // ---- phase 1: cheap conservative cull; the survivors' local indices are compacted into LDS.  The loads of all ITEMS
     // Gaussians of a thread are issued before any of them is used (one memory round trip for the phase, not ITEMS) ---------
     float pm[ITEMS][3], psm[ITEMS];
-    if (!use_cand) {
+    if (!use_cand || map_recs) {
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int64_t g = g0 + it * FRONT_THREADS + threadIdx.x;
         const bool active = g < a.N;
-        pm[it][0] = active ? a.means[3 * g] : 0.f;
-        pm[it][1] = active ? a.means[3 * g + 1] : 0.f;
-        pm[it][2] = active ? a.means[3 * g + 2] : 0.f;
-        psm[it] = active ? fmaxf(a.scales[3 * g], fmaxf(a.scales[3 * g + 1], a.scales[3 * g + 2])) : 0.f;
+        if (map_recs) {
+            const float4 cr = cull_row[it];
+            pm[it][0] = cr.x; pm[it][1] = cr.y; pm[it][2] = cr.z; psm[it] = cr.w;
+        } else {
+            pm[it][0] = active ? a.means[3 * g] : 0.f;
+            pm[it][1] = active ? a.means[3 * g + 1] : 0.f;
+            pm[it][2] = active ? a.means[3 * g + 2] : 0.f;
+            psm[it] = active ? fmaxf(a.scales[3 * g], fmaxf(a.scales[3 * g + 1], a.scales[3 * g + 2])) : 0.f;
+        }
     }
     // camera constants once per camera (not per item): the loop over the thread's items is the inner one
     bool survive[ITEMS];
@@ -1224,6 +1290,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
     for (int it = 0; it < ITEMS; ++it) {
         survive[it] = false;
         float sm = psm[it];
+        if (map_recs) { smax2[it] = sm; continue; }           // the cull row holds the square of the (exponentiated) scale
 #if GSX_FAST_CULL
         if (a.flags & GSX_PROJ_LOG_SCALES) sm = __builtin_amdgcn_exp2f(sm * 1.4426950408889634f) * 1.00001f;
 #else
@@ -1235,12 +1302,11 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
         Cam cam;
         load_cam(a.viewmats, a.Ks, c, cam);
         const float *R = cam.R;
-        const float RF = ((R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) + (R[3] * R[3] + R[4] * R[4] + R[5] * R[5])) +
-                         (R[6] * R[6] + R[7] * R[7] + R[8] * R[8]);
+        const float RF = rot_norm2_bound(R);
         const float tanx = 0.5f * (float)a.W / cam.fx, tany = 0.5f * (float)a.H / cam.fy;
         const float lx = fmaxf(((float)a.W - cam.cx) / cam.fx, cam.cx / cam.fx) + GSX_FOV_SLACK * tanx;
         const float ly = fmaxf(((float)a.H - cam.cy) / cam.fy, cam.cy / cam.fy) + GSX_FOV_SLACK * tany;
-        const float KJ = cam.fx * cam.fx * (1.0f + lx * lx) + cam.fy * cam.fy * (1.0f + ly * ly);
+        const float KJ = jac_norm2_bound(cam.fx, cam.fy, lx, ly);
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             const int64_t g = g0 + it * FRONT_THREADS + threadIdx.x;
@@ -1257,6 +1323,42 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
             }
         }
     }
+    if constexpr (ITEMS <= 4) {
+        // ONE ordered compaction for all items of the thread (two barriers, not two per item): the per-wavefront counts of the
+        // items travel in the bytes of one word; the list is ordered by local index = item * 1024 + thread, as before
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        unsigned long long m[ITEMS];
+        unsigned int packed = 0u;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int64_t g = g0 + it * FRONT_THREADS + threadIdx.x;
+            if (g < a.N && !survive[it] && a.vis_count) a.vis_count[g] = 0;
+            m[it] = __ballot(survive[it]);
+            packed |= (unsigned int)__popcll(m[it]) << (8 * it);
+        }
+        if (lane == 0) s_wcnt[wave] = (int)packed;
+        __syncthreads();
+        int base[ITEMS], tot[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) base[it] = tot[it] = 0;
+#pragma unroll
+        for (int w = 0; w < FRONT_THREADS / 64; ++w) {
+            const unsigned int cw = (unsigned int)s_wcnt[w];
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int cnt = (int)((cw >> (8 * it)) & 0xffu);
+                base[it] += (w < wave) ? cnt : 0;
+                tot[it] += cnt;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            if (survive[it])
+                s_list[n_surv + base[it] + __popcll(m[it] & ((1ull << lane) - 1ull))] = (unsigned short)(it * FRONT_THREADS + threadIdx.x);
+            n_surv += tot[it];
+        }
+    } else {
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int loc = it * FRONT_THREADS + threadIdx.x;
@@ -1267,8 +1369,13 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
         if (survive[it]) s_list[n_surv + pos] = (unsigned short)loc;
         n_surv += tot;
     }
-    }   // !use_cand
+    }
+    }   // !use_cand || map_recs
     __syncthreads();
+    GSX_FT(0, 7)
+#ifdef GSX_WG_TRACE
+    if (g_front_trace && threadIdx.x == 0) g_front_trace[((size_t)4096 + blockIdx.x) * 8 + 4] = (unsigned long long)n_surv;
+#endif
     // ---- phase 2: the projection proper, dense over the survivors (whole wavefronts of real work) ---------------------------
     for (int s0 = 0; s0 < n_surv; s0 += FRONT_THREADS) {
         const int si = s0 + threadIdx.x;
@@ -1277,11 +1384,23 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
         float mean[3] = {0.f, 0.f, 0.f};
         float opac = 0.f, col[3] = {0.f, 0.f, 0.f}, beta = 0.f;
         Sym3 S = {1.f, 0.f, 0.f, 1.f, 0.f, 1.f};
-        const int64_t cslot = (int64_t)blockIdx.x * seg_cap + si;      // candidate record of this thread (candidate mode)
+        // candidate record of this thread (candidate mode): the si-th of the row, or - records of the whole map - the one of
+        // the si-th survivor of this closure's cull
+        const int64_t cslot = (int64_t)blockIdx.x * seg_cap + (map_recs ? (active ? (int)s_list[si] : 0) : si);
         if (use_cand) {
             if (active) {
                 const float4 *src = reinterpret_cast<const float4 *>(a.cand + cslot);
+#if defined(GSX_DBG_FRONT) && GSX_DBG_FRONT == 1      // timing experiment only: no record load at all
+                const float4 r0 = make_float4((float)(si & 63) / 64.f - 0.5f, (float)((si >> 6) & 15) / 16.f - 0.5f, 3.f, 1e-4f);
+                const float4 r1 = make_float4(0.f, 0.f, 1e-4f, 0.f), r2 = make_float4(1e-4f, 0.5f, 0.5f, 0.5f);
+                const float4 r3 = make_float4(0.5f, 0.f, __int_as_float((int)(g0 + s_list[si])), 0.f);
+#elif defined(GSX_DBG_FRONT) && GSX_DBG_FRONT == 2    // timing experiment only: the first 16 bytes of the record
+                const float4 r0 = src[0];
+                const float4 r1 = make_float4(0.f, 0.f, 1e-4f, 0.f), r2 = make_float4(1e-4f, 0.5f, 0.5f, 0.5f);
+                const float4 r3 = make_float4(0.5f, 0.f, __int_as_float((int)(g0 + s_list[si])), 0.f);
+#else
                 const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+#endif
                 mean[0] = r0.x; mean[1] = r0.y; mean[2] = r0.z;
                 S.a00 = r0.w; S.a01 = r1.x; S.a02 = r1.y; S.a11 = r1.z; S.a12 = r1.w; S.a22 = r2.x;
                 opac = r2.y; col[0] = r2.z; col[1] = r2.w; col[2] = r3.x; beta = r3.y;
@@ -1306,6 +1425,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
             float M[9];
             covar_from_rot_scale(qr.R, s, M, S);
         }
+        if (__float_as_uint(S.a00) != 0x12345u && s0 == 0) { GSX_FT(0, 6) }
         int n_vis = 0;
         for (int c = 0; c < C; ++c) {
             Cam cam;
@@ -1337,6 +1457,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
             const int run = s_ninst[c];
             int tot;
             const int pos = run + ordered_position(has, s_wcnt, tot);
+            if (s0 == 0) { GSX_FT(0, 2) }
             if (threadIdx.x == 0) s_ninst[c] = run + tot;      // read again only behind the barrier that ends the trip
             const int64_t slot = ((int64_t)c * a.R + blockIdx.x) * seg_cap + pos;
             if (active) {
@@ -1373,13 +1494,16 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
                     a.recs[slot] = pr;
                 }
             }
+            if (s0 == 0) { GSX_FT(0, 3) }
             walk_rects(r, a.tile_w, 0u, 0u, [&](int tile, unsigned int, unsigned int) { atomicAdd(&s_cnt[tile], 1); },
                        c * n_tiles);
+            if (s0 == 0) { GSX_FT(0, 4) }
         }
         if (active && a.vis_count) a.vis_count[g] = n_vis;
         __syncthreads();                                     // s_ninst is read again at the top of the next trip
     }
     __syncthreads();
+    GSX_FT(0, 5)
     for (int i = threadIdx.x; i < C * n_tiles; i += FRONT_THREADS) {
         const int c = i / n_tiles, tl = i - c * n_tiles;
         a.cnt[((int64_t)c * a.R + blockIdx.x) * n_tiles + tl] = s_cnt[i];
@@ -1401,6 +1525,7 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
     const int t = threadIdx.x;
     const int ys0 = stripe * rps, ys1 = min(tile_h, ys0 + rps);
     const int span = max(0, (ys1 - ys0) * tile_w);
+    GSX_FT(1, 0)
     // Everything this workgroup needs from global memory that does not depend on the scan is requested first - the first
     // trip of camera 0's instance records, its row's bases for the stripe, the instance count - so that the kernel is one
     // memory round trip plus the scan deep, not four (a workgroup places only a few hundred entries: latency is all there is).
@@ -1473,6 +1598,7 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
         }
     }
     __syncthreads();
+    GSX_FT(1, 1)
     if (span <= 0) return;
     for (int c = 0; c < C; ++c) {
         const int32_t *brow = cnt + ((int64_t)c * R + row) * n_tiles;
@@ -1482,6 +1608,7 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
         }
     }
     __syncthreads();
+    GSX_FT(1, 2)
     for (int c = 0; c < C; ++c) {
         const int n = min(max(c == 0 ? n0 : n_inst[c * R + row], 0), seg_cap);
         const PreRec *seg = recs + ((int64_t)c * R + row) * seg_cap;
@@ -1500,6 +1627,7 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
             place_rects(r, tile_w, klo, khi, s_cur, M_cap, entries, c * n_tiles);
         }
     }
+    GSX_FT(1, 3)
 }
 
 // Pose gradient of a pose-only closure over the VISIBLE instances the front left behind (instead of a pass over all N
@@ -1636,7 +1764,7 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
 
 struct FrontLayout {
     int64_t counts_off, ninst_off, entries_off, scratch_off, matrix_off, recs_off, total;
-    int64_t cand_hdr_off, cand_n_off, cand_off, total_cand;      // candidate area, appended behind `total` (optional)
+    int64_t cand_hdr_off, cand_n_off, cand_off, cull_off, total_cand;   // candidate area, appended behind `total` (optional)
     int items, R;
 };
 
@@ -1659,7 +1787,8 @@ FrontLayout front_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M
     L.cand_hdr_off = L.total;
     L.cand_n_off = L.cand_hdr_off + gsx_align256(CAND_HDR * 4);
     L.cand_off = L.cand_n_off + gsx_align256((int64_t)GB_MAX * 4);
-    L.total_cand = gsx_align256(L.cand_off + (int64_t)L.R * FRONT_THREADS * items * (int64_t)sizeof(CandRec) + 256);
+    L.cull_off = gsx_align256(L.cand_off + (int64_t)L.R * FRONT_THREADS * items * (int64_t)sizeof(CandRec) + 256);
+    L.total_cand = gsx_align256(L.cull_off + (int64_t)L.R * FRONT_THREADS * items * 16 + 256);
     return L;
 }
 
@@ -1696,6 +1825,7 @@ extern "C" int gsx_front_candidates(const float *means, const float *quats, cons
     a.N = N; a.C = (int)C; a.W = W; a.H = H; a.flags = flags; a.tile_w = tile_w; a.tile_h = tile_h;
     a.items = L.items; a.R = L.R; a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane;
     a.cand_hdr = (float *)(ws + L.cand_hdr_off);
+    a.cull4 = (const float4 *)(ws + L.cull_off);
     CandRec *cand = (CandRec *)(ws + L.cand_off);
     int32_t *cand_n = (int32_t *)(ws + L.cand_n_off);
     hipStream_t st = (hipStream_t)stream;
@@ -1746,7 +1876,8 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
     a.conics = conics; a.rec = rec; a.v_rec = v_rec_clear;
     a.cnt = (int32_t *)(ws + L.matrix_off); a.n_inst = (int32_t *)(ws + L.ninst_off); a.recs = (PreRec *)(ws + L.recs_off);
     a.compact = compact;
-    a.cand = nullptr; a.cand_n = nullptr; a.cand_hdr = nullptr;
+    a.cand = nullptr; a.cand_n = nullptr; a.cand_hdr = nullptr; a.cull4 = nullptr;
+    GSX_CHECK_ARG(!(flags & GSX_PROJ_MAP_RECORDS) || (flags & GSX_PROJ_CANDIDATES));
     if (flags & GSX_PROJ_CANDIDATES) {
         // the candidate set gsx_front_candidates left in this workspace; a closure whose poses left its margins takes the
         // full path by itself (same results), so the flag is a promise about the workspace, not about the poses
@@ -1759,6 +1890,7 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
         a.cand = (const CandRec *)(ws + L.cand_off);
         a.cand_n = (const int32_t *)(ws + L.cand_n_off);
         a.cand_hdr = (float *)(ws + L.cand_hdr_off);
+        a.cull4 = (const float4 *)(ws + L.cull_off);
     }
     size_t front_lds = (size_t)((T + C + FRONT_THREADS / 64) * 4 + 2 * FRONT_THREADS * L.items);   // histogram + survivor list
     a.bal.order = nullptr;

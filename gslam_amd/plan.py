@@ -35,6 +35,7 @@ _SKIP_CULLED = 16       # GSX_PROJ_SKIP_CULLED
 _COMPACT = 32           # GSX_PROJ_COMPACT
 _CANDIDATES = 128       # GSX_PROJ_CANDIDATES
 _DEFER_SORT = 256       # GSX_PROJ_DEFER_SORT
+_MAP_RECORDS = 512      # GSX_PROJ_MAP_RECORDS
 
 
 def _arr(ptrs: Sequence[Optional[int]]):
@@ -286,6 +287,7 @@ class RenderPlan:
         self.flat = self.tile_order = self.isect_ws = None
         # per-frame candidate set (gsx_front_candidates): enable_candidates() + build_candidates() per frame
         self.candidates = False
+        self.map_records = False
         self.cand_margins = (0.0, 0.0)
         # CU-balanced launch order (gsx_tile_balance): a render whose T workgroups are all resident at once (more than one
         # and at most five per CU) runs as long as its most loaded CU; enable_balance() makes the rasteriser launches follow
@@ -323,6 +325,20 @@ class RenderPlan:
         self.stale = True
 
     # ---- per-frame candidate set ---------------------------------------------------------------------------------------
+    def _cand_flags(self) -> int:
+        return (_CANDIDATES | (_MAP_RECORDS if self.map_records else 0)) if self.candidates else 0
+
+    def enable_map_records(self) -> bool:
+        """Pose-only plans on the fused front: ``build_candidates`` leaves the pose-independent record of EVERY Gaussian (mean,
+        world covariance, activated opacity / colour / beta: 64 bytes) and a packed cull row each in the workspace; the
+        closures keep their own cull and read one record per survivor (GSX_PROJ_MAP_RECORDS).  Valid for any pose; to be
+        rebuilt when the map's arrays change (the tracker does it once per frame: one pass over the map against 36 closures).
+        Results are identical to the plain path bit for bit.  -> whether this plan's shape qualifies."""
+        if not self.enable_candidates(0.0, 0.0):
+            return False
+        self.map_records = True
+        return True
+
     def enable_candidates(self, rot_max: float = 0.02, trans_max: float = 0.02) -> bool:
         """Pose-only plans on the fused front: closures read the candidate set that ``build_candidates`` leaves in the
         workspace (the Gaussians that can be visible from any pose within ``rot_max`` (|R R0^T - I|_F) and ``trans_max`` of the
@@ -355,7 +371,8 @@ class RenderPlan:
         st = current_stream_ptr(self.dev) if st is None else st
         m = self.map
         check(lib.gsx_front_candidates(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
-                                       self.H, self.eps2d, self.near, self.far, self.flags, _p(m[3]), _p(m[4]), _p(m[5]),
+                                       self.H, self.eps2d, self.near, self.far,
+                                       self.flags | (_MAP_RECORDS if self.map_records else 0), _p(m[3]), _p(m[4]), _p(m[5]),
                                        self.cand_margins[0], self.cand_margins[1], self.capacity, _p(self.isect_ws),
                                        self.isect_ws.numel(), st), "gsx_front_candidates")
 
@@ -487,8 +504,8 @@ class RenderPlan:
     def _front(self, st: int, defer_sort: bool = False):
         m = self.map
         lean = self.lean
-        flags = self.flags | (_SKIP_CULLED if lean else 0) | (_COMPACT if self.compact else 0) | (
-            _CANDIDATES if self.candidates else 0) | (_DEFER_SORT if defer_sort else 0)
+        flags = self.flags | (_SKIP_CULLED if lean else 0) | (_COMPACT if self.compact else 0) | self._cand_flags() | (
+            _DEFER_SORT if defer_sort else 0)
         check(lib.gsx_front_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                 self.H, self.eps2d, self.near, self.far, flags,
                                 _p(m[3]), _p(m[4]), _p(m[5]), None if self.compact else _p(self.radii),
@@ -500,7 +517,11 @@ class RenderPlan:
                                 _p(self.tile_work), _p(self.balanced_order), self.CHUNK_COST, self.LIGHT_RATE, self.n_cus,
                                 _p(self.isect_ws), self.isect_ws.numel(), st), "gsx_front_fwd")
 
-    CUT_MARGIN = 0.05       # next closure's depth cut-off of a tile = depth of its deepest composited entry * (1 + this)
+    # next closure's depth cut-off of a tile = depth of its deepest composited entry * (1 + this).  Measured on the headline
+    # sequence (tools/dbg/cut_prof.sh; 253 closures x 1200 tiles): 0.02 -> 10 % of the tiles need a second slab, 0.05 -> 3.9 %,
+    # 0.1 -> 1.4 %, 0.2 -> 0.4 %, 0.5 -> 0.01 %, while the keys sorted per closure grow from 17 % to 27 % of all; the fused launch
+    # reads 81.9 / 81.2 / 80.8 / 81.1 / 81.5 us at 0.05 / 0.1 / 0.2 / 0.3 / 0.5
+    CUT_MARGIN = 0.2
 
     def enable_defer_sort(self, margin: Optional[float] = None) -> bool:
         """Pose-only plans on the fused front whose closure runs gsx_raster_track_fused: the front stops after the placement and
@@ -629,8 +650,8 @@ class RenderPlan:
         if self.grads == 'pose' and self.front:
             check(lib.gsx_front_pose_bwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C,
                                          self.W, self.H, self.eps2d, self.near, self.far,
-                                         self.flags | reset | (_COMPACT if self.compact else 0) | (
-                                             _CANDIDATES if self.candidates else 0), vr, self.capacity,
+                                         self.flags | reset | (_COMPACT if self.compact else 0) | self._cand_flags(),
+                                         vr, self.capacity,
                                          _p(self.isect_ws), self.isect_ws.numel(), _p(self.pose_ws), st),
                   "gsx_front_pose_bwd")
             return
@@ -716,7 +737,7 @@ class TrackClosure:
     CAND_MARGINS = (0.02, 0.02)    # |R R0^T - I|_F (~0.8 degrees) and metres the closures of a frame may move from its first pose
 
     def __init__(self, splats, camera, tail: str = 'fused', fuse_raster: bool = True, front: Optional[bool] = None,
-                 candidates: bool = False, defer_sort: Optional[bool] = None):
+                 candidates: bool = False, defer_sort: Optional[bool] = None, map_records: Optional[bool] = None):
         """fuse_raster (fused tail only): forward rasteriser, loss and rasteriser backward as ONE launch
         (gsx_raster_track_fused); False keeps them as two (the independent path the tests compare against).
         candidates: per-frame candidate set for the closures' projection (gsx_front_candidates).  OFF by default - measured
@@ -724,6 +745,9 @@ class TrackClosure:
         lr-sized steps, the line search's trial points); margins that cover them make the candidate set as large as what
         the per-closure cull keeps (334 k of 500 k at 0.06 / 0.06 against ~170 k visible), and tighter ones send most
         closures to the full path.  Results are identical either way.
+        map_records: the pose-independent record of EVERY Gaussian, rebuilt once per frame (RenderPlan.enable_map_records):
+        the closures keep their own cull and read one 64-byte record per survivor; None = where it applies (fused front,
+        compact records) unless ``candidates`` was asked for.  Results are identical either way.
         defer_sort: the tile sort moves into the fused rasteriser launch (RenderPlan.enable_defer_sort); None = where it
         applies (fused tail + fused rasteriser + fused front)."""
         assert tail in ('fused', 'split', 'host')
@@ -753,6 +777,8 @@ class TrackClosure:
         # ONCE per frame, with margins (gsx_front_candidates), and the closures read that candidate set
         if candidates:
             self.r.enable_candidates(*self.CAND_MARGINS)
+        elif map_records is None or map_records:
+            self.r.enable_map_records()
         if (defer_sort is None or defer_sort) and self.fuse_raster:
             self.r.enable_defer_sort()
         self.stream = torch.cuda.Stream(device=dev)

@@ -66,6 +66,13 @@ extern "C" {
                                      candidate set of gsx_front_candidates; closures whose poses stay within its margins project
                                      the candidates' pose-independent records instead of culling all N Gaussians again - same
                                      results bit for bit, and a closure outside the margins takes the full path by itself */
+#define GSX_PROJ_MAP_RECORDS 512   /* with GSX_PROJ_CANDIDATES, to gsx_front_candidates / gsx_front_fwd / gsx_front_pose_bwd: the
+                                     candidate area holds the pose-independent record of EVERY Gaussian (slot = Gaussian
+                                     index; margins ignored) and a packed cull row (mean, largest scale squared) each.  Valid
+                                     for any pose until the map's arrays change.  Closures keep their own conservative cull
+                                     (one coalesced 16-byte load per Gaussian) and read one 64-byte record per survivor instead
+                                     of gathering 14 floats from five arrays and rebuilding the covariance - same results
+                                     bit for bit (the record's covariance is the same float expression) */
 
 int gsx_version(void);
 const char *gsx_last_error(void);

@@ -227,7 +227,7 @@ def test_refiner_after_eager_ba_and_prune(dev):
 
 
 @pytest.mark.parametrize("n,n_cams,grads", [(20000, 1, 'full'), (20000, 1, 'pose'), (9000, 3, 'full'), (300000, 1, 'pose'),
-                                            (37, 2, 'full')])
+                                            (37, 2, 'full'), (20001, 2, 'full'), (20001, 1, 'pose')])
 def test_fused_front_equals_projection_plus_bin_sort(dev, n, n_cams, grads):
     """gsx_front_fwd (projection + count rows + instance records, in-kernel offset scan, striped placement) against
     gsx_project_fwd + gsx_isect_bin_sort: every integer output bit for bit, and the render that follows"""
@@ -236,7 +236,11 @@ def test_fused_front_equals_projection_plus_bin_sort(dev, n, n_cams, grads):
     from gslam_amd.synthetic import make_cameras, make_scene
     W, H = 640, 480
     sc = make_scene(n, 5)
-    sc["scales"] = sc["scales"] + (0.3 if n <= 20000 else 0.0)
+    # (20001: Gaussians e^1.5 times larger and strongly anisotropic - many of them straddle the frustum's border, where the
+    # front's conservative cull (radius bound from the largest scale and |R|_2) must not drop what the exact projection keeps)
+    sc["scales"] = sc["scales"] + (0.3 if n <= 20000 else 1.5 if n == 20001 else 0.0)
+    if n == 20001:
+        sc["scales"][:, 0] += 1.0
     m = GaussianSplattingData.from_dict(sc, dev).no_grad_clone()
     viewmats, Ks = make_cameras(n_cams, W, H)
     plans = []
@@ -535,28 +539,34 @@ def _track_closure(dev, n, seed, candidates, W=640, H=480, scale_shift=0.0):
     cam = Camera(make_intrinsics(W, H).to(dev), H, W)
     # (full sorted lists are compared below: the stand-alone tile sort, not the one inside the rasteriser that sorts what it
     # composites - tested on its own in test_tile_sort_inside_the_rasteriser_equals_the_sort_launch)
-    return splats, TrackClosure(splats, cam, tail='fused', candidates=candidates, defer_sort=False)
+    # candidates: False = the plain path (culls the map arrays, rebuilds covariances), True = per-frame candidate set with
+    # margins, 'records' = records of the whole map + per-closure cull (the default of TrackClosure)
+    return splats, TrackClosure(splats, cam, tail='fused', candidates=candidates is True, defer_sort=False,
+                                map_records=candidates == 'records')
 
 
 @pytest.mark.parametrize("n,W,H,shift", [(60000, 640, 480, 0.3), (500000, 640, 480, 0.0), (9000, 320, 240, 0.8)])
 def test_candidate_set_closures_equal_full_path(dev, n, W, H, shift):
     """per-frame candidate set (gsx_front_candidates): closures that project the candidates' pose-independent records give the
     SAME tile lists, records and pose gradient, bit for bit, as closures that cull the whole map - at the frame's first pose,
-    at poses inside the margins, and (by falling back on their own) at a pose outside them"""
+    at poses inside the margins, and (by falling back on their own) at a pose outside them; and so do closures over the
+    records of the whole map (GSX_PROJ_MAP_RECORDS: their own cull from the packed cull rows, one record per survivor), which
+    are valid at every pose"""
     from gslam_amd.synthetic import make_viewmat
     res = {}
     g = torch.Generator().manual_seed(3)
     img = torch.rand(H, W, 3, generator=g).to(dev)
     deltas = [(0.0, 0.0), (0.004, 0.006), (0.012, 0.012), (0.2, 0.3)]        # the last one leaves the 0.02 / 0.02 margins
-    for cand in (False, True):
+    for cand in (False, True, 'records'):
         splats, c = _track_closure(dev, n, 5, cand, W, H, shift)
+        assert c.r.map_records == (cand == 'records') and c.r.candidates == (cand is not False)
         V0 = make_viewmat(2.5).to(dev)
         c.load(V0, img, torch.zeros(2, device=dev))
         c.prepare()
         c.load(V0, img, torch.zeros(2, device=dev))
         if cand:
             n_cand, _, _ = c.r.candidate_stats()
-            assert 0 < n_cand < n
+            assert (0 < n_cand < n) if cand is True else n_cand == n
         out = []
         for k, (dr, dtr) in enumerate(deltas):
             # move the slot's pose (dR / dt of PoseZhou) and re-evaluate through the captured closure; the optimiser's step is
@@ -576,11 +586,11 @@ def test_candidate_set_closures_equal_full_path(dev, n, W, H, shift):
                         c.r.pose_ws.clone()[:c.r.pose_blocks * 12 * 4], c.loss_rows.clone()))
             if cand:
                 _, mode, fell_back = c.r.candidate_stats()
-                assert mode == (1 if k < 3 else 0), (k, mode)
-                assert fell_back == (0 if k < 3 else 1)
+                assert mode == (1 if k < 3 or cand == 'records' else 0), (k, mode)
+                assert fell_back == (0 if k < 3 or cand == 'records' else 1)
         res[cand] = out
-    for k in range(len(deltas)):
-        a, b = res[False][k], res[True][k]
+    for other, k in [(o, k) for o in (True, 'records') for k in range(len(deltas))]:
+        a, b = res[False][k], res[other][k]
         assert a[0] == b[0] > 0
         assert torch.equal(a[1], b[1])                       # the same slots in the same order: tile lists bit-exact
         assert torch.equal(a[2], b[2])                       # ... naming the same (camera, Gaussian) pairs

@@ -376,5 +376,7 @@ def test_warp_640x480_matches_the_fixture_pinned_torch_formulation(dev):
     e_hip = max(float((f1.grad.double() - t1.grad).abs().max()), float((f2.grad.double() - t2.grad).abs().max())) / scale
     e_f32 = max(float((u1.grad.double() - t1.grad).abs().max()), float((u2.grad.double() - t2.grad).abs().max())) / scale
     print(f"warp 640x480 pose gradients against float64: HIP {e_hip:.2e}, torch float32 autograd {e_f32:.2e} (of the largest entry)")
-    assert e_hip < 1e-3, (e_hip, e_f32)
+    # measured: HIP 6.8e-3, torch float32 autograd 1.5e-2 (pixels whose keep bit differs between float32 and float64 enter or
+    # leave the sum): the bar is the float32 autograd of the same formulation, not float64 round-off
+    assert e_hip < 2e-2 and e_hip <= 1.5 * e_f32 + 1e-3, (e_hip, e_f32)
     assert float(t2.grad[3].abs().max()) > 1.0
