@@ -706,3 +706,54 @@ def test_tile_sort_inside_the_rasteriser_equals_the_sort_launch(dev, n_gauss, sc
     assert stats[0] >= int((near2 > 0).sum()) * 0.9, stats
     assert (near3 > 0).sum() >= (near2 > 0).sum() * 0.9
     assert stats[1] == 0, stats                                                       # nothing went through memory
+
+
+def test_tile_sort_inside_the_rasteriser_with_piles_of_equal_depths(dev):
+    """the slow path of the sort inside the rasteriser: thousands of Gaussians on ONE plane perpendicular to the optical axis have
+    the same depth bits, no depth window can cut such a pile down to what the LDS sort takes, and the tile's workgroup falls back
+    to the merge sort through memory (sort_stats[1] counts those tiles).  Ties are broken by id in both implementations: the
+    consumed prefix is still the stand-alone sort's list entry for entry, and so are loss rows and gradient records.  A second
+    closure (cut-offs of the first = the one depth there is) and an almost transparent variant (pixels never saturate: the whole
+    pile is composited) take the same path."""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.plan import TrackClosure, current_stream_ptr
+    from gslam_amd.primitives import Camera
+    from gslam_amd.synthetic import make_intrinsics, make_scene
+    W, H = 640, 480
+    for opac_shift in (0.0, -3.0):
+        sc = make_scene(150000, 9)
+        g = torch.Generator().manual_seed(4)
+        sc["means"][:, 0] = (torch.rand(150000, generator=g) - 0.5) * 4.0
+        sc["means"][:, 1] = (torch.rand(150000, generator=g) - 0.5) * 3.0
+        sc["means"][:, 2] = 0.0                                     # one plane ...
+        sc["scales"] = sc["scales"] + 0.9
+        sc["opacities"] = sc["opacities"] + opac_shift
+        splats = GaussianSplattingData.from_dict(sc, dev)
+        cam = Camera(make_intrinsics(W, H).to(dev), H, W)
+        V = torch.eye(4)
+        V[2, 3] = 3.0                                               # ... seen head-on from 3 m: every depth is exactly 3.0
+        img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(8)).to(dev)
+        st = current_stream_ptr(dev)
+        ref = TrackClosure(splats, cam, defer_sort=False)
+        new = TrackClosure(splats, cam, defer_sort=True)
+        for c in (ref, new):
+            c.load(V.to(dev), img, torch.zeros(2, device=dev))
+            c.r.probe()
+        a = _fused_closure_outputs(ref, st, H, W)
+        off = a[4].cpu().numpy()
+        sizes = off[1:] - off[:-1]
+        assert sizes.max() > 1152, sizes.max()
+        for closure in range(2):
+            new.r.sort_stats.zero_()
+            b = _fused_closure_outputs(new, st, H, W)
+            stats = new.r.sort_stats.cpu().tolist()
+            assert stats[1] > 0, stats                              # piles went through the memory merge sort
+            assert torch.equal(a[4], b[4])
+            near = new.r.tile_near.cpu().numpy()
+            fa, fb = a[3].cpu().numpy(), b[3].cpu().numpy()
+            for t in range(new.r.T):
+                lo, n = int(off[t]), int(near[t])
+                assert 0 <= n <= sizes[t]
+                assert (fa[lo:lo + n] == fb[lo:lo + n]).all(), f"closure {closure}: tile {t}: sorted part differs from the full list"
+            assert float((a[0] - b[0]).abs().max()) <= 2e-6 * float(a[0].abs().max()) + 1e-12
+            assert float((a[2] - b[2]).abs().max()) <= 1e-4 * float(a[2].abs().max()) + 1e-12
