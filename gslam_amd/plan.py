@@ -146,7 +146,13 @@ _PLACEMENT_FAILS: Dict[tuple, int] = {}
 PLACEMENT_RETRIES = 3       # a failed probe is repeated by later plans this many times before the verdict sticks
 
 
-def placement_ok(dev, n_wgs: int, n_cus: int, lds_bytes: int = 25 * 1024):
+# LDS of a workgroup of the fused tracking rasteriser (raster_track_fused_kernel<12, true>: 29 856 bytes of static LDS, read off
+# the code object; 5 workgroups per CU): what the placement probe's workgroups allocate, so that they are placed like the
+# launches whose order the probe vouches for
+RASTER_LDS_BYTES = 29856
+
+
+def placement_ok(dev, n_wgs: int, n_cus: int, lds_bytes: int = RASTER_LDS_BYTES):
     """Does workgroup i of an ``n_wgs``-workgroup launch (256 threads, the rasteriser's LDS footprint, all resident at once)
     share its compute unit with workgroups i + G, i + 2 G, ... on this device?  The CU-balanced launch order
     (csrc/tile_balance.h) deals the tiles into G groups on that assumption - an undocumented property of the dispatcher,
