@@ -1390,17 +1390,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
         if (use_cand) {
             if (active) {
                 const float4 *src = reinterpret_cast<const float4 *>(a.cand + cslot);
-#if defined(GSX_DBG_FRONT) && GSX_DBG_FRONT == 1      // timing experiment only: no record load at all
-                const float4 r0 = make_float4((float)(si & 63) / 64.f - 0.5f, (float)((si >> 6) & 15) / 16.f - 0.5f, 3.f, 1e-4f);
-                const float4 r1 = make_float4(0.f, 0.f, 1e-4f, 0.f), r2 = make_float4(1e-4f, 0.5f, 0.5f, 0.5f);
-                const float4 r3 = make_float4(0.5f, 0.f, __int_as_float((int)(g0 + s_list[si])), 0.f);
-#elif defined(GSX_DBG_FRONT) && GSX_DBG_FRONT == 2    // timing experiment only: the first 16 bytes of the record
-                const float4 r0 = src[0];
-                const float4 r1 = make_float4(0.f, 0.f, 1e-4f, 0.f), r2 = make_float4(1e-4f, 0.5f, 0.5f, 0.5f);
-                const float4 r3 = make_float4(0.5f, 0.f, __int_as_float((int)(g0 + s_list[si])), 0.f);
-#else
                 const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-#endif
                 mean[0] = r0.x; mean[1] = r0.y; mean[2] = r0.z;
                 S.a00 = r0.w; S.a01 = r1.x; S.a02 = r1.y; S.a11 = r1.z; S.a12 = r1.w; S.a22 = r2.x;
                 opac = r2.y; col[0] = r2.z; col[1] = r2.w; col[2] = r3.x; beta = r3.y;

@@ -42,7 +42,7 @@ def main():
     setter = lib.gsx_debug_front_trace
     setter.argtypes, setter.restype = [C.c_void_p], C.c_int
     assert setter(buf.data_ptr()) == 0
-    if os.environ.get("FRONT_ONLY"):
+    if os.environ.get("FRONT_ONLY"):                     # the two front kernels alone (no rasteriser behind them)
         for _ in range(3):
             tr.plan.r._front(st, defer_sort=True)
         torch.cuda.synchronize()
