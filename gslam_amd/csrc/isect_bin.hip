@@ -465,9 +465,9 @@ __global__ __launch_bounds__(FINE_THREADS) void fine_place_kernel(const PreRec *
 constexpr int RUN0 = 64;
 
 // one rank-merge level: runs of length `run` in src[0..n) -> runs of 2*run in dst
-template <typename Ptr>
+template <typename Ptr, int TH = SORT_THREADS>
 __device__ __forceinline__ void merge_level(Ptr src, Ptr dst, int n, int run) {
-    for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
+    for (int i = threadIdx.x; i < n; i += TH) {
         const unsigned long long k = src[i];
         const int r = i / run;
         const int own = r * run, pair = (r & ~1) * run;
@@ -486,15 +486,16 @@ __device__ __forceinline__ void merge_level(Ptr src, Ptr dst, int n, int run) {
 }
 
 // sorts n <= cap keys read from `in` (global); returns the LDS buffer that holds the sorted keys
+template <int TH = SORT_THREADS>
 __device__ __forceinline__ unsigned long long *lds_sort(const unsigned long long *__restrict__ in, int n,
                                                         unsigned long long *bufA, unsigned long long *bufB) {
     const unsigned long long INF = ~0ull >> 1;            // larger than any key, still < 2^63
     const int n_pad = (n + RUN0 - 1) / RUN0 * RUN0;       // <= cap (cap is a multiple of 64)
     unsigned long long *src = bufA, *dst = bufB;
     __syncthreads();                                       // callers may still be reading the buffers
-    for (int i = threadIdx.x; i < n_pad; i += SORT_THREADS) src[i] = (i < n) ? in[i] : INF;
+    for (int i = threadIdx.x; i < n_pad; i += TH) src[i] = (i < n) ? in[i] : INF;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
+    for (int i = threadIdx.x; i < n; i += TH) {
         const unsigned long long k = src[i];
         const int cb = i & ~(RUN0 - 1);
         const ulonglong2 *s2 = reinterpret_cast<const ulonglong2 *>(src + cb);
@@ -509,7 +510,7 @@ __device__ __forceinline__ unsigned long long *lds_sort(const unsigned long long
     __syncthreads();
     { unsigned long long *t = src; src = dst; dst = t; }
     for (int run = RUN0; run < n; run <<= 1) {
-        merge_level(src, dst, n, run);
+        merge_level<unsigned long long *, TH>(src, dst, n, run);
         __syncthreads();
         unsigned long long *t = src; src = dst; dst = t;
     }
@@ -542,9 +543,9 @@ constexpr int BIG_NB = 4096;          // buckets, streaming regime
 constexpr int BIG_MAX_BUCKET = 256;
 
 // exclusive scan of s_cur[0..NB) in place (NB = PER * SORT_THREADS); returns true if some count exceeds `limit`
-template <int NB>
+template <int NB, int TH = SORT_THREADS>
 __device__ __forceinline__ bool bucket_scan(int *s_cur, int *s_wtot, int limit) {
-    constexpr int PER = NB / SORT_THREADS;
+    constexpr int PER = NB / TH;
     const int t = threadIdx.x;
     int cnt[PER];
     int v = 0, big = 0;
@@ -568,18 +569,19 @@ __device__ __forceinline__ bool bucket_scan(int *s_cur, int *s_wtot, int limit) 
 
 // merge sort of one tile with a `cap`-key LDS window (2 * cap keys of LDS at s_mem): chunks sorted in LDS and written
 // back in place, remaining levels through global memory.  Returns where the sorted keys are (LDS or global).
+template <int TH = SORT_THREADS>
 __device__ __forceinline__ const unsigned long long *merge_sort_tile(unsigned long long *seg, unsigned long long *scr,
                                                                      int n, unsigned long long *s_mem, int cap) {
-    if (n <= cap) return lds_sort(seg, n, s_mem, s_mem + cap);
+    if (n <= cap) return lds_sort<TH>(seg, n, s_mem, s_mem + cap);
     for (int cb = 0; cb < n; cb += cap) {
         const int len = min(cap, n - cb);
-        const unsigned long long *res = lds_sort(seg + cb, len, s_mem, s_mem + cap);
-        for (int i = threadIdx.x; i < len; i += SORT_THREADS) seg[cb + i] = res[i];
+        const unsigned long long *res = lds_sort<TH>(seg + cb, len, s_mem, s_mem + cap);
+        for (int i = threadIdx.x; i < len; i += TH) seg[cb + i] = res[i];
     }
     __syncthreads();
     unsigned long long *src = seg, *dst = scr;
     for (int run = cap; run < n; run <<= 1) {
-        merge_level(src, dst, n, run);
+        merge_level<unsigned long long *, TH>(src, dst, n, run);
         __syncthreads();
         unsigned long long *t = src; src = dst; dst = t;
     }
@@ -763,6 +765,220 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_count_kernel(unsigned 
     }
 }
 
+// ---- 4c. per-tile sort of DEEP lists -----------------------------------------------------------------------------------
+// tile_sort_count_kernel keeps 2048 keys in LDS; a longer list goes through memory three more times (histogram pass, scatter
+// into the scratch copy grouped by bucket - 8-byte stores to 4096 moving cursors, partial lines - and the windows that read it
+// back): 52 bytes per key counted at 5 M Gaussians / 1080p (8000-10400 keys per tile), 0.79 of the render's 3.2 ms.  A
+// workgroup may use all 160 KiB of a CU's LDS.  Here the keys are staged ONCE (8 bytes each) and what moves afterwards are
+// 16-bit indices into the staged keys: grouped by depth bucket, then ranked inside the bucket, then read out in order - 12
+// bytes of LDS per key, so a list of up to 12160 keys is read from memory once and leaves as ids (12 bytes of traffic per key).
+// A longer list is histogrammed once and then cut into depth windows of at most CAP keys; each window re-reads the segment and
+// stages its own keys (8 bytes per key and window; no scatter through memory, nothing written but the ids).  Same order as
+// tile_sort_count_kernel: monotone depth -> bucket map, exact (depth, id) rank inside a bucket; piles of equal depths fall back
+// to the merge sort (in an LDS window of CAP / 2 keys).  1024 threads: every phase is a chain of LDS round trips, and one
+// workgroup is all a CU holds.  Measured at 5 M / 1080p (tools/dbg/sort_trace.py, us per tile): load 6.2, histogram 1.1, scan
+// 1.5, grouping 2.2, rank 7.0, read-out 1.8; 789 -> 520 us for the launch.  Tried on top and not kept: the tile's keys held in
+// registers through histogram and grouping (same time), keys instead of indices in the grouped array with the staging buffer
+// dropped and the rank / read-out steps in lock step over four keys (620 us: 128 registers per thread, spills), persistent
+// workgroups that request the next tile's keys while they sort (load 6.2 -> 1.1 us per tile, launch 590-630 us: the
+// hardware's own dispatch of 8160 workgroups overlaps their phases better), two workgroups of 6400 keys per CU (765-900 us:
+// two windows per tile).
+constexpr int DEEP_NB = 4096;
+constexpr int DEEP_MAX_BUCKET = 256;
+constexpr int DEEP_THREADS = 1024;
+constexpr int DEEP_LOADS = 12;                                                // keys a thread has in flight while it stages / filters
+#ifndef GSX_DEEP_LO_FROM
+#define GSX_DEEP_LO_FROM 2048
+#endif
+#ifndef GSX_DEEP_HI_FROM
+#define GSX_DEEP_HI_FROM 3500
+#endif
+constexpr int DEEP_CAP_LO = 5376, DEEP_CAP_HI = 12160;                        // LDS: 79 KiB (two workgroups per CU) / 159 KiB
+constexpr int64_t DEEP_CAP_LO_FROM = GSX_DEEP_LO_FROM, DEEP_CAP_HI_FROM = GSX_DEEP_HI_FROM;   // list capacity per tile from which each is used
+
+// DIAGNOSTIC build only (-DGSX_WG_TRACE, tools/dbg/sort_trace.py): thread 0 of the first 4096 workgroups stamps s_memrealtime
+// (100 MHz) at the phase boundaries.  Nothing of this is compiled into the product library.
+#ifdef GSX_WG_TRACE
+__device__ unsigned long long *g_sort_trace = nullptr;         // [4096 workgroups][8 stamps]
+#define GSX_ST(k)                                                                                                          \
+    if (g_sort_trace && threadIdx.x == 0 && blockIdx.x < 4096) g_sort_trace[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();
+}  // namespace
+extern "C" int gsx_debug_sort_trace(void *buffer) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sort_trace), &buffer, sizeof(buffer)) == hipSuccess ? 0 : 1;
+}
+namespace {
+#else
+#define GSX_ST(k)
+#endif
+
+template <int CAP>
+__global__ __launch_bounds__(DEEP_THREADS) void tile_sort_deep_kernel(unsigned long long *__restrict__ entries,
+                                                                      unsigned long long *__restrict__ scratch,
+                                                                      const int32_t *__restrict__ offsets, int n_tiles,
+                                                                      int tile_n_bits, int64_t M_cap, uint32_t id_max,
+                                                                      int64_t *__restrict__ isect_ids,
+                                                                      int32_t *__restrict__ flatten_ids) {
+    static_assert(CAP % 128 == 0 && CAP < 65536 && 12 * CAP + 4 * DEEP_NB + 256 <= 163840, "keys, two index arrays, cursors: one CU's LDS");
+    __shared__ __attribute__((aligned(16))) unsigned long long s_a[CAP];     // staged keys
+    __shared__ unsigned short s_g[CAP];                                       // indices into s_a, grouped by bucket
+    __shared__ unsigned short s_o[CAP];                                       // indices into s_a, in sorted order
+    __shared__ int s_cur[DEEP_NB];
+    __shared__ unsigned int s_red[2 * (DEEP_THREADS / 64)];
+    __shared__ int s_wtot[DEEP_THREADS / 64];
+    __shared__ int s_n;
+    const int tile = blockIdx.x;
+    const int t = threadIdx.x;
+    const int64_t start = max((int64_t)0, min((int64_t)offsets[tile], M_cap));
+    const int64_t end = max((int64_t)0, min((int64_t)offsets[tile + 1], M_cap));
+    const int n = (int)(end - start);
+    if (n <= 0) return;
+    const int c = tile / n_tiles, tl = tile - c * n_tiles;
+    const long long hi_part = ((long long)c << (32 + tile_n_bits)) | ((long long)tl << 32);
+    unsigned long long *seg = entries + start;
+    auto emit = [&](int64_t o, unsigned long long k) {
+        flatten_ids[o] = (int32_t)min((uint32_t)k, id_max);  // never hand an out-of-range gather index on
+        if (isect_ids) isect_ids[o] = hi_part | (long long)(k >> 32);
+    };
+    const bool fits = n <= CAP;
+    GSX_ST(0)
+    // 1. range of the depth bits; a list that fits is staged on the way (the only time its keys are read).  DEEP_LOADS keys
+    // per thread are requested before the first is used: one workgroup per CU has nobody to hide a memory round trip behind
+    unsigned int dmin = 0xffffffffu, dmax = 0u;
+    if (fits) {
+        for (int i0 = 0; i0 < n; i0 += DEEP_LOADS * DEEP_THREADS) {
+            unsigned long long kk[DEEP_LOADS];
+#pragma unroll
+            for (int q = 0; q < DEEP_LOADS; ++q) {
+                const int i = i0 + q * DEEP_THREADS + t;
+                kk[q] = (i < n) ? seg[i] : 0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < DEEP_LOADS; ++q) {
+                const int i = i0 + q * DEEP_THREADS + t;
+                if (i < n) {
+                    s_a[i] = kk[q];
+                    const unsigned int d = (unsigned int)(kk[q] >> 32);
+                    dmin = min(dmin, d); dmax = max(dmax, d);
+                }
+            }
+        }
+    } else {
+        // one block in four is sampled for the range: keys outside it clamp to the end buckets (the map stays monotone)
+#pragma unroll 4
+        for (int i = t; i < n; i += 4 * DEEP_THREADS) {
+            const unsigned int d = (unsigned int)(seg[i] >> 32);
+            dmin = min(dmin, d); dmax = max(dmax, d);
+        }
+    }
+    for (int i = t; i < DEEP_NB; i += DEEP_THREADS) s_cur[i] = 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dmin = min(dmin, (unsigned int)__shfl_xor((int)dmin, off, 64));
+        dmax = max(dmax, (unsigned int)__shfl_xor((int)dmax, off, 64));
+    }
+    if ((t & 63) == 0) { s_red[t >> 6] = dmin; s_red[DEEP_THREADS / 64 + (t >> 6)] = dmax; }
+    __syncthreads();
+    GSX_ST(1)
+    dmin = 0xffffffffu; dmax = 0u;
+#pragma unroll
+    for (int w = 0; w < DEEP_THREADS / 64; ++w) { dmin = min(dmin, s_red[w]); dmax = max(dmax, s_red[DEEP_THREADS / 64 + w]); }
+    const float fmin_ = __uint_as_float(dmin), fmax_ = __uint_as_float(dmax);
+    const float range = fmax_ - fmin_;
+    const float scale = (range > 0.0f) ? (float)(DEEP_NB - 1) / range : 0.0f;
+    auto bucket_of = [&](unsigned long long k) -> int {
+        const float d = __uint_as_float((unsigned int)(k >> 32));
+        const int b = (int)((d - fmin_) * scale);
+        return min(max(b, 0), DEEP_NB - 1);
+    };
+    // 2. histogram over the whole list, exclusive scan: s_cur[b] = keys in the buckets before b
+    if (fits) {
+        for (int i = t; i < n; i += DEEP_THREADS) atomicAdd(&s_cur[bucket_of(s_a[i])], 1);
+    } else {
+        for (int i0 = 0; i0 < n; i0 += DEEP_LOADS * DEEP_THREADS) {
+            unsigned long long kk[DEEP_LOADS];
+#pragma unroll
+            for (int q = 0; q < DEEP_LOADS; ++q) {
+                const int i = i0 + q * DEEP_THREADS + t;
+                kk[q] = (i < n) ? seg[i] : ~0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < DEEP_LOADS; ++q)
+                if (i0 + q * DEEP_THREADS + t < n) atomicAdd(&s_cur[bucket_of(kk[q])], 1);
+        }
+    }
+    __syncthreads();
+    GSX_ST(2)
+    const bool piles = bucket_scan<DEEP_NB, DEEP_THREADS>(s_cur, s_wtot, DEEP_MAX_BUCKET);
+    GSX_ST(3)
+    if (piles) {                                                 // piles of equal depths: merge sort, its two buffers in s_a
+        const unsigned long long *sorted = merge_sort_tile<DEEP_THREADS>(seg, scratch + start, n, s_a, CAP / 2);
+        for (int i = t; i < n; i += DEEP_THREADS) emit(start + i, sorted[i]);
+        return;
+    }
+    // 3. windows of whole buckets [b0, b1) holding at most CAP keys.  The returning cursor of a bucket starts at the number of
+    // keys before the bucket and ends at the next bucket's start; positions inside the window = cursor value - ws
+    int b0 = 0;
+    while (b0 < DEEP_NB) {
+        const int ws = s_cur[b0];                                    // keys before the window (bucket b0 is untouched so far)
+        if (ws >= n) break;
+        int b1;
+        if (fits) {
+            b1 = DEEP_NB;
+        } else {
+            int lo = b0 + 1, hi = DEEP_NB;                           // largest b1 with (keys before b1) - ws <= CAP
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                const int upto = (mid < DEEP_NB) ? s_cur[mid] : n;
+                if (upto - ws <= CAP) lo = mid; else hi = mid - 1;
+            }
+            b1 = lo;
+        }
+        const int len = ((b1 < DEEP_NB) ? s_cur[b1] : n) - ws;
+        if (t == 0) s_n = 0;
+        __syncthreads();                                             // every thread has read the window's bounds
+        if (fits) {
+            for (int i = t; i < n; i += DEEP_THREADS)
+                s_g[atomicAdd(&s_cur[bucket_of(s_a[i])], 1)] = (unsigned short)i;
+        } else {
+            for (int i0 = 0; i0 < n; i0 += DEEP_LOADS * DEEP_THREADS) {
+                unsigned long long kk[DEEP_LOADS];
+#pragma unroll
+                for (int q = 0; q < DEEP_LOADS; ++q) {
+                    const int i = i0 + q * DEEP_THREADS + t;
+                    kk[q] = (i < n) ? seg[i] : ~0ull;
+                }
+#pragma unroll
+                for (int q = 0; q < DEEP_LOADS; ++q) {
+                    const int b = bucket_of(kk[q]);
+                    if (i0 + q * DEEP_THREADS + t < n && b >= b0 && b < b1) {
+                        const int slot = atomicAdd(&s_n, 1);         // where the key is staged (any order)
+                        s_a[slot] = kk[q];
+                        s_g[atomicAdd(&s_cur[b], 1) - ws] = (unsigned short)slot;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        GSX_ST(4)
+        for (int p = t; p < len; p += DEEP_THREADS) {
+            const int i = s_g[p];
+            const unsigned long long k = s_a[i];
+            const int b = bucket_of(k);
+            const int bs = (b > b0 ? s_cur[b - 1] : ws) - ws, be = s_cur[b] - ws;
+            int rank = 0;
+#pragma unroll 4
+            for (int j = bs; j < be; ++j) rank += (s_a[s_g[j]] < k) ? 1 : 0;
+            s_o[bs + rank] = (unsigned short)i;
+        }
+        __syncthreads();
+        GSX_ST(5)
+        for (int p = t; p < len; p += DEEP_THREADS) emit(start + ws + p, s_a[s_o[p]]);
+        __syncthreads();
+        GSX_ST(6)
+        b0 = b1;
+    }
+}
+
 int bit_length(uint32_t v) {
     int n = 0;
     while (v) { ++n; v >>= 1; }
@@ -908,8 +1124,18 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
         // regime from its tile's size (counting sort in LDS, streamed counting sort, merge sort for degenerate depths)
         const uint32_t id_max = (uint32_t)(C * N - 1);
         const int tnb = bit_length((uint32_t)n_tiles);
-        hipLaunchKernelGGL(tile_sort_count_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, scratch,
-                           offsets, (int)n_tiles, tnb, M_cap, id_max, isect_ids, flatten_ids);
+        // lists deeper than the 2048 keys tile_sort_count_kernel holds in LDS (judged by the capacity per tile - the sizes
+        // themselves are only known on the device): the kernels with a 4032- / 9152-key window (two / one workgroup per CU)
+        const int64_t per_tile = M_cap / (T > 0 ? T : 1);
+        if (per_tile > DEEP_CAP_HI_FROM)
+            hipLaunchKernelGGL(tile_sort_deep_kernel<DEEP_CAP_HI>, dim3((unsigned)T), dim3(DEEP_THREADS), 0, st, entries,
+                               scratch, offsets, (int)n_tiles, tnb, M_cap, id_max, isect_ids, flatten_ids);
+        else if (per_tile > DEEP_CAP_LO_FROM)
+            hipLaunchKernelGGL(tile_sort_deep_kernel<DEEP_CAP_LO>, dim3((unsigned)T), dim3(DEEP_THREADS), 0, st, entries,
+                               scratch, offsets, (int)n_tiles, tnb, M_cap, id_max, isect_ids, flatten_ids);
+        else
+            hipLaunchKernelGGL(tile_sort_count_kernel, dim3((unsigned)T), dim3(SORT_THREADS), 0, st, entries, scratch,
+                               offsets, (int)n_tiles, tnb, M_cap, id_max, isect_ids, flatten_ids);
         GSX_CHECK_LAUNCH();
     }
     return GSX_OK;
