@@ -787,11 +787,14 @@ constexpr int DEEP_NB = 4096;
 constexpr int DEEP_MAX_BUCKET = 256;
 constexpr int DEEP_THREADS = 1024;
 constexpr int DEEP_LOADS = 12;                                                // keys a thread has in flight while it stages / filters
+// Thresholds on the list CAPACITY per tile (plans size it at 1.5 x the probed lists): the 8-keyframe BA window of the headline
+// has 1500 keys per tile and a capacity of 2230 - tile_sort_count_kernel (three 512-thread workgroups per CU, most lists in its
+// 2048-key window) sorts it in 71 us, the 5376-key kernel in 123
 #ifndef GSX_DEEP_LO_FROM
-#define GSX_DEEP_LO_FROM 2048
+#define GSX_DEEP_LO_FROM 3500
 #endif
 #ifndef GSX_DEEP_HI_FROM
-#define GSX_DEEP_HI_FROM 3500
+#define GSX_DEEP_HI_FROM 5500
 #endif
 constexpr int DEEP_CAP_LO = 5376, DEEP_CAP_HI = 12160;                        // LDS: 79 KiB (two workgroups per CU) / 159 KiB
 constexpr int64_t DEEP_CAP_LO_FROM = GSX_DEEP_LO_FROM, DEEP_CAP_HI_FROM = GSX_DEEP_HI_FROM;   // list capacity per tile from which each is used
