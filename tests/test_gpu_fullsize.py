@@ -392,3 +392,39 @@ def test_crops_of_the_two_largest_configs_against_the_live_oracle(dev, oracle32)
         assert l1 < 1e-4 and la < 1e-4 and l1d < 1e-3, (n, l1, l1d, la)
         del out, sc
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n,left_share,depth_mode", [(220_000, 0.5, "spread"), (70_000, 0.5, "ties"), (35_000, 0.75, "spread"),
+                                                     (70_000, 0.5, "piles"), (36_000, 0.75, "piles")])
+def test_deep_tile_lists_one_pass_sort(dev, oracle32, n, left_share, depth_mode):
+    """tile_sort_deep_kernel (lists of more than 2048 keys, chosen by the list capacity per tile): a 64x48 image is 12 tiles, so
+    a few ten thousand small Gaussians give lists of 3000-35000 keys - the 12160-key kernel with one window (70 k), with
+    three depth windows that re-read the segment (220 k), the 5376-key kernel with lists on both sides of its window (35 k,
+    three quarters of them in the left half of the image), runs of equal depths inside a bucket ("ties") and piles of equal
+    depths that send a list to the merge sort in half the window ("piles") - against the oracle, bit for bit"""
+    from gslam_amd import ops
+    g = torch.Generator().manual_seed(11)
+    W, H, tw, th = 64, 48, 4, 3
+    m2d = torch.rand(1, n, 2, generator=g) * torch.tensor([float(W), float(H)])
+    n_left = int(n * left_share)
+    m2d[0, :n_left, 0] *= 0.5                                        # that share of the Gaussians in the left half
+    m2d[0, n_left:, 0] = 0.5 * W + 0.5 * m2d[0, n_left:, 0]
+    radii = torch.full((1, n), 3, dtype=torch.int32)
+    dep = torch.rand(1, n, generator=g) * 5 + 0.5
+    if depth_mode == "ties":
+        dep[0, 1000:1400] = dep[0, 1000]                             # 400 equal depths: one bucket, ranked by id
+        dep[0, 5000:5040] = dep[0, 5000]
+    elif depth_mode == "piles":
+        dep[0, : n // 2] = 2.5                                       # half of every list at one depth: no depth window can cut it
+    tpg, ids, flat = ops.isect_tiles(m2d.to(dev), radii.to(dev), dep.to(dev), 16, tw, th)
+    otpg, oids, oflat = oracle32.isect_tiles(m2d.numpy(), radii.numpy(), dep.numpy(), 16, tw, th)
+    per_tile = np.bincount(((oids >> 32) & 15).astype(np.int64), minlength=12)
+    cap_per_tile = len(oids) // 12
+    if n >= 70_000:
+        assert cap_per_tile > 5500                                   # the 12160-key kernel
+        assert (per_tile.max() > 12160) == (n >= 220_000)
+    else:
+        assert 3500 < cap_per_tile <= 5500                           # the 5376-key kernel
+        assert per_tile.max() > 5376 > per_tile.min()
+    assert np.array_equal(tpg.cpu().numpy(), otpg)
+    assert np.array_equal(ids.cpu().numpy(), oids) and np.array_equal(flat.cpu().numpy(), oflat)
