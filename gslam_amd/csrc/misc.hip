@@ -85,20 +85,38 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
 // way.  DEG is a template parameter so that basis, coefficients and accumulators are registers, not scratch.
 constexpr int SH_BLOCK = 256;
 
+// Staging of the coefficient rows of a workgroup's 256 Gaussians, ONLY of those some camera sees (radii > 0): nobody reads the
+// others - two thirds of a 5 M map are outside a 1080p frustum, 640 of the 960 MB of coefficient rows.  Every wavefront stages
+// the 64 rows its own lanes consume: the ballot of the lanes' visibility is the list of rows, one 192-byte load (48 lanes) per
+// visible row, all of them independent.  (A per-element test inside the streaming copy - a division and a flag read per float -
+// made both SH kernels twice as slow as reading everything.)
 template <int DEG>
-__device__ __forceinline__ void sh_stage_in(const float *__restrict__ coeffs, int64_t g0, int rows, int Kc,
-                                            float *s_rows) {
+__device__ __forceinline__ void sh_stage_in(const float *__restrict__ coeffs, const int32_t *__restrict__ radii, int64_t g0,
+                                            int64_t N, int C, int Kc, float *s_rows) {
     constexpr int NBC = (DEG + 1) * (DEG + 1) * 3, PITCH = NBC | 1;
-    const float *src = coeffs + g0 * Kc * 3;
-    const int total = rows * Kc * 3;
-    if (Kc * 3 == NBC) {
-        for (int i = threadIdx.x; i < total; i += SH_BLOCK) s_rows[(i / NBC) * PITCH + (i % NBC)] = src[i];
-    } else {
-        const int rl = Kc * 3;
-        for (int i = threadIdx.x; i < total; i += SH_BLOCK) {
-            const int r = i / rl, col = i - r * rl;
-            if (col < NBC) s_rows[r * PITCH + col] = src[i];
+    const int lane = threadIdx.x & 63, w0 = threadIdx.x & ~63;
+    const int64_t g = g0 + threadIdx.x;
+    bool vis = g < N;
+    if (vis && radii) {
+        vis = false;
+        for (int c = 0; c < C; ++c) vis = vis || radii[(int64_t)c * N + g] > 0;
+    }
+    unsigned long long m = __ballot(vis);
+    const float *src = coeffs + (g0 + w0) * (int64_t)Kc * 3;
+    constexpr int U = 32;                                    // rows in flight per wavefront (one load each)
+    while (m != 0ull) {
+        int j[U];
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            j[u] = (m != 0ull) ? __ffsll((long long)m) - 1 : -1;
+            m &= m - 1ull;                                   // (0 & anything = 0: stays empty once it is)
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (j[u] >= 0 && lane < NBC) ? src[(int64_t)j[u] * Kc * 3 + lane] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (j[u] >= 0 && lane < NBC) s_rows[(w0 + j[u]) * PITCH + lane] = v[u];
     }
 }
 
@@ -113,8 +131,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(const float *__restric
     constexpr int NB = (DEG + 1) * (DEG + 1), NBC = NB * 3, PITCH = NBC | 1;
     __shared__ float s_rows[SH_BLOCK * PITCH];
     const int64_t g0 = (int64_t)blockIdx.x * SH_BLOCK;
-    const int rows = (int)min((int64_t)SH_BLOCK, N - g0);
-    sh_stage_in<DEG>(coeffs, g0, rows, Kc, s_rows);
+    sh_stage_in<DEG>(coeffs, radii, g0, N, C, Kc, s_rows);
     __syncthreads();
     const int64_t g = g0 + threadIdx.x;
     if (g >= N) return;
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(const float *__restric
     __shared__ float s_cam[SH_BLOCK / 64][3];
     const int64_t g0 = (int64_t)blockIdx.x * SH_BLOCK;
     const int rows = (int)min((int64_t)SH_BLOCK, N - g0);
-    sh_stage_in<DEG>(coeffs, g0, rows, Kc, s_rows);
+    sh_stage_in<DEG>(coeffs, radii, g0, N, C, Kc, s_rows);
     __syncthreads();
     const int64_t g = g0 + threadIdx.x;
     float co[NBC], vco[NBC];
