@@ -103,8 +103,10 @@ __device__ __forceinline__ void walk_rects(const Rect &r, int tile_w, unsigned i
 // walk_rects for the placement passes: appends the lane's key to every tile of its rectangle through the LDS cursors.
 // Small rectangles take two tiles per trip - both returning LDS adds are issued before the first result is waited
 // for - because the chain add -> wait -> store -> next tile ran at the LDS round-trip latency per tile.
+template <bool CUT = false>
 __device__ __forceinline__ void place_rects(const Rect &r, int tile_w, unsigned int lo, unsigned int hi, int *s_cur,
-                                            int64_t M_cap, unsigned long long *__restrict__ entries, int base = 0) {
+                                            int64_t M_cap, unsigned long long *__restrict__ entries, int base = 0,
+                                            const unsigned int *s_cut = nullptr /* CUT: only keys with hi <= s_cut[tile] */) {
     const int w = r.x1 - r.x0, h = r.y1 - r.y0;
     const int area = (w > 0 && h > 0) ? w * h : 0;
     const unsigned long long key = ((unsigned long long)hi << 32) | lo;
@@ -113,17 +115,20 @@ __device__ __forceinline__ void place_rects(const Rect &r, int tile_w, unsigned 
         for (int k = 0; k < area; k += 2) {
             const int t0 = base + y * tile_w + x;
             if (++x == r.x1) { x = r.x0; ++y; }
-            const bool two = k + 1 < area;
+            bool two = k + 1 < area;
             const int t1 = base + y * tile_w + x;
             if (++x == r.x1) { x = r.x0; ++y; }
-            const int p0 = atomicAdd(&s_cur[t0], 1);
+            bool one = true;
+            if constexpr (CUT) { one = hi <= s_cut[t0]; two = two && hi <= s_cut[t1]; }
+            const int p0 = one ? atomicAdd(&s_cur[t0], 1) : -1;
             const int p1 = two ? atomicAdd(&s_cur[t1], 1) : -1;
-            if ((uint64_t)(uint32_t)p0 < (uint64_t)M_cap) entries[p0] = key;
+            if (one && (uint64_t)(uint32_t)p0 < (uint64_t)M_cap) entries[p0] = key;
             if (two && (uint64_t)(uint32_t)p1 < (uint64_t)M_cap) entries[p1] = key;
         }
     }
     const Rect none = {0, 0, 0, 0};
     walk_rects(area > COOP_AREA ? r : none, tile_w, lo, hi, [&](int tile, unsigned int l, unsigned int hh) {
+        if constexpr (CUT) { if (hh > s_cut[tile]) return; }
         const int pos = atomicAdd(&s_cur[tile], 1);
         if ((uint64_t)(uint32_t)pos < (uint64_t)M_cap) entries[pos] = ((unsigned long long)hh << 32) | l;
     }, base);
@@ -165,9 +170,16 @@ __global__ __launch_bounds__(BIN_THREADS) void count_matrix_kernel(const float *
 constexpr int CS_GROUPS = 16;
 constexpr int CS_ROWS = GB_MAX / CS_GROUPS;                 // rows per wavefront, at most
 
+// NEAR (near placement, gsx_front_fwd_near): a word of the matrix holds the pairs in front of the tile's cut-off in its low half and
+// the pairs behind it in its high half.  Only the near pairs are placed: the rows get the exclusive prefix of the NEAR counts, the
+// per-tile totals count BOTH (the tile's segment keeps room for the far keys, which its rasteriser workgroup appends itself if a
+// pixel outlives the near ones), and near_out[] gets the near totals = the keys the placement writes.
+template <bool NEAR>
 __global__ __launch_bounds__(64 * CS_GROUPS) void column_scan_kernel(int32_t *__restrict__ cnt, int gblocks,
-                                                                     int n_tiles, int32_t *__restrict__ counts /*[T]*/) {
+                                                                     int n_tiles, int32_t *__restrict__ counts /*[T]*/,
+                                                                     int32_t *__restrict__ near_out /*[T]*/) {
     __shared__ int s_tot[CS_GROUPS][64];
+    __shared__ int s_far[NEAR ? CS_GROUPS : 1][64];
     const int c = blockIdx.y;
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int tl = blockIdx.x * 64 + lane;
@@ -176,27 +188,33 @@ __global__ __launch_bounds__(64 * CS_GROUPS) void column_scan_kernel(int32_t *__
     const int r0 = rg * rpg, r1 = min(gblocks, r0 + rpg);
     int32_t *col = cnt + (int64_t)c * gblocks * n_tiles + tl;
     int v[CS_ROWS];
-    int sum = 0;
+    int sum = 0, far = 0;
 #pragma unroll
     for (int u = 0; u < CS_ROWS; ++u) {
         v[u] = (in && r0 + u < r1) ? col[(int64_t)(r0 + u) * n_tiles] : 0;
+        if constexpr (NEAR) { far += (int)((unsigned int)v[u] >> 16); v[u] &= 0xffff; }
         sum += v[u];
     }
     s_tot[rg][lane] = sum;
+    if constexpr (NEAR) s_far[rg][lane] = far;
     __syncthreads();
-    int run = 0, total = 0;
+    int run = 0, total = 0, far_total = 0;
 #pragma unroll
     for (int w = 0; w < CS_GROUPS; ++w) {
         const int tw = s_tot[w][lane];
         run += (w < rg) ? tw : 0;
         total += tw;
+        if constexpr (NEAR) far_total += s_far[w][lane];
     }
 #pragma unroll
     for (int u = 0; u < CS_ROWS; ++u) {
         if (in && r0 + u < r1) col[(int64_t)(r0 + u) * n_tiles] = run;
         run += v[u];
     }
-    if (in && rg == 0) counts[(int64_t)c * n_tiles + tl] = total;
+    if (in && rg == 0) {
+        counts[(int64_t)c * n_tiles + tl] = total + far_total;
+        if constexpr (NEAR) near_out[(int64_t)c * n_tiles + tl] = total;
+    }
 }
 
 // exclusive scan of the T per-tile counts held in offsets[] -> offsets[T+1], M, overflow status (one workgroup)
@@ -1064,8 +1082,8 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
             hipLaunchKernelGGL(coarse_count_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(S * 4), st,
                                means2d, radii, N, tile_w, tile_h, (int)items, sw, S, cnt);
             GSX_CHECK_LAUNCH();
-            hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(64 * CS_GROUPS), 0,
-                               st, cnt, (int)gblocks, S, coff);
+            hipLaunchKernelGGL(column_scan_kernel<false>, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(64 * CS_GROUPS), 0,
+                               st, cnt, (int)gblocks, S, coff, (int32_t *)nullptr);
             GSX_CHECK_LAUNCH();
             hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, (int)(C * S), C * N, coff, n_inst, status,
                                (int32_t *)nullptr);
@@ -1081,8 +1099,8 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
             hipLaunchKernelGGL(fine_count_kernel, dim3(gb2), dim3(FINE_THREADS), (size_t)(C * G * 4), st, recs, n_inst,
                                (int)chunk, tile_w, tile_h, (int)C, cnt);
             GSX_CHECK_LAUNCH();
-            hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((T + 63) / 64), 1u), dim3(64 * CS_GROUPS), 0, st, cnt,
-                               (int)gb2, (int)T, offsets);
+            hipLaunchKernelGGL(column_scan_kernel<false>, dim3((unsigned)((T + 63) / 64), 1u), dim3(64 * CS_GROUPS), 0, st, cnt,
+                               (int)gb2, (int)T, offsets, (int32_t *)nullptr);
             GSX_CHECK_LAUNCH();
             hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, (int)T, M_cap, offsets, M_dev, status, tile_order);
             GSX_CHECK_LAUNCH();
@@ -1105,8 +1123,8 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
                 hipLaunchKernelGGL(count_matrix_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS),
                                    (size_t)(n_tiles * 4), st, means2d, radii, N, tile_w, tile_h, (int)items, cnt);
                 GSX_CHECK_LAUNCH();
-                hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((n_tiles + 63) / 64), (unsigned)C),
-                                   dim3(64 * CS_GROUPS), 0, st, cnt, (int)gblocks, (int)n_tiles, offsets);
+                hipLaunchKernelGGL(column_scan_kernel<false>, dim3((unsigned)((n_tiles + 63) / 64), (unsigned)C),
+                                   dim3(64 * CS_GROUPS), 0, st, cnt, (int)gblocks, (int)n_tiles, offsets, (int32_t *)nullptr);
                 GSX_CHECK_LAUNCH();
             } else {
                 if (!gsx_zero_async(offsets, T, st)) return GSX_E_LAUNCH;
@@ -1214,6 +1232,9 @@ struct FrontArgs {
     // 16-byte load per Gaussian instead of two 12-byte-stride arrays) and read ONE 64-byte line per survivor instead of
     // gathering 14 floats from five arrays and rebuilding the covariance (15 of the projection's 27 us at 500 k, traced)
     const float4 *cull4;          // [R * seg_cap]
+    // near placement (gsx_front_fwd_near): depth bits of every tile's cut-off.  An (instance, tile) pair behind its tile's cut-off is
+    // counted in the HIGH half of the count-matrix word (kept out of the placement, room left for it in the tile's segment)
+    const uint32_t *tile_cut;     // [C * n_tiles], nullable
 };
 
 // What the projection needs of one Gaussian that does not depend on the pose: built once per frame for the Gaussians that
@@ -1466,6 +1487,8 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
     int *s_cnt = s_front, *s_ninst = s_front + C * n_tiles;
     int *s_wcnt = s_ninst + C;                                                     // [FRONT_THREADS / 64] scratch
     unsigned short *s_list = reinterpret_cast<unsigned short *>(s_wcnt + FRONT_THREADS / 64);   // [1024 * items] local indices
+    // [C * n_tiles] cut-offs of the near placement, behind the survivor list (only with a.tile_cut)
+    unsigned int *s_cutv = reinterpret_cast<unsigned int *>(s_list + FRONT_THREADS * ITEMS);
     int n_surv = 0;
     GSX_FT(0, 0)
     const int seg_cap = FRONT_THREADS * ITEMS;
@@ -1482,6 +1505,8 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
         }
     }
     for (int i = threadIdx.x; i < C * n_tiles + C; i += FRONT_THREADS) s_front[i] = 0;
+    if (a.tile_cut)
+        for (int i = threadIdx.x; i < C * n_tiles; i += FRONT_THREADS) s_cutv[i] = a.tile_cut[i];
     __syncthreads();
     GSX_FT(0, 1)
     // per-frame candidate records (pose-only plans): valid while every camera stays within the margins they were built for;
@@ -1714,6 +1739,10 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
                 }
             }
             if (s0 == 0) { GSX_FT(0, 3) }
+            if (a.tile_cut)     // near placement: pairs behind their tile's cut-off count in the high half of the word
+                walk_rects(r, a.tile_w, 0u, __float_as_uint(depth), [&](int tile, unsigned int, unsigned int dbits) {
+                    atomicAdd(&s_cnt[tile], dbits <= s_cutv[tile] ? 1 : 0x10000); }, c * n_tiles);
+            else
             walk_rects(r, a.tile_w, 0u, 0u, [&](int tile, unsigned int, unsigned int) { atomicAdd(&s_cnt[tile], 1); },
                        c * n_tiles);
             if (s0 == 0) { GSX_FT(0, 4) }
@@ -1736,8 +1765,9 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
     const PreRec *__restrict__ recs, const int32_t *__restrict__ n_inst, int R, int seg_cap, int C, int tile_w,
     int tile_h, int stripes, int rps, int64_t M_cap, const int32_t *__restrict__ counts, int prescanned,
     const int32_t *__restrict__ cnt, int32_t *__restrict__ offsets_out, int64_t *__restrict__ M_dev,
-    int32_t *__restrict__ status, unsigned long long *__restrict__ entries, int compact) {
-    extern __shared__ int s_cur[];                          // [T]: exclusive offsets, then this stripe's write cursors
+    int32_t *__restrict__ status, unsigned long long *__restrict__ entries, int compact,
+    const uint32_t *__restrict__ tile_cut /* nullable: near placement - only keys with depth bits <= tile_cut[tile] are written */) {
+    extern __shared__ int s_cur[];                          // [T]: exclusive offsets, then this stripe's write cursors; [T] cut-offs
     __shared__ long long s_wsum[FPLACE_THREADS / 64];
     const int n_tiles = tile_w * tile_h, T = C * n_tiles;
     const int stripe = blockIdx.x % stripes, row = blockIdx.x / stripes;
@@ -1754,6 +1784,13 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
     const int n0 = n_inst[row];
     int base0 = 0;
     if (t < span) base0 = cnt[(int64_t)row * n_tiles + ys0 * tile_w + t];
+    unsigned int *s_cut = reinterpret_cast<unsigned int *>(s_cur + T);
+    if (tile_cut)                                           // the cut-offs of this stripe's tiles, every camera
+        for (int c = 0; c < C; ++c)
+            for (int i = t; i < span; i += FPLACE_THREADS) {
+                const int tl = c * n_tiles + ys0 * tile_w + i;
+                s_cut[tl] = tile_cut[tl];
+            }
     if (prescanned) {
         for (int i = t; i < T; i += FPLACE_THREADS) s_cur[i] = counts[i];
     } else {
@@ -1843,7 +1880,8 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
                 klo = compact ? (unsigned int)(((int64_t)c * R + row) * seg_cap + i) : pr.id; khi = pr.depth;
                 if (r.y1 <= r.y0) r = Rect{0, 0, 0, 0};
             }
-            place_rects(r, tile_w, klo, khi, s_cur, M_cap, entries, c * n_tiles);
+            if (tile_cut) place_rects<true>(r, tile_w, klo, khi, s_cur, M_cap, entries, c * n_tiles, s_cut);
+            else place_rects(r, tile_w, klo, khi, s_cur, M_cap, entries, c * n_tiles);
         }
     }
     GSX_FT(1, 3)
@@ -2059,14 +2097,17 @@ extern "C" int gsx_front_candidates(const float *means, const float *quats, cons
     return GSX_OK;
 }
 
-extern "C" int gsx_front_fwd(const float *means, const float *quats, const float *scales, const float *viewmats,
-                             const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
-                             float far_plane, int flags, const float *logit_opacities, const float *logit_colors,
-                             const float *log_uncertainties, int32_t *radii, float *means2d, float *depths, float *conics,
-                             int32_t *tiles_per_gauss, float *rec, float *v_rec_clear, int32_t *vis_count, int64_t M_cap,
-                             int32_t *offsets, int64_t *M_dev, int32_t *status, int32_t *flatten_ids, int32_t *tile_order,
-                             const int32_t *tile_work, int32_t *balanced_order, float chunk_cost, float light_rate,
-                             int n_cus, void *workspace, int64_t workspace_bytes, void *stream) {
+static int front_fwd_impl(const float *means, const float *quats, const float *scales, const float *viewmats,
+                          const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                          float far_plane, int flags, const float *logit_opacities, const float *logit_colors,
+                          const float *log_uncertainties, int32_t *radii, float *means2d, float *depths, float *conics,
+                          int32_t *tiles_per_gauss, float *rec, float *v_rec_clear, int32_t *vis_count, int64_t M_cap,
+                          int32_t *offsets, int64_t *M_dev, int32_t *status, int32_t *flatten_ids, int32_t *tile_order,
+                          const int32_t *tile_work, int32_t *balanced_order, float chunk_cost, float light_rate,
+                          int n_cus, void *workspace, int64_t workspace_bytes, const uint32_t *tile_cut,
+                          int32_t *tile_placed, void *stream) {
+    // near placement: keys behind their tile's cut-off are counted (offsets, M: as ever) but not written
+    GSX_CHECK_ARG(!tile_cut || (tile_placed && !tile_order && (flags & GSX_PROJ_DEFER_SORT)));
     GSX_CHECK_ARG(N >= 1 && C >= 1 && C <= 255 && W > 0 && H > 0 && C * N < ((int64_t)1 << 31));
     GSX_CHECK_ARG(!balanced_order || (tile_work && n_cus >= 1 && n_cus <= gsx_bal::MAX_BINS && chunk_cost >= 0.f &&
                                       chunk_cost < 1e6f && light_rate > 0.f && light_rate <= 1.f));
@@ -2074,7 +2115,8 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
     GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && logit_opacities && logit_colors && rec);
     GSX_CHECK_ARG(compact || (radii && tiles_per_gauss));
     GSX_CHECK_ARG(!(flags & GSX_PROJ_BETAS) || log_uncertainties);
-    GSX_CHECK_ARG(offsets && M_dev && status && flatten_ids && M_cap >= 1 && M_cap < ((int64_t)1 << 31));
+    GSX_CHECK_ARG(offsets && M_dev && status && (flatten_ids || (flags & GSX_PROJ_DEFER_SORT)) && M_cap >= 1 &&
+                  M_cap < ((int64_t)1 << 31));
     const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
     const int64_t n_tiles = (int64_t)tile_w * tile_h, T = C * n_tiles;
     GSX_CHECK_ARG(tile_w < 65536 && tile_h < 4096);
@@ -2096,6 +2138,7 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
     a.cnt = (int32_t *)(ws + L.matrix_off); a.n_inst = (int32_t *)(ws + L.ninst_off); a.recs = (PreRec *)(ws + L.recs_off);
     a.compact = compact;
     a.cand = nullptr; a.cand_n = nullptr; a.cand_hdr = nullptr; a.cull4 = nullptr;
+    a.tile_cut = tile_cut;
     GSX_CHECK_ARG(!(flags & GSX_PROJ_MAP_RECORDS) || (flags & GSX_PROJ_CANDIDATES));
     if (flags & GSX_PROJ_CANDIDATES) {
         // the candidate set gsx_front_candidates left in this workspace; a closure whose poses left its margins takes the
@@ -2112,6 +2155,7 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
         a.cull4 = (const float4 *)(ws + L.cull_off);
     }
     size_t front_lds = (size_t)((T + C + FRONT_THREADS / 64) * 4 + 2 * FRONT_THREADS * L.items);   // histogram + survivor list
+    if (tile_cut) front_lds += (size_t)T * 4;                                                      // + the tiles' cut-offs
     a.bal.order = nullptr;
     if (balanced_order) {
         GSX_CHECK_ARG(T <= gsx_bal::MAX_TILES);
@@ -2137,8 +2181,12 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
     // with a launch order wanted the totals are scanned (and bucketed) by the one-workgroup kernel into `offsets` itself;
     // otherwise every placement workgroup scans them on its own and workgroup 0 publishes the offsets
     int32_t *col_out = tile_order ? offsets : counts;
-    hipLaunchKernelGGL(column_scan_kernel, dim3((unsigned)((n_tiles + 63) / 64), (unsigned)C), dim3(64 * CS_GROUPS), 0, st,
-                       a.cnt, L.R, (int)n_tiles, col_out);
+    if (tile_cut)
+        hipLaunchKernelGGL(column_scan_kernel<true>, dim3((unsigned)((n_tiles + 63) / 64), (unsigned)C), dim3(64 * CS_GROUPS), 0, st,
+                           a.cnt, L.R, (int)n_tiles, col_out, tile_placed);
+    else
+        hipLaunchKernelGGL(column_scan_kernel<false>, dim3((unsigned)((n_tiles + 63) / 64), (unsigned)C), dim3(64 * CS_GROUPS), 0, st,
+                           a.cnt, L.R, (int)n_tiles, col_out, (int32_t *)nullptr);
     GSX_CHECK_LAUNCH();
     if (tile_order) {
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, (int)T, M_cap, offsets, M_dev, status, tile_order);
@@ -2148,9 +2196,10 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
     const int rps = (tile_h + stripes - 1) / stripes;
     unsigned long long *entries = (unsigned long long *)(ws + L.entries_off);
     unsigned long long *scratch = (unsigned long long *)(ws + L.scratch_off);
-    hipLaunchKernelGGL(front_place_kernel, dim3((unsigned)(L.R * stripes)), dim3(FPLACE_THREADS), (size_t)(T * 4), st,
+    hipLaunchKernelGGL(front_place_kernel, dim3((unsigned)(L.R * stripes)), dim3(FPLACE_THREADS),
+                       (size_t)(T * (tile_cut ? 8 : 4)), st,
                        a.recs, a.n_inst, L.R, FRONT_THREADS * L.items, (int)C, tile_w, tile_h, stripes, rps, M_cap,
-                       col_out, tile_order ? 1 : 0, a.cnt, offsets, M_dev, status, entries, compact);
+                       col_out, tile_order ? 1 : 0, a.cnt, offsets, M_dev, status, entries, compact, tile_cut);
     GSX_CHECK_LAUNCH();
     if (flags & GSX_PROJ_DEFER_SORT) return GSX_OK;     // the consumer sorts each tile's keys itself (gsx_raster_track_fused_sorting)
     const uint32_t id_max = compact ? (uint32_t)(C * (int64_t)L.R * FRONT_THREADS * L.items - 1) : (uint32_t)(C * N - 1);
@@ -2158,6 +2207,35 @@ extern "C" int gsx_front_fwd(const float *means, const float *quats, const float
                        (int)n_tiles, bit_length((uint32_t)n_tiles), M_cap, id_max, (int64_t *)nullptr, flatten_ids);
     GSX_CHECK_LAUNCH();
     return GSX_OK;
+}
+
+extern "C" int gsx_front_fwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                             const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                             float far_plane, int flags, const float *logit_opacities, const float *logit_colors,
+                             const float *log_uncertainties, int32_t *radii, float *means2d, float *depths, float *conics,
+                             int32_t *tiles_per_gauss, float *rec, float *v_rec_clear, int32_t *vis_count, int64_t M_cap,
+                             int32_t *offsets, int64_t *M_dev, int32_t *status, int32_t *flatten_ids, int32_t *tile_order,
+                             const int32_t *tile_work, int32_t *balanced_order, float chunk_cost, float light_rate,
+                             int n_cus, void *workspace, int64_t workspace_bytes, void *stream) {
+    return front_fwd_impl(means, quats, scales, viewmats, Ks, N, C, W, H, eps2d, near_plane, far_plane, flags, logit_opacities,
+                          logit_colors, log_uncertainties, radii, means2d, depths, conics, tiles_per_gauss, rec, v_rec_clear,
+                          vis_count, M_cap, offsets, M_dev, status, flatten_ids, tile_order, tile_work, balanced_order,
+                          chunk_cost, light_rate, n_cus, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+extern "C" int gsx_front_fwd_near(const float *means, const float *quats, const float *scales, const float *viewmats,
+                                  const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                                  float far_plane, int flags, const float *logit_opacities, const float *logit_colors,
+                                  const float *log_uncertainties, float *rec, float *v_rec_clear, int64_t M_cap,
+                                  int32_t *offsets, int64_t *M_dev, int32_t *status, const int32_t *tile_work,
+                                  int32_t *balanced_order, float chunk_cost, float light_rate, int n_cus, void *workspace,
+                                  int64_t workspace_bytes, const uint32_t *tile_cut, int32_t *tile_placed, void *stream) {
+    GSX_CHECK_ARG(tile_cut && tile_placed && (flags & GSX_PROJ_COMPACT) && (flags & GSX_PROJ_DEFER_SORT));
+    return front_fwd_impl(means, quats, scales, viewmats, Ks, N, C, W, H, eps2d, near_plane, far_plane, flags, logit_opacities,
+                          logit_colors, log_uncertainties, nullptr, nullptr, nullptr, nullptr, nullptr, rec, v_rec_clear,
+                          nullptr, M_cap, offsets, M_dev, status, nullptr, nullptr,
+                          tile_work, balanced_order, chunk_cost, light_rate, n_cus, workspace, workspace_bytes, tile_cut,
+                          tile_placed, stream);
 }
 
 extern "C" int gsx_front_keys(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int flags, int64_t *out3) {

@@ -441,16 +441,21 @@ extern "C" int gsx_raster_track_fused(const float *rec, const float *backgrounds
     return GSX_OK;
 }
 
-extern "C" int gsx_raster_track_fused_sorting(const float *rec, const float *backgrounds, const int32_t *offsets,
-                                              int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
-                                              const float *gt, const float *exposure, float w_photo, float *alphas,
-                                              int32_t *last_ids, float *v_render, float *loss_rows, float *v_rec,
-                                              const int32_t *tile_order, int32_t *tile_work, uint64_t *keys,
-                                              uint64_t *keys_sorted, uint32_t id_max, uint32_t *tile_cut, float cut_margin,
-                                              int32_t *tile_near, int32_t *sort_stats, void *stream) {
+static int raster_track_fused_sorting_impl(const float *rec, const float *backgrounds, const int32_t *offsets,
+                                           int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
+                                           const float *gt, const float *exposure, float w_photo, float *alphas,
+                                           int32_t *last_ids, float *v_render, float *loss_rows, float *v_rec,
+                                           const int32_t *tile_order, int32_t *tile_work, uint64_t *keys,
+                                           uint64_t *keys_sorted, uint32_t id_max, uint32_t *tile_cut, float cut_margin,
+                                           int32_t *tile_near, int32_t *sort_stats, const int32_t *tile_placed,
+                                           const void *inst_recs, const int32_t *n_inst, int64_t R, int64_t seg_cap,
+                                           int compact, void *stream) {
     GSX_CHECK_ARG(offsets && gt && exposure && loss_rows && v_rec && C >= 1 && W > 0 && H > 0);
     GSX_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31) && (M == 0 || (rec && flatten_ids && keys && keys_sorted)));
     GSX_CHECK_ARG(tile_cut && cut_margin >= 0.f && cut_margin < 16.f && offsets_has_end == 1);
+    // near placement: the instance records the tile workgroups complete their segments from ([C][R][seg_cap], seg_cap = 1024 * 2^k)
+    GSX_CHECK_ARG(!tile_placed || (inst_recs && n_inst && R >= 1 && R <= 640 && seg_cap >= 1024 && seg_cap <= 8192 &&
+                                   (seg_cap & (seg_cap - 1)) == 0 && C * R * seg_cap < ((int64_t)1 << 31)));
     const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
     const int64_t T = C * tile_w * tile_h;
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
@@ -460,11 +465,42 @@ extern "C" int gsx_raster_track_fused_sorting(const float *rec, const float *bac
     TileSortArgs ts;
     ts.keys = (unsigned long long *)keys; ts.sorted = (unsigned long long *)keys_sorted; ts.tile_cut = tile_cut;
     ts.tile_near = tile_near; ts.stats = sort_stats; ts.id_max = id_max; ts.margin = cut_margin;
+    ts.tile_placed = tile_placed; ts.inst = (const uint4 *)inst_recs; ts.n_inst = n_inst; ts.R = (int)R;
+    ts.seg_cap = (int)seg_cap; ts.compact = compact;
     hipLaunchKernelGGL((raster_track_fused_kernel<12, true>), dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, rec,
                        backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas, last_ids, v_rec,
                        tile_order, la, ts);
     GSX_CHECK_LAUNCH();
     return GSX_OK;
+}
+
+extern "C" int gsx_raster_track_fused_sorting(const float *rec, const float *backgrounds, const int32_t *offsets,
+                                              int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
+                                              const float *gt, const float *exposure, float w_photo, float *alphas,
+                                              int32_t *last_ids, float *v_render, float *loss_rows, float *v_rec,
+                                              const int32_t *tile_order, int32_t *tile_work, uint64_t *keys,
+                                              uint64_t *keys_sorted, uint32_t id_max, uint32_t *tile_cut, float cut_margin,
+                                              int32_t *tile_near, int32_t *sort_stats, void *stream) {
+    return raster_track_fused_sorting_impl(rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, C, W, H, gt, exposure,
+                                           w_photo, alphas, last_ids, v_render, loss_rows, v_rec, tile_order, tile_work, keys,
+                                           keys_sorted, id_max, tile_cut, cut_margin, tile_near, sort_stats, nullptr, nullptr,
+                                           nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int gsx_raster_track_fused_near(const float *rec, const float *backgrounds, const int32_t *offsets,
+                                           int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
+                                           const float *gt, const float *exposure, float w_photo, float *alphas,
+                                           int32_t *last_ids, float *v_render, float *loss_rows, float *v_rec,
+                                           const int32_t *tile_order, int32_t *tile_work, uint64_t *keys,
+                                           uint64_t *keys_sorted, uint32_t id_max, uint32_t *tile_cut, float cut_margin,
+                                           int32_t *tile_near, int32_t *sort_stats, const int32_t *tile_placed,
+                                           const void *inst_recs, const int32_t *n_inst, int64_t R, int64_t seg_cap,
+                                           int compact, void *stream) {
+    GSX_CHECK_ARG(tile_placed != nullptr);
+    return raster_track_fused_sorting_impl(rec, backgrounds, offsets, flatten_ids, M, offsets_has_end, C, W, H, gt, exposure,
+                                           w_photo, alphas, last_ids, v_render, loss_rows, v_rec, tile_order, tile_work, keys,
+                                           keys_sorted, id_max, tile_cut, cut_margin, tile_near, sort_stats, tile_placed,
+                                           inst_recs, n_inst, R, seg_cap, compact, stream);
 }
 
 extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,

@@ -31,6 +31,12 @@ constexpr uint32_t CUT_NONE = 0x7f800000u; // +inf: no cut-off, sort everything
 
 typedef unsigned long long u64;
 
+// The workgroup reads back through the vector L1 what it has just written to memory (ids, sorted keys, appended keys).  A line of
+// those arrays can already sit in the CU's L1 - the compositing loop of the PREVIOUS slab read the ids next to where this slab's go -
+// and a store does not update it: without the invalidate the first entries of a second slab were composited from stale ids (found by
+// the pose-jump case of test_tile_sort_inside_the_rasteriser_equals_the_sort_launch: 36 of 1200 tiles off by 1e-4 relative).
+#define GSX_TSORT_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+
 // one rank-merge level: runs of length `run` in src[0..n) -> runs of 2 * run in dst (stable; LDS or global pointers)
 template <typename Ptr>
 __device__ __forceinline__ void merge_level(Ptr src, Ptr dst, int n, int run) {
@@ -253,7 +259,70 @@ __device__ __forceinline__ int sort_window(const u64 *__restrict__ keys, u64 *__
         sorted[i] = k;
     }
     __syncthreads();
+    GSX_TSORT_ACQUIRE();
     return m;
+}
+
+// Near placement (gsx_front_fwd_near): the front placed only the keys in front of the tile's depth cut-off; the tile's segment keeps
+// room for the others.  When a pixel of the tile outlives the placed keys, the tile's workgroup appends the keys BEHIND the cut-off
+// itself: it walks the instance records of camera c the front left behind ([R][seg_cap] 16-byte records {x0 | x1 << 16,
+// y0 | y1 << 12 | c << 24, depth bits, flatten id}, n_inst[c * R + row] valid ones per row) and writes the key of every instance
+// whose tile rectangle holds (tx, ty) and whose depth bits are > cut_bits - the complement of the placement's test, on the same
+// words - to out[0..cap) in any order (the slab sort behind it fixes the order).  The rare, slow path: one workgroup reads every
+// record of the camera (170 k x 16 B at 500 k Gaussians), 64-record stretches of the rows, eight in flight per wavefront; the
+// stretches that hold records are found by a ballot over a row-length table in LDS.  Returns the number of keys appended
+// (workgroup-uniform; more than cap = inconsistent counts, clamped by the caller).  Every thread must call it.
+__device__ __forceinline__ int complete_tile(const uint4 *__restrict__ inst, const int32_t *__restrict__ n_inst, int R,
+                                             int seg_cap, int c, int tx, int ty, uint32_t cut_bits, int compact,
+                                             u64 *__restrict__ out, int cap, void *pool, int *s_ctl) {
+    int *s_n = reinterpret_cast<int *>(pool);                  // [R] valid records per row
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __syncthreads();                                           // the pool may still be in use as something else
+    if (t == 0) s_ctl[10] = 0;
+    for (int i = t; i < R; i += THREADS) s_n[i] = min(max(n_inst[c * R + i], 0), seg_cap);
+    __syncthreads();
+    const int sh = 31 - __clz(max(seg_cap >> 6, 1));           // seg_cap = 1024 * 2^k: 64-record stretches per row = 2^sh
+    const int n_str = R << sh;
+    const uint4 *base = inst + (int64_t)c * R * seg_cap;
+    const int64_t slot0 = (int64_t)c * R * seg_cap;
+    for (int k0 = wave * 64; k0 < n_str; k0 += THREADS) {
+        const int k = k0 + lane;
+        const int nr = (k < n_str) ? s_n[k >> sh] : 0;
+        unsigned long long mask = __ballot(((k & ((1 << sh) - 1)) << 6) < nr);
+        while (mask != 0ull) {
+            uint4 rr[8];
+            int idx[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                rr[u] = make_uint4(0u, 0u, 0u, 0u);
+                idx[u] = -1;
+                if (mask != 0ull) {
+                    const int l = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1ull;
+                    const int kk = k0 + l;
+                    const int row = kk >> sh, i = ((kk & ((1 << sh) - 1)) << 6) + lane;
+                    const int n_row = __builtin_amdgcn_readlane(nr, l);
+                    if (i < n_row) {
+                        idx[u] = row * seg_cap + i;
+                        rr[u] = base[idx[u]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int x0 = (int)(rr[u].x & 0xffffu), x1 = (int)(rr[u].x >> 16);
+                const int y0 = (int)(rr[u].y & 0xfffu), y1 = (int)((rr[u].y >> 12) & 0xfffu);
+                if (idx[u] >= 0 && tx >= x0 && tx < x1 && ty >= y0 && ty < y1 && rr[u].z > cut_bits) {
+                    const int p = atomicAdd(&s_ctl[10], 1);
+                    const uint32_t klo = compact ? (uint32_t)(slot0 + idx[u]) : rr[u].w;
+                    if (p < cap) out[p] = ((u64)rr[u].z << 32) | klo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    GSX_TSORT_ACQUIRE();
+    return s_ctl[10];
 }
 
 // Sorts ALL n keys of the segment, any n: chunks of MERGE_CAP keys rank-sorted in LDS and written back in place, the remaining
@@ -284,5 +353,6 @@ __device__ __forceinline__ void sort_all(u64 *__restrict__ keys, u64 *__restrict
         if (src != sorted) sorted[i] = k;
     }
     __syncthreads();
+    GSX_TSORT_ACQUIRE();
 }
 }  // namespace gsx_tsort

@@ -301,8 +301,9 @@ class RenderPlan:
         self.tile_work = self.balanced_order = None
         # tile sort inside the fused tracking rasteriser (gsx_raster_track_fused_sorting): enable_defer_sort()
         self.defer_sort = False
+        self.near_place = False
         self.cut_margin = self.CUT_MARGIN
-        self.tile_cut = self.tile_near = self.sort_stats = None
+        self.tile_cut = self.tile_near = self.sort_stats = self.tile_placed = None
         self.balance_note = "identity / heaviest-first order (shape does not qualify for the balanced order)"
         self.n_cus = int(torch.cuda.get_device_properties(dev).multi_processor_count) if dev.type == 'cuda' else 0
         self.last_M = 0
@@ -512,6 +513,14 @@ class RenderPlan:
         lean = self.lean
         flags = self.flags | (_SKIP_CULLED if lean else 0) | (_COMPACT if self.compact else 0) | self._cand_flags() | (
             _DEFER_SORT if defer_sort else 0)
+        if defer_sort and self.near_place:
+            check(lib.gsx_front_fwd_near(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
+                                         self.H, self.eps2d, self.near, self.far, flags, _p(m[3]), _p(m[4]), _p(m[5]),
+                                         _p(self.rec), self._clear_ptr(), self.capacity, _p(self.offsets), _p(self.M_dev),
+                                         _p(self.status), _p(self.tile_work), _p(self.balanced_order), self.CHUNK_COST,
+                                         self.LIGHT_RATE, self.n_cus, _p(self.isect_ws), self.isect_ws.numel(),
+                                         _p(self.tile_cut), _p(self.tile_placed), st), "gsx_front_fwd_near")
+            return
         check(lib.gsx_front_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                 self.H, self.eps2d, self.near, self.far, flags,
                                 _p(m[3]), _p(m[4]), _p(m[5]), None if self.compact else _p(self.radii),
@@ -528,6 +537,22 @@ class RenderPlan:
     # 0.1 -> 1.4 %, 0.2 -> 0.4 %, 0.5 -> 0.01 %, while the keys sorted per closure grow from 17 % to 27 % of all; the fused launch
     # reads 81.9 / 81.2 / 80.8 / 81.1 / 81.5 us at 0.05 / 0.1 / 0.2 / 0.3 / 0.5
     CUT_MARGIN = 0.2
+
+    # with the near placement the cut-off also decides which keys are WRITTEN; a tile whose cut-off was too tight reads every instance
+    # record of its camera to find the rest (tile_sort_lds.h complete_tile), so the margin is chosen for that to be rare
+    NEAR_MARGIN = 0.5
+
+    def enable_near_placement(self, margin: Optional[float] = None) -> bool:
+        """On top of ``enable_defer_sort``: the front counts the keys behind a tile's depth cut-off without placing them
+        (gsx_front_fwd_near) and the rasteriser's tile workgroups append them themselves in the rare case a pixel outlives the
+        placed ones (gsx_raster_track_fused_near).  ``offsets`` / ``M_dev`` still describe the full lists; ``tile_placed[t]`` is what
+        the front wrote.  Same consumed lists, entry for entry.  -> whether this plan's shape qualifies."""
+        if not self.enable_defer_sort(self.NEAR_MARGIN if margin is None else margin):
+            return False
+        if not self.near_place:
+            self.near_place = True
+            self.tile_placed = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
+        return True
 
     def enable_defer_sort(self, margin: Optional[float] = None) -> bool:
         """Pose-only plans on the fused front whose closure runs gsx_raster_track_fused: the front stops after the placement and
@@ -588,6 +613,16 @@ class RenderPlan:
             check(lib.gsx_front_keys(self.N, self.C, self.tile_w, self.tile_h, self.capacity,
                                      _COMPACT if self.compact else 0, lay), "gsx_front_keys")
             base = self.isect_ws.data_ptr()
+            if self.near_place:
+                l4 = (C.c_int64 * 4)()
+                check(lib.gsx_front_layout(self.N, self.C, self.tile_w, self.tile_h, self.capacity, l4), "gsx_front_layout")
+                check(lib.gsx_raster_track_fused_near(
+                    _p(self.rec), _p(self.backgrounds), _p(self.offsets), _p(self.flat), self.capacity, 1, self.C, self.W, self.H,
+                    _p(gt), _p(exposure), float(w_photo), None, None, None, _p(rows), _p(self.v_rec), _p(self.launch_order),
+                    _p(self.tile_work), base + int(lay[0]), base + int(lay[1]), int(lay[2]), _p(self.tile_cut),
+                    float(self.cut_margin), _p(self.tile_near), _p(self.sort_stats), _p(self.tile_placed), base + int(l4[2]),
+                    base + int(l4[3]), int(l4[0]), int(l4[1]), 1 if self.compact else 0, st), "gsx_raster_track_fused_near")
+                return
             check(lib.gsx_raster_track_fused_sorting(
                 _p(self.rec), _p(self.backgrounds), _p(self.offsets), _p(self.flat), self.capacity, 1, self.C, self.W, self.H,
                 _p(gt), _p(exposure), float(w_photo), None, None, None, _p(rows), _p(self.v_rec), _p(self.launch_order),
@@ -743,8 +778,11 @@ class TrackClosure:
     CAND_MARGINS = (0.02, 0.02)    # |R R0^T - I|_F (~0.8 degrees) and metres the closures of a frame may move from its first pose
 
     def __init__(self, splats, camera, tail: str = 'fused', fuse_raster: bool = True, front: Optional[bool] = None,
-                 candidates: bool = False, defer_sort: Optional[bool] = None, map_records: Optional[bool] = None):
-        """fuse_raster (fused tail only): forward rasteriser, loss and rasteriser backward as ONE launch
+                 candidates: bool = False, defer_sort: Optional[bool] = None, map_records: Optional[bool] = None,
+                 near_place: Optional[bool] = None):
+        """near_place: the front leaves the keys behind a tile's depth cut-off out of the placement (RenderPlan.enable_near_placement);
+        None = wherever defer_sort applies.
+        fuse_raster (fused tail only): forward rasteriser, loss and rasteriser backward as ONE launch
         (gsx_raster_track_fused); False keeps them as two (the independent path the tests compare against).
         candidates: per-frame candidate set for the closures' projection (gsx_front_candidates).  OFF by default - measured
         on the headline sequence: the 36 evaluation points of a frame spread over up to ~0.1 rad / 0.1 m (Adam's
@@ -786,7 +824,10 @@ class TrackClosure:
         elif map_records is None or map_records:
             self.r.enable_map_records()
         if (defer_sort is None or defer_sort) and self.fuse_raster:
-            self.r.enable_defer_sort()
+            if near_place is None or near_place:
+                self.r.enable_near_placement()
+            else:
+                self.r.enable_defer_sort()
         self.stream = torch.cuda.Stream(device=dev)
         self.graph = HipGraph()
         self._chains: Dict[int, HipGraph] = {}

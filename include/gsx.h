@@ -250,8 +250,9 @@ int gsx_raster_track_fused(const float *rec, const float *backgrounds, const int
  * (slower, same result).  "depth <= cut" is a prefix of the (depth, id) order, so what is composited is the reference's list, entry
  * for entry.  keys / keys_sorted: the key buffer of gsx_front_fwd's workspace and its scratch copy (gsx_front_keys: byte offsets
  * [0], [1] and the largest valid id [2]); tile_near [T] (nullable): how many entries of each tile ended up sorted (= valid in
- * flatten_ids); sort_stats [4] (nullable, accumulating): tiles that fell back to their whole segment, tiles that took the
- * through-memory merge sort.  offsets must carry its end ([T + 1] entries). */
+ * flatten_ids); sort_stats [4] (nullable, accumulating): [0] slabs sorted behind a tile's first one, [1] segments that took the
+ * through-memory merge sort (piles of equal depths; keys whose depth bits no window takes - NaN, sign bit), [2], [3] see
+ * gsx_raster_track_fused_near.  offsets must carry its end ([T + 1] entries). */
 int gsx_raster_track_fused_sorting(const float *rec, const float *backgrounds, const int32_t *offsets, int32_t *flatten_ids,
                                    int64_t M, int offsets_has_end, int64_t C, int W, int H, const float *gt,
                                    const float *exposure, float w_photo, float *alphas, int32_t *last_ids, float *v_render,
@@ -259,6 +260,37 @@ int gsx_raster_track_fused_sorting(const float *rec, const float *backgrounds, c
                                    uint64_t *keys, uint64_t *keys_sorted, uint32_t id_max, uint32_t *tile_cut,
                                    float cut_margin, int32_t *tile_near, int32_t *sort_stats, void *stream);
 int gsx_front_keys(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int flags, int64_t *out3);
+
+/* ---- Near placement (round 5): the depth cut-off of a pose-only closure applied where the tile lists are BUILT, not only where they
+ * are sorted.  A tracking closure composites the nearest 17-27 % of a tile's keys before every pixel of the tile has saturated
+ * (gslam/frontend.py:604-662 evaluates 36 renders per frame from nearly the same pose), so the front of the next closure counts an
+ * (instance, tile) pair behind the tile's cut-off of the previous closure (tile_cut [T], as left by the rasteriser launch below)
+ * WITHOUT placing its key: offsets [T + 1], M_dev and status describe the FULL lists exactly as gsx_front_fwd leaves them - every
+ * tile's segment keeps room for all of its keys - but only the keys with depth bits <= tile_cut[t] are written, at the front of
+ * the segment, unsorted; tile_placed [T] tells how many.  gsx_front_fwd_near = gsx_front_fwd(flags | GSX_PROJ_COMPACT |
+ * GSX_PROJ_DEFER_SORT) restricted to what such a closure reads (no radii / means2d / depths / conics / tiles_per_gauss /
+ * vis_count / flatten_ids / tile_order outputs).
+ * gsx_raster_track_fused_near = gsx_raster_track_fused_sorting over such segments: a tile whose pixels outlive its placed keys
+ * appends the keys behind the cut-off to its segment ITSELF, from the front's instance records (inst_recs / n_inst / R / seg_cap:
+ * gsx_front_layout out4[2], [3], [0], [1] of the same workspace; compact = GSX_PROJ_COMPACT was set), and goes on slab by slab -
+ * slower (one workgroup reads every instance record of its camera), rare, and the same list: what is composited is a prefix of
+ * the reference's sorted list, entry for entry (gslam/rasterization.py:259-274).  A tile whose pixels outlive its WHOLE list
+ * leaves no cut-off (0x7f800000).  sort_stats [4] (accumulating): [0] slabs sorted behind a tile's first one, [1] segments sorted
+ * through memory, [2] tiles that appended their far keys, [3] tiles whose appended count disagreed with offsets (must stay 0). */
+int gsx_front_fwd_near(const float *means, const float *quats, const float *scales, const float *viewmats, const float *Ks,
+                       int64_t N, int64_t C, int W, int H, float eps2d, float near_plane, float far_plane, int flags,
+                       const float *logit_opacities, const float *logit_colors, const float *log_uncertainties, float *rec,
+                       float *v_rec_clear, int64_t M_cap, int32_t *offsets, int64_t *M_dev, int32_t *status,
+                       const int32_t *tile_work, int32_t *balanced_order, float chunk_cost, float light_rate, int n_cus,
+                       void *workspace, int64_t workspace_bytes, const uint32_t *tile_cut, int32_t *tile_placed, void *stream);
+int gsx_raster_track_fused_near(const float *rec, const float *backgrounds, const int32_t *offsets, int32_t *flatten_ids,
+                                int64_t M, int offsets_has_end, int64_t C, int W, int H, const float *gt,
+                                const float *exposure, float w_photo, float *alphas, int32_t *last_ids, float *v_render,
+                                float *loss_rows, float *v_rec, const int32_t *tile_order, int32_t *tile_work,
+                                uint64_t *keys, uint64_t *keys_sorted, uint32_t id_max, uint32_t *tile_cut,
+                                float cut_margin, int32_t *tile_near, int32_t *sort_stats, const int32_t *tile_placed,
+                                const void *inst_recs, const int32_t *n_inst, int64_t R, int64_t seg_cap, int compact,
+                                void *stream);
 /* Launch order for the rasteriser kernels of a render whose T workgroups are all resident at once (T <= 2048): deals the
  * tiles into n_cus groups of near-equal weight (weight = trips + chunk_cost * chunks of tile_work, as measured by an earlier
  * gsx_raster_fwd_track_loss of a nearby pose) and writes tile_order [T] so that the workgroups i, i + n_cus, i + 2 n_cus, ...
