@@ -31,11 +31,10 @@ constexpr uint32_t CUT_NONE = 0x7f800000u; // +inf: no cut-off, sort everything
 
 typedef unsigned long long u64;
 
-// The workgroup reads back through the vector L1 what it has just written to memory (ids, sorted keys, appended keys).  A line of
-// those arrays can already sit in the CU's L1 - the compositing loop of the PREVIOUS slab read the ids next to where this slab's go -
-// and a store does not update it: without the invalidate the first entries of a second slab were composited from stale ids (found by
-// the pose-jump case of test_tile_sort_inside_the_rasteriser_equals_the_sort_launch: 36 of 1200 tiles off by 1e-4 relative).
-#define GSX_TSORT_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+// (The workgroup reads back through the vector L1 what it has just written to memory - ids, sorted keys, appended keys.  All
+// wavefronts of a workgroup share the CU's L1, which keeps its own stores and loads in order: the workgroup barrier is enough.  An
+// agent-scope acquire here - tried in round 5 while chasing what turned out to be a vote taken under `if (lane == 0)` - invalidates
+// the L1 and the XCD's L2 for every tile resident on the CU: the fused launch went from 80 to 110 us.)
 
 // one rank-merge level: runs of length `run` in src[0..n) -> runs of 2 * run in dst (stable; LDS or global pointers)
 template <typename Ptr>
@@ -259,7 +258,6 @@ __device__ __forceinline__ int sort_window(const u64 *__restrict__ keys, u64 *__
         sorted[i] = k;
     }
     __syncthreads();
-    GSX_TSORT_ACQUIRE();
     return m;
 }
 
@@ -321,7 +319,6 @@ __device__ __forceinline__ int complete_tile(const uint4 *__restrict__ inst, con
         }
     }
     __syncthreads();
-    GSX_TSORT_ACQUIRE();
     return s_ctl[10];
 }
 
@@ -353,6 +350,5 @@ __device__ __forceinline__ void sort_all(u64 *__restrict__ keys, u64 *__restrict
         if (src != sorted) sorted[i] = k;
     }
     __syncthreads();
-    GSX_TSORT_ACQUIRE();
 }
 }  // namespace gsx_tsort

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--light-rate", type=float, default=None, help="RenderPlan.LIGHT_RATE (A/B)")
     ap.add_argument("--cut-margin", type=float, default=None, help="RenderPlan.CUT_MARGIN of the in-rasteriser tile sort (A/B)")
     ap.add_argument("--no-defer-sort", action="store_true", help="stand-alone tile sort launch (A/B)")
+    ap.add_argument("--no-near", action="store_true", help="every key placed (round-4 placement), sort inside the rasteriser (A/B)")
+    ap.add_argument("--near-margin", type=float, default=None, help="RenderPlan.NEAR_MARGIN of the near placement (A/B)")
     args = ap.parse_args()
     import bench
     if args.order_per_tile is not None:
@@ -41,6 +43,12 @@ def main():
     if args.cut_margin is not None:
         import gslam_amd.plan as P3
         P3.RenderPlan.CUT_MARGIN = args.cut_margin
+    if args.near_margin is not None:
+        import gslam_amd.plan as P6
+        P6.RenderPlan.NEAR_MARGIN = args.near_margin
+    if args.no_near:
+        import gslam_amd.plan as P7
+        P7.RenderPlan.enable_near_placement = lambda self, margin=None: self.enable_defer_sort()
     if args.no_defer_sort:
         import gslam_amd.plan as P4
         P4.RenderPlan.enable_defer_sort = lambda self, margin=None: False
@@ -83,6 +91,9 @@ def main():
         st4 = r.sort_stats.cpu().tolist()
         near, off = r.tile_near.cpu().numpy(), r.offsets.cpu().numpy()
         sizes = off[1:r.T + 1] - off[:r.T]
+        if getattr(r, "near_place", False):
+            print(f"near placement: {int(r.tile_placed.sum())} of {int(sizes.sum())} keys placed in the last closure, "
+                  f"{st4[2]} tiles appended their far keys over all closures so far, {st4[3]} inconsistent")
         print(f"tile sort inside the rasteriser: {st4[0]} tile fall-backs, {st4[1]} through-memory sorts over all closures so far "
               f"({r.T} tiles per closure); last closure: {int(near.sum())} of {int(sizes.sum())} entries sorted, "
               f"largest near list {int(near.max())}, largest segment {int(sizes.max())}, margin {r.cut_margin}")
