@@ -1205,6 +1205,13 @@ using namespace gsx_proj;
 
 constexpr int FRONT_THREADS = 1024;
 constexpr int FPLACE_THREADS = 256;
+#ifndef GSX_FPLACE_PRE
+#define GSX_FPLACE_PRE 4
+#endif
+constexpr int FPLACE_PRE = GSX_FPLACE_PRE;      // instance records a placement thread requests up front
+constexpr int FPLACE_ROUND = 2;                 // trips of 256 records per round of the placement walk
+constexpr int FPLACE_LIST = FPLACE_ROUND * FPLACE_THREADS;   // LDS list of a round's records that touch the stripe (16 B each)
+static_assert(FPLACE_PRE % FPLACE_ROUND == 0, "the prefetched records are whole rounds");
 #ifndef GSX_FRONT_STRIPES
 #define GSX_FRONT_STRIPES 8
 #endif
@@ -1767,8 +1774,9 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
     const int32_t *__restrict__ cnt, int32_t *__restrict__ offsets_out, int64_t *__restrict__ M_dev,
     int32_t *__restrict__ status, unsigned long long *__restrict__ entries, int compact,
     const uint32_t *__restrict__ tile_cut /* nullable: near placement - only keys with depth bits <= tile_cut[tile] are written */) {
-    extern __shared__ int s_cur[];                          // [T]: exclusive offsets, then this stripe's write cursors; [T] cut-offs
+    extern __shared__ __attribute__((aligned(16))) int s_cur[];   // [T]: exclusive offsets, then this stripe's write cursors; [T] cut-offs; list
     __shared__ long long s_wsum[FPLACE_THREADS / 64];
+    __shared__ int s_nlist;
     const int n_tiles = tile_w * tile_h, T = C * n_tiles;
     const int stripe = blockIdx.x % stripes, row = blockIdx.x / stripes;
     const int t = threadIdx.x;
@@ -1778,9 +1786,15 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
     // Everything this workgroup needs from global memory that does not depend on the scan is requested first - the first
     // trip of camera 0's instance records, its row's bases for the stripe, the instance count - so that the kernel is one
     // memory round trip plus the scan deep, not four (a workgroup places only a few hundred entries: latency is all there is).
+    // (ALL the records a thread will place for camera 0 - up to FPLACE_PRE trips, which covers a 1024-instance row - not only
+    // the first: the walk below was a chain of record load -> LDS add -> store per trip, 9 of the workgroup's 13 us at 500 k)
     const PreRec *seg0 = recs + (int64_t)row * seg_cap;
-    PreRec pre0 = {0u, 0u, 0u, 0u};
-    if (t < seg_cap) pre0 = seg0[t];
+    PreRec pre[FPLACE_PRE];
+#pragma unroll
+    for (int k = 0; k < FPLACE_PRE; ++k) {
+        pre[k] = PreRec{0u, 0u, 0u, 0u};
+        if (t + k * FPLACE_THREADS < seg_cap) pre[k] = seg0[t + k * FPLACE_THREADS];
+    }
     const int n0 = n_inst[row];
     int base0 = 0;
     if (t < span) base0 = cnt[(int64_t)row * n_tiles + ys0 * tile_w + t];
@@ -1865,23 +1879,71 @@ __global__ __launch_bounds__(FPLACE_THREADS) void front_place_kernel(
     }
     __syncthreads();
     GSX_FT(1, 2)
+    // Seven of eight records do not touch this stripe: walked where they were loaded, every trip of the loop ran at the pace of
+    // its longest rectangle with an eighth of the lanes at work (9 of the workgroup's 13 us at 500 k, traced).  The records that do
+    // touch the stripe are compacted into an LDS list first (any order: the segment is sorted later), then walked one per lane.
+    uint4 *s_list = reinterpret_cast<uint4 *>(s_cur + (((tile_cut ? 2 * T : T) + 3) & ~3));      // [FPLACE_LIST], 16-byte aligned
     for (int c = 0; c < C; ++c) {
         const int n = min(max(c == 0 ? n0 : n_inst[c * R + row], 0), seg_cap);
         const PreRec *seg = recs + ((int64_t)c * R + row) * seg_cap;
-        for (int i0 = 0; i0 < n; i0 += FPLACE_THREADS) {
-            const int i = i0 + t;
-            Rect r = {0, 0, 0, 0};
-            unsigned int klo = 0u, khi = 0u;
-            if (i < n) {
-                const PreRec pr = (c == 0 && i0 == 0) ? pre0 : seg[i];
-                r.x0 = (int)(pr.xs & 0xffffu); r.x1 = (int)(pr.xs >> 16);
-                r.y0 = max((int)(pr.ys_c & 0xfffu), ys0); r.y1 = min((int)((pr.ys_c >> 12) & 0xfffu), ys1);
-                // the low key word: flatten id, or the instance's slot (same order - slots are monotone in the flatten id)
-                klo = compact ? (unsigned int)(((int64_t)c * R + row) * seg_cap + i) : pr.id; khi = pr.depth;
-                if (r.y1 <= r.y0) r = Rect{0, 0, 0, 0};
-            }
+        auto place_one = [&](const Rect &r, unsigned int klo, unsigned int khi) {
             if (tile_cut) place_rects<true>(r, tile_w, klo, khi, s_cur, M_cap, entries, c * n_tiles, s_cut);
             else place_rects(r, tile_w, klo, khi, s_cur, M_cap, entries, c * n_tiles);
+        };
+        // rounds of FPLACE_ROUND (= 2) trips = at most FPLACE_LIST records: the list cannot overflow
+        auto do_round = [&](int rbase, const PreRec &pa, const PreRec &pb) {
+            if (t == 0) s_nlist = 0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < FPLACE_ROUND; ++k) {
+                const PreRec &p = k == 0 ? pa : pb;
+                const int i = rbase + k * FPLACE_THREADS + t;
+                Rect r = {0, 0, 0, 0};
+                if (i < n) {
+                    r.x0 = (int)(p.xs & 0xffffu); r.x1 = (int)(p.xs >> 16);
+                    r.y0 = max((int)(p.ys_c & 0xfffu), ys0); r.y1 = min((int)((p.ys_c >> 12) & 0xfffu), ys1);
+                }
+                const bool has = (r.y1 > r.y0) && (r.x1 > r.x0);
+                // the low key word: flatten id, or the instance's slot (same order - slots are monotone in the flatten id)
+                const unsigned int klo = compact ? (unsigned int)(((int64_t)c * R + row) * seg_cap + i) : p.id;
+                const unsigned long long m = __ballot(has);
+                int wbase = 0;
+                if ((t & 63) == 0 && m != 0ull) wbase = atomicAdd(&s_nlist, __popcll(m));
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                const int pos = wbase + __popcll(m & ((1ull << (t & 63)) - 1ull));
+                if (has && pos < FPLACE_LIST)
+                    s_list[pos] = make_uint4(p.xs, (unsigned int)r.y0 | ((unsigned int)r.y1 << 16), p.depth, klo);
+            }
+            __syncthreads();
+            if (rbase == 0) { GSX_FT(1, 4) }
+            const int total = min(s_nlist, FPLACE_LIST);
+            const int trips = (total + FPLACE_THREADS - 1) / FPLACE_THREADS;
+            for (int tr = 0; tr < trips; ++tr) {        // (whole wavefronts: large rectangles are walked cooperatively)
+                const int j = tr * FPLACE_THREADS + t;
+                Rect r = {0, 0, 0, 0};
+                unsigned int klo = 0u, khi = 0u;
+                if (j < total) {
+                    const uint4 e = s_list[j];
+                    r.x0 = (int)(e.x & 0xffffu); r.x1 = (int)(e.x >> 16);
+                    r.y0 = (int)(e.y & 0xffffu); r.y1 = (int)(e.y >> 16);
+                    khi = e.z; klo = e.w;
+                }
+                place_one(r, klo, khi);
+            }
+            __syncthreads();                            // the list is rewritten by the next round
+        };
+        int rbase = 0;
+        if (c == 0) {                                   // the two rounds whose records were requested at the top
+            static_assert(FPLACE_PRE == 4 && FPLACE_ROUND == 2, "prefetched rounds are written out");
+            if (n > 0) do_round(0, pre[0], pre[1]);
+            if (n > FPLACE_LIST) do_round(FPLACE_LIST, pre[2], pre[3]);
+            rbase = 2 * FPLACE_LIST;
+        }
+        for (; rbase < n; rbase += FPLACE_LIST) {
+            const int ia = rbase + t, ib = rbase + FPLACE_THREADS + t;
+            const PreRec none = {0u, 0u, 0u, 0u};
+            const PreRec pa = (ia < n) ? seg[ia] : none, pb = (ib < n) ? seg[ib] : none;
+            do_round(rbase, pa, pb);
         }
     }
     GSX_FT(1, 3)
@@ -2197,7 +2259,7 @@ static int front_fwd_impl(const float *means, const float *quats, const float *s
     unsigned long long *entries = (unsigned long long *)(ws + L.entries_off);
     unsigned long long *scratch = (unsigned long long *)(ws + L.scratch_off);
     hipLaunchKernelGGL(front_place_kernel, dim3((unsigned)(L.R * stripes)), dim3(FPLACE_THREADS),
-                       (size_t)(T * (tile_cut ? 8 : 4)), st,
+                       (size_t)(((T * (tile_cut ? 8 : 4) + 15) & ~(int64_t)15) + FPLACE_LIST * 16), st,
                        a.recs, a.n_inst, L.R, FRONT_THREADS * L.items, (int)C, tile_w, tile_h, stripes, rps, M_cap,
                        col_out, tile_order ? 1 : 0, a.cnt, offsets, M_dev, status, entries, compact, tile_cut);
     GSX_CHECK_LAUNCH();

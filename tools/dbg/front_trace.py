@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 
 NAMES = [["entry", "LDS zeroed", "records loaded, projected, compacted", "rows + instance records written (issue)",
           "rectangles counted", "workgroup done counting", "phase 2: covariance of the survivor ready", "phase 1 done (cull + compaction)"],
-         ["entry", "tile totals scanned", "cursors of the stripe ready", "placed (issue)"]]
+         ["entry", "tile totals scanned", "cursors of the stripe ready", "placed (issue)", "first round's list built"]]
 
 
 def main():
@@ -57,7 +57,7 @@ def main():
         rows = a[k][a[k][:, 0] > 0]
         t0 = rows[:, 0].min()
         print(f"{kern}: {len(rows)} workgroups stamped; microseconds after the first entry")
-        for j, name in sorted(enumerate(NAMES[k]), key=lambda x: {7: 1.5, 6: 1.7}.get(x[0], x[0]) if k == 0 else x[0]):
+        for j, name in sorted(enumerate(NAMES[k]), key=lambda x: {7: 1.5, 6: 1.7}.get(x[0], x[0]) if k == 0 else {4: 2.5}.get(x[0], x[0])):
             v = rows[:, j]
             v = (v[v > 0] - t0) / 100.0
             if len(v):
