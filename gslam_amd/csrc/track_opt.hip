@@ -4,6 +4,7 @@
 #include "gsx_common.h"
 #include "pose_math.h"
 #include "track_opt.h"
+#include "track_tail.h"
 
 #define TO_ENTRY(name) gsx_track_opt_##name
 #define TO_TENSORS 4

@@ -7,6 +7,7 @@
 #define TO_MAXN 80
 #define TO_MAXH 10
 #include "track_opt.h"
+#include "track_tail.h"
 
 #define TO_ENTRY(name) gsx_window_opt_##name
 #define TO_TENSORS 16
