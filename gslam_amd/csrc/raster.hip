@@ -503,6 +503,18 @@ extern "C" int gsx_raster_track_fused_near(const float *rec, const float *backgr
                                            inst_recs, n_inst, R, seg_cap, compact, stream);
 }
 
+// static LDS of the fused tracking rasteriser's workgroup, read off the code object: what the start-up probe of the CU-balanced
+// launch order allocates per workgroup so that its workgroups are placed like the launches it vouches for (plan.placement_ok)
+extern "C" int64_t gsx_raster_track_fused_lds_bytes(void) {
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&raster_track_fused_kernel<12, true>)) != hipSuccess) {
+        (void)hipGetLastError();
+        gsx_set_error("gsx_raster_track_fused_lds_bytes: hipFuncGetAttributes failed");
+        return -1;
+    }
+    return (int64_t)attr.sharedSizeBytes;
+}
+
 extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,
                               const int32_t *flatten_ids, int64_t M, int offsets_has_end, int64_t C, int W, int H,
                               int tile_w, int tile_h, const float *alphas, const int32_t *last_ids,

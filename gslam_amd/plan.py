@@ -146,13 +146,17 @@ _PLACEMENT_FAILS: Dict[tuple, int] = {}
 PLACEMENT_RETRIES = 3       # a failed probe is repeated by later plans this many times before the verdict sticks
 
 
-# LDS of a workgroup of the fused tracking rasteriser (raster_track_fused_kernel<12, true>: 29 856 bytes of static LDS, read off
-# the code object; 5 workgroups per CU): what the placement probe's workgroups allocate, so that they are placed like the
-# launches whose order the probe vouches for
-RASTER_LDS_BYTES = 29856
+def raster_lds_bytes() -> int:
+    """static LDS of a workgroup of the fused tracking rasteriser, asked of the loaded code object (it depends on GSX_TC_ROWS,
+    the staging strides and the tile-sort pool, which diagnostic builds override): what the placement probe's workgroups allocate,
+    so that they are placed like the launches whose order the probe vouches for"""
+    n = int(lib.gsx_raster_track_fused_lds_bytes())
+    if n <= 0:
+        raise RuntimeError("gsx_raster_track_fused_lds_bytes failed: " + lib.gsx_last_error().decode(errors="replace"))
+    return n
 
 
-def placement_ok(dev, n_wgs: int, n_cus: int, lds_bytes: int = RASTER_LDS_BYTES):
+def placement_ok(dev, n_wgs: int, n_cus: int, lds_bytes: Optional[int] = None):
     """Does workgroup i of an ``n_wgs``-workgroup launch (256 threads, the rasteriser's LDS footprint, all resident at once)
     share its compute unit with workgroups i + G, i + 2 G, ... on this device?  The CU-balanced launch order
     (csrc/tile_balance.h) deals the tiles into G groups on that assumption - an undocumented property of the dispatcher,
@@ -161,6 +165,8 @@ def placement_ok(dev, n_wgs: int, n_cus: int, lds_bytes: int = RASTER_LDS_BYTES)
     ``torch.cuda.synchronize`` drains it only for an instant - another host thread (the backend's BA stream) can enqueue work
     before the probe's workgroups are placed - so the probe is repeated twice on the spot and, if it still fails, by the next
     ``PLACEMENT_RETRIES`` plans that ask; only then does the identity / heaviest-first order stick (logged).  -> (ok, note)"""
+    if lds_bytes is None:
+        lds_bytes = raster_lds_bytes()
     key = (str(dev), int(n_wgs), int(n_cus), int(lds_bytes))
     hit = _PLACEMENT.get(key)
     if hit is not None:
@@ -1343,8 +1349,11 @@ class MappingStep:
         CONTRACT: the update is gated ON THE DEVICE by the sticky overflow status of the render: once a tile
         list of this plan has overflowed, every further step() computes gradients and applies NOTHING until the host has
         settled it.  So follow every step() - or every short run of them - with ``finish_step()`` (one read-back of loss and
-        flag, grows the lists, tells the caller to redo) or at least ``capacity_ok()``; the host-side step counters assume
-        the update happened and are corrected by ``finish_step()`` / ``capacity_ok()`` when it did not."""
+        flag, grows the lists, tells the caller to redo) or at least ``capacity_ok()``.  The host-side step counters
+        (``adam.note_steps``, ``self.steps``) assume the update happened: ``finish_step()`` takes the skipped iteration back
+        out of them; ``capacity_ok()`` does NOT - it cannot know how many of the polled steps were gated - so a caller that
+        polls must redo its iterations from a state it trusts (the device-side step counters, which the gate also holds,
+        stay exact either way: Adam's bias correction reads those)."""
         if graphed and (not self.graph.captured or (self.r is not None and self.r.stale)):
             self.prepare()
         st = current_stream_ptr(self.dev)

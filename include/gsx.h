@@ -260,6 +260,8 @@ int gsx_raster_track_fused_sorting(const float *rec, const float *backgrounds, c
                                    uint64_t *keys, uint64_t *keys_sorted, uint32_t id_max, uint32_t *tile_cut,
                                    float cut_margin, int32_t *tile_near, int32_t *sort_stats, void *stream);
 int gsx_front_keys(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int flags, int64_t *out3);
+/* static LDS bytes of a workgroup of gsx_raster_track_fused_sorting's kernel, read off the loaded code object (-1 on error) */
+int64_t gsx_raster_track_fused_lds_bytes(void);
 
 /* ---- Near placement (round 5): the depth cut-off of a pose-only closure applied where the tile lists are BUILT, not only where they
  * are sorted.  A tracking closure composites the nearest 17-27 % of a tile's keys before every pixel of the tile has saturated

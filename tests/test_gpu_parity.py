@@ -175,10 +175,12 @@ def _oracle_pipeline(o, sc, viewmats, Ks, W, H, ch, seed=3):
 
 
 @pytest.mark.parametrize("n,c,W,H,ch", [(3000, 1, 640, 480, 5), (3000, 2, 320, 240, 3), (2000, 1, 200, 120, 1),
-                                         (2000, 1, 330, 250, 4), (2000, 1, 330, 250, 2), (2500, 4, 640, 480, 5)])
+                                         (2000, 1, 330, 250, 4), (2000, 1, 330, 250, 2), (2500, 4, 640, 480, 5),
+                                         (2500, 4, 640, 480, 3), (14000, 4, 640, 480, 4)])
 def test_raster_forward_backward_vs_oracle(dev, oracle32, n, c, W, H, ch):
-    """the raster kernels the launch selects for each shape - one camera: quadrant kernels; (2500, 4, 640x480): 4800 tiles,
-    the full-chip backward with two pixels per lane - against the CPU oracle"""
+    """the raster kernels the launch selects for each shape - one camera: quadrant kernels; (.., 4, 640x480): 4800 tiles, the
+    full-chip backward (round 5: raster_bwd_full_kernel, the transposed contraction with opacity and colour columns; the 14 000
+    Gaussian case has tile lists deeper than its 320 accumulator rows: the straight-to-memory path) - against the CPU oracle"""
     from gslam_amd import ops
     from gslam_amd.synthetic import make_cameras, make_scene
     sc = make_scene(n, 4)
