@@ -24,6 +24,7 @@
 //                      degenerate depth distributions): merge sort by ranks in an LDS window of up to 8192 keys,
 //                      continued through global memory beyond that.  Writes flatten_ids / isect_ids
 #include <stdlib.h>
+#include <algorithm>
 
 #include "gsx_common.h"
 #include "tile_balance.h"
@@ -1205,6 +1206,7 @@ namespace {
 using namespace gsx_proj;
 
 constexpr int FRONT_THREADS = 1024;
+#define GSX_ROW_CURSORS 64                      // = gsx_tsort::ROW_CURSORS (tile_sort_lds.h)
 constexpr int FPLACE_THREADS = 256;
 #ifndef GSX_FPLACE_PRE
 #define GSX_FPLACE_PRE 4
@@ -1243,6 +1245,13 @@ struct FrontArgs {
     // near placement (gsx_front_fwd_near): depth bits of every tile's cut-off.  An (instance, tile) pair behind its tile's cut-off is
     // counted in the HIGH half of the count-matrix word (kept out of the placement, room left for it in the tile's segment)
     const uint32_t *tile_cut;     // [C * n_tiles], nullable
+    // row keys (gsx_front_fwd_rows): the workgroup leaves its row's keys in its own segment of `row_keys`, grouped by tile, and in
+    // its row of the count matrix the word (offset inside the segment << 13 | count) per tile - no column scan, no placement
+    // launch: the rasteriser's tile workgroups collect their keys themselves (tile_sort_lds.h gather_tile_keys)
+    unsigned long long *row_keys; // [R][row_cap], nullable
+    int row_cap;
+    int32_t *status;
+    unsigned long long *cursor;   // the render's GSX_ROW_CURSORS key counters (M_dev [64]): zeroed here, advanced by the tile workgroups
 };
 
 // What the projection needs of one Gaussian that does not depend on the pose: built once per frame for the Gaussians that
@@ -1760,6 +1769,64 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
     }
     __syncthreads();
     GSX_FT(0, 5)
+    if (a.row_keys != nullptr) {
+        // ---- row keys: exclusive scan of the row's per-tile counts (its segment is grouped by tile), the words out, then the row's
+        // instance records are walked a second time - they were written a few microseconds ago by this workgroup - and every key
+        // goes to its tile's stretch of the row's segment through the LDS cursors.  Nothing waits for another workgroup.
+        const int TT = C * n_tiles;
+        const int per = (TT + FRONT_THREADS - 1) / FRONT_THREADS;
+        const int lo = min(TT, (int)threadIdx.x * per), hi = min(TT, lo + per);
+        int sum = 0;
+        for (int i = lo; i < hi; ++i) sum += s_cnt[i];
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if ((int)(threadIdx.x & 63) >= o) incl += v;
+        }
+        if ((threadIdx.x & 63) == 63) s_wcnt[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int run = incl - sum, total = 0;
+#pragma unroll
+        for (int w = 0; w < FRONT_THREADS / 64; ++w) {
+            const int ws = s_wcnt[w];
+            run += (w < (int)(threadIdx.x >> 6)) ? ws : 0;
+            total += ws;
+        }
+        for (int i = lo; i < hi; ++i) {
+            const int cnt = s_cnt[i];
+            const int c = i / n_tiles, tl = i - c * n_tiles;
+            // (tile-major: a tile's workgroup reads the words of all rows as ONE contiguous stretch - row-major, its column was
+            // R cache lines fetched for 4 bytes each)
+            a.cnt[((int64_t)c * n_tiles + tl) * a.R + blockIdx.x] =
+                (int32_t)(((uint32_t)min(run, (1 << 19) - 1) << 13) | (uint32_t)min(cnt, 8191));
+            s_cnt[i] = run;                                 // the tile's write cursor inside the row's segment
+            run += cnt;
+        }
+        if (threadIdx.x == 0) {
+            if (total > a.row_cap || total >= (1 << 19)) atomicOr(a.status, 1);     // the row outgrew its segment: the plan grows, redoes
+        }
+        if (blockIdx.x == 0 && threadIdx.x < GSX_ROW_CURSORS) a.cursor[threadIdx.x] = 0ull;
+        __syncthreads();
+        unsigned long long *seg_keys = a.row_keys + (int64_t)blockIdx.x * a.row_cap;
+        for (int c = 0; c < C; ++c) {
+            const int n = min(s_ninst[c], seg_cap);
+            const PreRec *seg = a.recs + ((int64_t)c * a.R + blockIdx.x) * seg_cap;
+            for (int i0 = 0; i0 < n; i0 += FRONT_THREADS) {
+                const int i = i0 + (int)threadIdx.x;
+                Rect r = {0, 0, 0, 0};
+                unsigned int klo = 0u, khi = 0u;
+                if (i < n) {
+                    const PreRec pr = seg[i];
+                    r.x0 = (int)(pr.xs & 0xffffu); r.x1 = (int)(pr.xs >> 16);
+                    r.y0 = (int)(pr.ys_c & 0xfffu); r.y1 = (int)((pr.ys_c >> 12) & 0xfffu);
+                    klo = a.compact ? (unsigned int)(((int64_t)c * a.R + blockIdx.x) * seg_cap + i) : pr.id;
+                    khi = pr.depth;
+                }
+                place_rects(r, a.tile_w, klo, khi, s_cnt, (int64_t)a.row_cap, seg_keys, c * n_tiles);
+            }
+        }
+    } else
     for (int i = threadIdx.x; i < C * n_tiles; i += FRONT_THREADS) {
         const int c = i / n_tiles, tl = i - c * n_tiles;
         a.cnt[((int64_t)c * a.R + blockIdx.x) * n_tiles + tl] = s_cnt[i];
@@ -2030,7 +2097,7 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
 }
 
 struct FrontLayout {
-    int64_t counts_off, ninst_off, entries_off, scratch_off, matrix_off, recs_off, total;
+    int64_t counts_off, ninst_off, entries_off, scratch_off, rowkeys_off, matrix_off, recs_off, total;
     int64_t cand_hdr_off, cand_n_off, cand_off, cull_off, total_cand;   // candidate area, appended behind `total` (optional)
     int items, R;
 };
@@ -2048,7 +2115,8 @@ FrontLayout front_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M
     L.ninst_off = gsx_align256((T + 1) * 4);
     L.entries_off = L.ninst_off + gsx_align256(C * (int64_t)GB_MAX * 4);
     L.scratch_off = L.entries_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);
-    L.matrix_off = L.scratch_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);
+    L.rowkeys_off = L.scratch_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);         // [R][M_cap / R] row segments (row keys)
+    L.matrix_off = L.rowkeys_off + gsx_align256((M_cap > 0 ? M_cap : 1) * 8);
     L.recs_off = L.matrix_off + gsx_align256(T * (int64_t)GB_MAX * 4);
     L.total = gsx_align256(L.recs_off + C * (int64_t)L.R * FRONT_THREADS * items * 16 + 256);
     L.cand_hdr_off = L.total;
@@ -2149,6 +2217,14 @@ static int front_fwd_impl(const float *means, const float *quats, const float *s
     a.compact = compact;
     a.cand = nullptr; a.cand_n = nullptr; a.cand_hdr = nullptr; a.cull4 = nullptr;
     a.tile_cut = tile_cut;
+    a.row_keys = nullptr; a.row_cap = 0; a.status = status; a.cursor = (unsigned long long *)M_dev;
+    if (flags & GSX_PROJ_ROW_KEYS) {
+        // the front ends with the projection launch: keys per row, collected by the consumer's tile workgroups
+        GSX_CHECK_ARG(compact && (flags & GSX_PROJ_DEFER_SORT) && !tile_order && !tile_cut && L.R <= 768);
+        a.row_keys = (unsigned long long *)(ws + L.rowkeys_off);
+        a.row_cap = (int)std::min<int64_t>(M_cap / L.R, (1 << 19) - 1);
+        GSX_CHECK_ARG(a.row_cap >= 1);
+    }
     GSX_CHECK_ARG(!(flags & GSX_PROJ_MAP_RECORDS) || (flags & GSX_PROJ_CANDIDATES));
     if (flags & GSX_PROJ_CANDIDATES) {
         // the candidate set gsx_front_candidates left in this workspace; a closure whose poses left its margins takes the
@@ -2188,6 +2264,7 @@ static int front_fwd_impl(const float *means, const float *quats, const float *s
                  return GSX_E_UNSUPPORTED;
     }
     GSX_CHECK_LAUNCH();
+    if (flags & GSX_PROJ_ROW_KEYS) return GSX_OK;
     // with a launch order wanted the totals are scanned (and bucketed) by the one-workgroup kernel into `offsets` itself;
     // otherwise every placement workgroup scans them on its own and workgroup 0 publishes the offsets
     int32_t *col_out = tile_order ? offsets : counts;
@@ -2253,6 +2330,15 @@ extern "C" int gsx_front_keys(int64_t N, int64_t C, int tile_w, int tile_h, int6
     const FrontLayout L = front_layout(N, C, tile_w, tile_h, M_cap);
     out3[0] = L.entries_off; out3[1] = L.scratch_off;
     out3[2] = (flags & GSX_PROJ_COMPACT) ? (C * (int64_t)L.R * FRONT_THREADS * L.items - 1) : (C * N - 1);   // largest valid id
+    return GSX_OK;
+}
+
+// out4 = { byte offset of the row segments of keys ([R][row_cap] x 8 bytes), byte offset of the row words (int32 [C][tiles][R]:
+// offset inside the row's segment << 13 | count), row_cap, R } of a front run with GSX_PROJ_ROW_KEYS
+extern "C" int gsx_front_rows_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int64_t *out4) {
+    GSX_CHECK_ARG(out4 && N >= 1 && C >= 1 && M_cap >= 1);
+    const FrontLayout L = front_layout(N, C, tile_w, tile_h, M_cap);
+    out4[0] = L.rowkeys_off; out4[1] = L.matrix_off; out4[2] = std::min<int64_t>(M_cap / L.R, (1 << 19) - 1); out4[3] = L.R;
     return GSX_OK;
 }
 

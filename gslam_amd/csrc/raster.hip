@@ -467,6 +467,7 @@ static int raster_track_fused_sorting_impl(const float *rec, const float *backgr
     ts.tile_near = tile_near; ts.stats = sort_stats; ts.id_max = id_max; ts.margin = cut_margin;
     ts.tile_placed = tile_placed; ts.inst = (const uint4 *)inst_recs; ts.n_inst = n_inst; ts.R = (int)R;
     ts.seg_cap = (int)seg_cap; ts.compact = compact;
+    ts.row_words = nullptr; ts.row_keys = nullptr; ts.row_cap = 0; ts.cursor = nullptr; ts.status = nullptr; ts.tile_span = nullptr;
     hipLaunchKernelGGL((raster_track_fused_kernel<12, true>), dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, rec,
                        backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, alphas, last_ids, v_rec,
                        tile_order, la, ts);
@@ -513,6 +514,50 @@ extern "C" int64_t gsx_raster_track_fused_lds_bytes(void) {
         return -1;
     }
     return (int64_t)attr.sharedSizeBytes;
+}
+
+// layouts of the front's workspace (isect_bin.hip)
+extern "C" int gsx_front_rows_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int64_t *out4);
+extern "C" int gsx_front_keys(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int flags, int64_t *out3);
+extern "C" int64_t gsx_front_workspace_bytes(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap);
+
+extern "C" int gsx_raster_track_fused_rows(const float *rec, const float *backgrounds, int32_t *flatten_ids, int64_t M_cap,
+                                           int64_t N, int64_t C, int W, int H, const float *gt, const float *exposure,
+                                           float w_photo, float *alphas, int32_t *last_ids, float *v_render, float *loss_rows,
+                                           float *v_rec, const int32_t *tile_order, int32_t *tile_work, uint32_t *tile_cut,
+                                           float cut_margin, int32_t *tile_near, int32_t *sort_stats, int32_t *tile_span,
+                                           int64_t *M_dev, int32_t *status, void *front_workspace, int64_t workspace_bytes,
+                                           void *stream) {
+    GSX_CHECK_ARG(rec && flatten_ids && gt && exposure && loss_rows && v_rec && M_dev && status && front_workspace);
+    GSX_CHECK_ARG(C >= 1 && C <= 255 && W > 0 && H > 0 && N >= 1 && M_cap >= 1 && M_cap < ((int64_t)1 << 31));
+    GSX_CHECK_ARG(tile_cut && cut_margin >= 0.f && cut_margin < 16.f);
+    const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
+    const int64_t T = C * tile_w * tile_h;
+    GSX_CHECK_ARG(T < ((int64_t)1 << 31));
+    if (workspace_bytes < gsx_front_workspace_bytes(N, C, tile_w, tile_h, M_cap)) {
+        gsx_set_error("gsx_raster_track_fused_rows: not the workspace of the front (%lld bytes)", (long long)workspace_bytes);
+        return GSX_E_WORKSPACE;
+    }
+    int64_t rl[4], kl[3];
+    if (gsx_front_rows_layout(N, C, tile_w, tile_h, M_cap, rl) != GSX_OK ||
+        gsx_front_keys(N, C, tile_w, tile_h, M_cap, GSX_PROJ_COMPACT, kl) != GSX_OK)
+        return GSX_E_INVALID;
+    GSX_CHECK_ARG(rl[3] <= 768);
+    char *ws = (char *)front_workspace;
+    TrackLossArgs la;
+    la.gt = gt; la.exposure = exposure; la.w_photo = w_photo; la.v_render = v_render; la.rows = loss_rows;
+    la.tile_work = tile_work;
+    TileSortArgs ts;
+    ts.keys = (unsigned long long *)(ws + kl[0]); ts.sorted = (unsigned long long *)(ws + kl[1]); ts.tile_cut = tile_cut;
+    ts.tile_near = tile_near; ts.stats = sort_stats; ts.id_max = (uint32_t)kl[2]; ts.margin = cut_margin;
+    ts.tile_placed = nullptr; ts.inst = nullptr; ts.n_inst = nullptr; ts.R = (int)rl[3]; ts.seg_cap = 0; ts.compact = 1;
+    ts.row_words = (const uint32_t *)(ws + rl[1]); ts.row_keys = (const unsigned long long *)(ws + rl[0]);
+    ts.row_cap = (int)rl[2]; ts.cursor = (unsigned long long *)M_dev; ts.status = status; ts.tile_span = tile_span;
+    hipLaunchKernelGGL((raster_track_fused_kernel<12, true>), dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, rec,
+                       backgrounds, (const int32_t *)nullptr, flatten_ids, M_cap, 1, W, H, tile_w, tile_h, alphas, last_ids,
+                       v_rec, tile_order, la, ts);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
 }
 
 extern "C" int gsx_raster_bwd(const float *rec, int CH, const float *backgrounds, const int32_t *offsets,

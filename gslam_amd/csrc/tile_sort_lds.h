@@ -114,9 +114,8 @@ __device__ __forceinline__ bool bucket_scan(int *s_cur, int *s_w, int limit) {
 // the NEXT slab.  Returns m >= 0, or -1 if even one bucket of the histogram holds more than CAPK keys (a pile of equal
 // depths: nothing written, take sort_all).  Every thread of the workgroup must call it; `pool` = POOL_BYTES of LDS nobody
 // else uses meanwhile, s_ctl = CTL_WORDS ints.
-__device__ __forceinline__ int sort_window(const u64 *__restrict__ keys, u64 *__restrict__ sorted, int32_t *__restrict__ flat,
-                                           int n, uint32_t lo_bits, uint32_t hi_bits, uint32_t id_max, void *pool,
-                                           int *s_ctl) {
+// first stage of sort_window: the pool is taken over, the control block and the bucket counters start from zero
+__device__ __forceinline__ void sort_window_begin(uint32_t hi_bits, void *pool, int *s_ctl) {
     u64 *s_a = reinterpret_cast<u64 *>(pool), *s_b = s_a + CAPK;
     int *s_cur = reinterpret_cast<int *>(s_b + CAPK);
     const int t = threadIdx.x;
@@ -124,36 +123,62 @@ __device__ __forceinline__ int sort_window(const u64 *__restrict__ keys, u64 *__
     if (t == 0) { s_ctl[0] = 0; s_ctl[1] = 0x7fffffff; s_ctl[2] = 0; s_ctl[3] = (int)hi_bits; }
     for (int i = t; i < NB; i += THREADS) s_cur[i] = 0;
     __syncthreads();
-    // a. the keys of the window, compacted into LDS in any order; range of their depths
-    auto filter = [&](uint32_t hi, bool store) {
-        unsigned int dmin = 0x7fffffffu, dmax = 0u;
-        for (int i0 = 0; i0 < n; i0 += 4 * THREADS) {          // four loads in flight per thread
-            u64 kk[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * THREADS + t;
-                kk[u] = (i < n) ? keys[i] : ~0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned int d = (unsigned int)(kk[u] >> 32);
-                if (d > lo_bits && d <= hi) {                  // (the padding's high word is 0xffffffff: never passes)
-                    if (store) {
-                        const int p = atomicAdd(&s_ctl[0], 1);
-                        if (p < CAPK) s_a[p] = kk[u];
-                    }
-                    dmin = min(dmin, d); dmax = max(dmax, d);
-                }
-            }
-        }
+}
+
+// a key of the window into the LDS list (any order), the range of the window's depths in the caller's registers
+struct WindowAcc {
+    unsigned int dmin = 0x7fffffffu, dmax = 0u;
+    __device__ __forceinline__ void add(u64 key, unsigned int d, void *pool, int *s_ctl) {
+        const int p = atomicAdd(&s_ctl[0], 1);
+        if (p < CAPK) reinterpret_cast<u64 *>(pool)[p] = key;
+        dmin = min(dmin, d); dmax = max(dmax, d);
+    }
+    __device__ __forceinline__ void finish(int *s_ctl) {     // every thread of the workgroup
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             dmin = min(dmin, (unsigned int)__shfl_xor((int)dmin, off, 64));
             dmax = max(dmax, (unsigned int)__shfl_xor((int)dmax, off, 64));
         }
-        if ((t & 63) == 0) { atomicMin(&s_ctl[1], (int)dmin); atomicMax(&s_ctl[2], (int)dmax); }
-    };
-    filter(hi_bits, true);
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_ctl[1], (int)dmin); atomicMax(&s_ctl[2], (int)dmax); }
+    }
+};
+
+__device__ __forceinline__ int sort_window_rest(const u64 *__restrict__ keys, u64 *__restrict__ sorted, int32_t *__restrict__ flat,
+                                                int n, uint32_t lo_bits, uint32_t hi_bits, uint32_t id_max, void *pool,
+                                                int *s_ctl);
+
+__device__ __forceinline__ int sort_window(const u64 *__restrict__ keys, u64 *__restrict__ sorted, int32_t *__restrict__ flat,
+                                           int n, uint32_t lo_bits, uint32_t hi_bits, uint32_t id_max, void *pool,
+                                           int *s_ctl) {
+    const int t = threadIdx.x;
+    sort_window_begin(hi_bits, pool, s_ctl);
+    // a. the keys of the window, compacted into LDS in any order; range of their depths
+    WindowAcc acc;
+    for (int i0 = 0; i0 < n; i0 += 4 * THREADS) {              // four loads in flight per thread
+        u64 kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * THREADS + t;
+            kk[u] = (i < n) ? keys[i] : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned int d = (unsigned int)(kk[u] >> 32);
+            if (d > lo_bits && d <= hi_bits) acc.add(kk[u], d, pool, s_ctl);   // (the padding's high word is 0xffffffff: never passes)
+        }
+    }
+    acc.finish(s_ctl);
+    return sort_window_rest(keys, sorted, flat, n, lo_bits, hi_bits, id_max, pool, s_ctl);
+}
+
+// Everything behind the first filter pass of a window (the window's keys - at most CAPK of them stored - sit in the LDS list, their
+// count in s_ctl[0], their depth range in s_ctl[1..2]); `keys[0..n)` is scanned again only if the window holds more than CAPK keys.
+__device__ __forceinline__ int sort_window_rest(const u64 *__restrict__ keys, u64 *__restrict__ sorted, int32_t *__restrict__ flat,
+                                                int n, uint32_t lo_bits, uint32_t hi_bits, uint32_t id_max, void *pool,
+                                                int *s_ctl) {
+    u64 *s_a = reinterpret_cast<u64 *>(pool), *s_b = s_a + CAPK;
+    int *s_cur = reinterpret_cast<int *>(s_b + CAPK);
+    const int t = threadIdx.x;
     __syncthreads();
     int m = s_ctl[0];
     if (m == 0) return 0;
@@ -259,6 +284,105 @@ __device__ __forceinline__ int sort_window(const u64 *__restrict__ keys, u64 *__
     }
     __syncthreads();
     return m;
+}
+
+// Row keys (gsx_front_fwd_rows, round 5): the front does not build tile segments at all - no count matrix scan, no placement launch.
+// Every projection workgroup leaves the keys of ITS row of Gaussians in the row's own segment, grouped by tile, and one word per
+// (camera, tile, row): offset inside the row's segment << ROW_SHIFT | count.  The tile's workgroup collects its keys itself:
+//   * reads its R words (one per thread, contiguous), scans the counts: the tile's total n and every row's place in the tile;
+//   * reserves [base, base + n) of the contiguous key buffer with ONE atomic on one of ROW_CURSORS cursors, each over its own
+//     1 / ROW_CURSORS of the buffer (segments are handed out in the order the tiles ask - nobody needs tile-major offsets in a
+//     pose-only closure; the cursors add up to the render's M.  ONE cursor was 1200 same-address atomics per launch, served one
+//     after the other: the tiles waited up to 20 us for their turn);
+//   * copies the rows' stretches into that segment (what later slabs and the through-memory paths scan) and feeds the keys of the
+//     first window (lo_bits, hi_bits] straight into the LDS list of sort_window_rest, which the caller runs next.
+// -> n (0 if the buffer is full: status bit 1, the overflow protocol of the launch plans), base in `base_out`.
+// Every thread of the workgroup must call it.  R <= 3 * THREADS rows.
+constexpr int ROW_SHIFT = 13;                  // count in the low 13 bits of a row word (a row holds at most 8192 instances)
+constexpr int ROW_CURSORS = 64;                // key counters of a render (tile t draws on counter t % 64)
+__device__ __forceinline__ int gather_tile_keys(const uint32_t *__restrict__ row_words, const u64 *__restrict__ row_keys, int R,
+                                                int row_cap, int64_t col /* index of the tile's first word: (camera * tiles + tile-in-camera) * R */, int n_tiles,
+                                                int tile, unsigned long long *__restrict__ cursors, int64_t M_cap,
+                                                int32_t *__restrict__ status, u64 *__restrict__ keys, uint32_t lo_bits,
+                                                uint32_t hi_bits, void *pool, int *s_ctl, int &base_out) {
+    const int t = threadIdx.x;
+    // (the column's words are requested before the pool is taken over: nothing below depends on the two barriers of the hand-over)
+    constexpr int RPT = 3;
+    uint32_t wd[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int r = t + u * THREADS;
+        wd[u] = (r < R) ? row_words[(int64_t)col + r] : 0u;
+    }
+    sort_window_begin(hi_bits, pool, s_ctl);
+    int cnt[RPT], off[RPT], sum = 0;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        cnt[u] = (int)(wd[u] & ((1u << ROW_SHIFT) - 1u));
+        off[u] = (int)(wd[u] >> ROW_SHIFT);
+        if (off[u] + cnt[u] > row_cap) cnt[u] = max(0, row_cap - off[u]);          // (a row that overflowed its segment: flagged by the front)
+        sum += cnt[u];
+    }
+    // the first four keys of the thread's first row: on their way while the counts are scanned and the segment is reserved
+    const u64 *src0 = row_keys + (int64_t)t * row_cap + off[0];
+    u64 k0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k0[j] = (j < cnt[0]) ? src0[j] : ~0ull;
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if ((t & 63) >= o) incl += v;
+    }
+    if ((t & 63) == 63) s_ctl[12 + (t >> 6)] = incl;
+    __syncthreads();
+    int dst = incl - sum, total = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) {
+        const int ws = s_ctl[12 + w];
+        dst += (w < (t >> 6)) ? ws : 0;
+        total += ws;
+    }
+    if (t == 0) {
+        long long base = -1;
+        if (total > 0) {
+            const long long sub = (long long)M_cap / ROW_CURSORS;
+            const int j = tile % ROW_CURSORS;
+            const long long local = (long long)atomicAdd(cursors + j, (unsigned long long)total);
+            base = (long long)j * sub + local;
+            if (local + total > sub) { atomicOr(status, 1); base = -1; }
+        }
+        s_ctl[11] = (int)base;
+    }
+    __syncthreads();
+    const int base = s_ctl[11];
+    base_out = max(base, 0);
+    if (base < 0) total = 0;
+    WindowAcc acc;
+    if (total > 0) {
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int r = t + u * THREADS;
+            const u64 *src = row_keys + (int64_t)r * row_cap + off[u];
+            u64 *out = keys + base + dst;
+            for (int i0 = 0; i0 < cnt[u]; i0 += 4) {           // four loads in flight
+                u64 kk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kk[j] = (u == 0 && i0 == 0) ? k0[j] : ((i0 + j < cnt[u]) ? src[i0 + j] : ~0ull);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (i0 + j < cnt[u]) {
+                        out[i0 + j] = kk[j];
+                        const unsigned int d = (unsigned int)(kk[j] >> 32);
+                        if (d > lo_bits && d <= hi_bits) acc.add(kk[j], d, pool, s_ctl);
+                    }
+                }
+            }
+            dst += cnt[u];
+        }
+    }
+    acc.finish(s_ctl);
+    return total;
 }
 
 // Near placement (gsx_front_fwd_near): the front placed only the keys in front of the tile's depth cut-off; the tile's segment keeps

@@ -36,6 +36,7 @@ _COMPACT = 32           # GSX_PROJ_COMPACT
 _CANDIDATES = 128       # GSX_PROJ_CANDIDATES
 _DEFER_SORT = 256       # GSX_PROJ_DEFER_SORT
 _MAP_RECORDS = 512      # GSX_PROJ_MAP_RECORDS
+_ROW_KEYS = 1024        # GSX_PROJ_ROW_KEYS
 
 
 def _arr(ptrs: Sequence[Optional[int]]):
@@ -307,6 +308,10 @@ class RenderPlan:
         self.tile_work = self.balanced_order = None
         # tile sort inside the fused tracking rasteriser (gsx_raster_track_fused_sorting): enable_defer_sort()
         self.defer_sort = False
+        self.row_keys = False         # the front ends with the projection; the rasteriser's tiles collect their keys (enable_row_keys)
+        self._rows_last = False       # the last front ran with row keys (M is the sum of self.key_counters then)
+        self.key_counters = None
+        self.tile_span = None
         self.near_place = False
         self.cut_margin = self.CUT_MARGIN
         self.tile_cut = self.tile_near = self.sort_stats = self.tile_placed = None
@@ -412,10 +417,16 @@ class RenderPlan:
             self._alloc_lists(want)
         return m
 
+    def keys_total(self) -> int:
+        """M of the last render (one blocking read): the front's count, or - row keys - the sum of the 64 key counters"""
+        if self.row_keys and self._rows_last:
+            return int(self.key_counters.sum().item())
+        return int(self.M_dev.item())
+
     def check_capacity(self) -> bool:
         """after the launches have been issued: True iff no render since the last check overflowed the tile lists.  On
         False the capacity has been grown (``stale`` is set): re-capture and redo.  One blocking read of 12 bytes."""
-        st, m = int(self.status.item()), int(self.M_dev.item())
+        st, m = int(self.status.item()), self.keys_total()
         self.last_M = m
         if st & 2:
             # the binning kernels clamped a negative / out-of-range tile count (hardening flag, csrc/isect_bin.hip): the
@@ -517,8 +528,11 @@ class RenderPlan:
     def _front(self, st: int, defer_sort: bool = False):
         m = self.map
         lean = self.lean
+        rows = bool(defer_sort and self.row_keys)
+        self._rows_last = rows
+        m_dev = self.key_counters if rows else self.M_dev
         flags = self.flags | (_SKIP_CULLED if lean else 0) | (_COMPACT if self.compact else 0) | self._cand_flags() | (
-            _DEFER_SORT if defer_sort else 0)
+            _DEFER_SORT if defer_sort else 0) | (_ROW_KEYS if rows else 0)
         if defer_sort and self.near_place:
             check(lib.gsx_front_fwd_near(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                          self.H, self.eps2d, self.near, self.far, flags, _p(m[3]), _p(m[4]), _p(m[5]),
@@ -534,7 +548,8 @@ class RenderPlan:
                                 None, None if self.compact else _p(self.tiles),
                                 _p(self.rec), self._clear_ptr(), None if self.compact else _p(self.vis_count),
                                 self.capacity, _p(self.offsets),
-                                _p(self.M_dev), _p(self.status), _p(self.flat), _p(self.tile_order),
+                                _p(m_dev), _p(self.status), _p(self.flat),
+                                None if rows else _p(self.tile_order),
                                 _p(self.tile_work), _p(self.balanced_order), self.CHUNK_COST, self.LIGHT_RATE, self.n_cus,
                                 _p(self.isect_ws), self.isect_ws.numel(), st), "gsx_front_fwd")
 
@@ -558,6 +573,25 @@ class RenderPlan:
         if not self.near_place:
             self.near_place = True
             self.tile_placed = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
+        return True
+
+    def enable_row_keys(self) -> bool:
+        """On top of ``enable_defer_sort``: the front stops after its projection launch - every projection workgroup leaves its row's
+        keys grouped by tile in the row's own segment (GSX_PROJ_ROW_KEYS) - and the rasteriser's tile workgroups collect their keys
+        themselves (gsx_raster_track_fused_rows): the column scan and the placement launch are gone from the closure's chain.
+        ``offsets`` is not written; ``tile_span[t] = (start, count)`` of every tile's segment and ``M_dev`` come out of the
+        rasteriser launch.  Same composited lists, entry for entry.  -> whether this plan's shape qualifies."""
+        if not (self.defer_sort and self.compact and not self.near_place):
+            return False
+        lay = (C.c_int64 * 4)()
+        check(lib.gsx_front_rows_layout(self.N, self.C, self.tile_w, self.tile_h, 4096, lay), "gsx_front_rows_layout")
+        if int(lay[3]) > 768:
+            return False
+        if not self.row_keys:
+            self.row_keys = True
+            self.tile_span = torch.zeros(self.T, 2, dtype=torch.int32, device=self.dev)
+            # 64 key counters (tile t draws its segment on counter t % 64; their sum is the render's M)
+            self.key_counters = torch.zeros(64, dtype=torch.int64, device=self.dev)
         return True
 
     def enable_defer_sort(self, margin: Optional[float] = None) -> bool:
@@ -613,6 +647,15 @@ class RenderPlan:
         of every tile in one launch (pose-only CH = 4 plans); follow with backward(st, rasterised=True)"""
         assert self.CH == 4 and self.geom_only and self.n_touched is None and self.capacity > 0
         gt, exposure, w_photo, rows = track_loss
+        if self.front and self.defer_sort and self.row_keys:
+            self._front(st, defer_sort=True)
+            check(lib.gsx_raster_track_fused_rows(
+                _p(self.rec), _p(self.backgrounds), _p(self.flat), self.capacity, self.N, self.C, self.W, self.H, _p(gt),
+                _p(exposure), float(w_photo), None, None, None, _p(rows), _p(self.v_rec), _p(self.launch_order),
+                _p(self.tile_work), _p(self.tile_cut), float(self.cut_margin), _p(self.tile_near), _p(self.sort_stats),
+                _p(self.tile_span), _p(self.key_counters), _p(self.status), _p(self.isect_ws), self.isect_ws.numel(), st),
+                "gsx_raster_track_fused_rows")
+            return
         if self.front and self.defer_sort:
             self._front(st, defer_sort=True)
             lay = (C.c_int64 * 3)()
@@ -785,7 +828,7 @@ class TrackClosure:
 
     def __init__(self, splats, camera, tail: str = 'fused', fuse_raster: bool = True, front: Optional[bool] = None,
                  candidates: bool = False, defer_sort: Optional[bool] = None, map_records: Optional[bool] = None,
-                 near_place: Optional[bool] = None):
+                 near_place: Optional[bool] = None, row_keys: Optional[bool] = None):
         """near_place: the front leaves the keys behind a tile's depth cut-off out of the placement (RenderPlan.enable_near_placement).
         OFF by default - built, exact and measured in round 5: with 31 % of the keys written the placement launch is
         as long as before (26.5 against 25.1 us: it is a chain of latencies, not of stores), the projection pays 1.5 us for the
@@ -837,6 +880,10 @@ class TrackClosure:
                 self.r.enable_near_placement()
             else:
                 self.r.enable_defer_sort()
+                # row_keys: no column scan, no placement launch - the rasteriser's tiles collect their keys from the projection
+                # rows (RenderPlan.enable_row_keys); None = wherever the sort runs inside the rasteriser
+                if row_keys is None or row_keys:
+                    self.r.enable_row_keys()
         self.stream = torch.cuda.Stream(device=dev)
         self.graph = HipGraph()
         self._chains: Dict[int, HipGraph] = {}

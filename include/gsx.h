@@ -66,6 +66,15 @@ extern "C" {
                                      candidate set of gsx_front_candidates; closures whose poses stay within its margins project
                                      the candidates' pose-independent records instead of culling all N Gaussians again - same
                                      results bit for bit, and a closure outside the margins takes the full path by itself */
+#define GSX_PROJ_ROW_KEYS 1024    /* gsx_front_fwd only, with GSX_PROJ_COMPACT | GSX_PROJ_DEFER_SORT (round 5): the front ENDS with the
+                                     projection launch - no count-matrix scan, no placement launch.  Every projection workgroup leaves
+                                     the keys of its row of Gaussians in the row's own segment of the workspace, grouped by tile, and
+                                     one word per (camera, tile, row): offset inside the segment << 13 | count (gsx_front_rows_layout).
+                                     offsets / flatten_ids are not written; M_dev is int64 [64] here: 64 key counters, zeroed by this
+                                     launch, whose SUM is the render's M once the consumer's tile workgroups have collected their
+                                     keys (gsx_raster_track_fused_rows: tile t reserves its segment on counter t % 64, each counter
+                                     over its own 64th of the key buffer); status bit 1 also reports a row that outgrew its segment
+                                     (M_cap / rows keys) or a counter that outgrew its 64th. */
 #define GSX_PROJ_MAP_RECORDS 512   /* with GSX_PROJ_CANDIDATES, to gsx_front_candidates / gsx_front_fwd / gsx_front_pose_bwd: the
                                      candidate area holds the pose-independent record of EVERY Gaussian (slot = Gaussian
                                      index; margins ignored) and a packed cull row (mean, largest scale squared) each.  Valid
@@ -260,6 +269,23 @@ int gsx_raster_track_fused_sorting(const float *rec, const float *backgrounds, c
                                    uint64_t *keys, uint64_t *keys_sorted, uint32_t id_max, uint32_t *tile_cut,
                                    float cut_margin, int32_t *tile_near, int32_t *sort_stats, void *stream);
 int gsx_front_keys(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int flags, int64_t *out3);
+/* out4 = { byte offset of the row segments of keys ([rows][row_cap] x 8 bytes), byte offset of the row words (int32 [C][tiles][rows]),
+ * row_cap, rows } of a front run with GSX_PROJ_ROW_KEYS in a workspace of gsx_front_workspace_bytes(.., M_cap) */
+int gsx_front_rows_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int64_t *out4);
+/* gsx_raster_track_fused_sorting behind a front that ran with GSX_PROJ_ROW_KEYS: every tile's workgroup first COLLECTS its keys -
+ * reads its column of row words, reserves a segment of the contiguous key buffer with one atomic on one of the 64 counters M_dev [64]
+ * (segments are handed out in the order the tiles ask; tile_span [T][2] = {start, count} of every tile, out), copies the rows'
+ * stretches there and feeds the
+ * keys of the first depth window straight into the LDS sort - and then runs exactly the launch above on that segment.  Two launches
+ * (column scan, placement) and the 8-fold re-read of the instance records are gone from the closure's chain; what a tile composites
+ * is the reference's list, entry for entry (gslam/rasterization.py:259-274).  status: the plan's sticky status word (bit 1: the
+ * key buffer is full). */
+int gsx_raster_track_fused_rows(const float *rec, const float *backgrounds, int32_t *flatten_ids, int64_t M_cap, int64_t N,
+                                int64_t C, int W, int H, const float *gt, const float *exposure, float w_photo, float *alphas,
+                                int32_t *last_ids, float *v_render, float *loss_rows, float *v_rec, const int32_t *tile_order,
+                                int32_t *tile_work, uint32_t *tile_cut, float cut_margin, int32_t *tile_near,
+                                int32_t *sort_stats, int32_t *tile_span, int64_t *M_dev, int32_t *status,
+                                void *front_workspace, int64_t workspace_bytes, void *stream);
 /* static LDS bytes of a workgroup of gsx_raster_track_fused_sorting's kernel, read off the loaded code object (-1 on error) */
 int64_t gsx_raster_track_fused_lds_bytes(void);
 

@@ -433,7 +433,7 @@ def test_fused_raster_launch_equals_forward_then_backward(dev, front):
     st = current_stream_ptr(dev)
     res = []
     for fuse in (False, True):
-        c = TrackClosure(splats, cam, fuse_raster=fuse, front=front)
+        c = TrackClosure(splats, cam, fuse_raster=fuse, front=front, row_keys=False)   # (tile-major segments compared)
         assert c.fuse_raster == fuse and c.r.front == front
         c.load(make_viewmat(2.0).to(dev), img, torch.tensor([0.02, -0.01], device=dev))
         c.r.probe()
@@ -669,7 +669,7 @@ def test_tile_sort_inside_the_rasteriser_equals_the_sort_launch(dev, n_gauss, sc
     img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(8)).to(dev)
     st = current_stream_ptr(dev)
     ref = TrackClosure(splats, cam, defer_sort=False)
-    new = TrackClosure(splats, cam, defer_sort=True, near_place=near_place)
+    new = TrackClosure(splats, cam, defer_sort=True, near_place=near_place, row_keys=False)   # (the front builds the tile segments)
     assert new.r.defer_sort and not ref.r.defer_sort and new.r.near_place == near_place
     for c in (ref, new):
         c.load(make_viewmat(2.0).to(dev), img, torch.tensor([0.02, -0.01], device=dev))
@@ -788,7 +788,7 @@ def test_tile_sort_inside_the_rasteriser_with_piles_of_equal_depths(dev):
         img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(8)).to(dev)
         st = current_stream_ptr(dev)
         ref = TrackClosure(splats, cam, defer_sort=False)
-        new = TrackClosure(splats, cam, defer_sort=True)
+        new = TrackClosure(splats, cam, defer_sort=True, row_keys=False)
         for c in (ref, new):
             c.load(V.to(dev), img, torch.zeros(2, device=dev))
             c.r.probe()
@@ -810,3 +810,118 @@ def test_tile_sort_inside_the_rasteriser_with_piles_of_equal_depths(dev):
                 assert (fa[lo:lo + n] == fb[lo:lo + n]).all(), f"closure {closure}: tile {t}: sorted part differs from the full list"
             assert float((a[0] - b[0]).abs().max()) <= 2e-6 * float(a[0].abs().max()) + 1e-12
             assert float((a[2] - b[2]).abs().max()) <= 1e-4 * float(a[2].abs().max()) + 1e-12
+
+
+def _row_keys_outputs(c, st, H, W):
+    tl = (c.img, c.exposure, 1.0 / (H * W), c.loss_rows)
+    c.r.v_rec.zero_()
+    c.r.forward_track_fused(st, tl)
+    torch.cuda.synchronize()
+    v_rec = c.r.v_rec.clone()
+    c.r.backward(st, rasterised=True)
+    torch.cuda.synchronize()
+    assert c.r.check_capacity()
+    return (c.loss_rows.clone(), c.r.tile_work.clone(), v_rec, c.r.flat.clone(), c.r.tile_near.clone(),
+            c.r.pose_ws.view(torch.float32)[:c.r.pose_blocks * 12].clone())
+
+
+@pytest.mark.parametrize("n_gauss,scale_up,planes", [(80000, 0.4, False), (300000, 0.9, False), (150000, 0.9, True)])
+def test_tiles_collect_their_keys_from_the_projection_rows(dev, n_gauss, scale_up, planes):
+    """GSX_PROJ_ROW_KEYS + gsx_raster_track_fused_rows (round 5): the front ends with its projection launch - every projection
+    workgroup leaves its row's keys grouped by tile in the row's own segment - and the rasteriser's tile workgroups collect their
+    keys themselves (one atomic on the render's key counter hands out the segments).  Against the front that builds the tile
+    segments (count matrix -> column scan -> placement): the same number of keys in every tile, the same keys (as multisets: the
+    segments are unsorted), the consumed prefix of every tile's sorted list entry for entry, loss rows bit for bit, gradient
+    records and pose partials to float-atomic noise, M equal - in a first closure (no cut-offs), a second one, after a pose jump
+    (cut-offs of the old pose: further slabs are read from the tile's own copy of its keys) and with cut-offs far too tight; on a
+    scene whose tiles outgrow the LDS sort; on piles of equal depths (the through-memory sort over the collected segment); and
+    through the captured closure: same optimiser trajectory."""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.plan import TrackClosure, current_stream_ptr
+    from gslam_amd.primitives import Camera
+    from gslam_amd.synthetic import make_intrinsics, make_scene, make_viewmat
+    from gslam_amd._lib import lib as _l
+    W, H = 640, 480
+    sc = make_scene(n_gauss, 6)
+    sc["scales"] = sc["scales"] + scale_up
+    V0 = make_viewmat(2.0)
+    if planes:
+        g = torch.Generator().manual_seed(4)
+        sc["means"][:, 0] = (torch.rand(n_gauss, generator=g) - 0.5) * 4.0
+        sc["means"][:, 1] = (torch.rand(n_gauss, generator=g) - 0.5) * 3.0
+        sc["means"][:, 2] = 0.0
+        V0 = torch.eye(4)
+        V0[2, 3] = 3.0
+    splats = GaussianSplattingData.from_dict(sc, dev)
+    cam = Camera(make_intrinsics(W, H).to(dev), H, W)
+    img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(8)).to(dev)
+    st = current_stream_ptr(dev)
+    ref = TrackClosure(splats, cam, defer_sort=True, row_keys=False)
+    new = TrackClosure(splats, cam, defer_sort=True)
+    assert new.r.row_keys and not ref.r.row_keys
+    for c in (ref, new):
+        c.load(V0.to(dev), img, torch.tensor([0.02, -0.01], device=dev))
+        c.r.probe()
+    lay = (C.c_int64 * 3)()
+    _l.gsx_front_keys(new.r.N, new.r.C, new.r.tile_w, new.r.tile_h, new.r.capacity, 32, lay)
+
+    def compare(what, check_keys=False):
+        a, b = _row_keys_outputs(ref, st, H, W), _row_keys_outputs(new, st, H, W)
+        off = ref.r.offsets[:ref.r.T + 1].cpu().numpy()
+        sizes = off[1:] - off[:-1]
+        span = new.r.tile_span.cpu().numpy()
+        assert (span[:, 1] == sizes).all(), what                                   # every tile collected what the front would place
+        assert new.r.keys_total() == ref.r.keys_total() == int(sizes.sum()), what
+        assert torch.equal(a[4], b[4]), what                                       # same consumed prefix lengths
+        near = b[4].cpu().numpy()
+        fa, fb = a[3].cpu().numpy(), b[3].cpu().numpy()
+        for t in range(new.r.T):
+            n = int(near[t])
+            assert (fa[off[t]:off[t] + n] == fb[span[t, 0]:span[t, 0] + n]).all(), f"{what}: tile {t}: consumed prefix differs"
+        assert torch.equal(a[0], b[0]), what                                       # loss rows: same lists, same arithmetic
+        assert torch.equal(a[1], b[1]), what                                       # work counters
+        assert float(a[2].abs().max()) > 0
+        assert float((a[2] - b[2]).abs().max()) < 1e-4 * float(a[2].abs().max()), what
+        assert float((a[5] - b[5]).abs().max()) < 2e-4 * float(a[5].abs().max()) + 1e-12, what
+        if check_keys:                                                             # the collected segments as multisets of keys
+            ka = ref.r.isect_ws[int(lay[0]):int(lay[0]) + 8 * int(off[-1])].view(torch.int64).cpu().numpy()
+            kb = new.r.isect_ws[int(lay[0]):int(lay[0]) + 8 * new.r.capacity].view(torch.int64).cpu().numpy()   # (segments anywhere)
+            for t in range(0, new.r.T, 5):
+                assert sorted(ka[off[t]:off[t + 1]].tolist()) == sorted(kb[span[t, 0]:span[t, 0] + span[t, 1]].tolist()), (what, t)
+        return sizes, near
+
+    sizes, near1 = compare("first closure", check_keys=True)
+    if n_gauss >= 300000:
+        assert sizes.max() > 1152
+    new.r.sort_stats.zero_()
+    sizes, near2 = compare("second closure")
+    assert planes or near2.sum() < 0.97 * sizes.sum()
+    if not planes:
+        V2 = V0.clone()
+        cth, sth = float(np.cos(0.06)), float(np.sin(0.06))
+        V2 = torch.tensor([[cth, 0.0, sth, 0.0], [0.0, 1.0, 0.0, 0.0], [-sth, 0.0, cth, 0.0], [0.0, 0.0, 0.0, 1.0]]) @ V2
+        V2[0, 3] += 0.05
+        for c in (ref, new):
+            c.r.viewmats[0].copy_(V2.to(dev))
+        compare("pose jump", check_keys=True)
+        assert int(new.r.sort_stats[0].item()) > 0 or n_gauss >= 300000            # cut-offs failed, later slabs were sorted
+    for c in (ref, new):
+        c.r.tile_cut.fill_(0x3a83126f)                                             # depth 0.001: an empty first slab everywhere
+    compare("cut-offs too tight")
+    if planes:
+        assert int(new.r.sort_stats[1].item()) > 0                                 # piles went through the memory merge sort
+    # the whole closure, captured
+    for c in (ref, new):
+        c.load(V0.to(dev), img, torch.tensor([0.02, -0.01], device=dev))
+        c.prepare()
+        c.load(V0.to(dev), img, torch.tensor([0.02, -0.01], device=dev))
+        c.init_optimizer(4, 1e-3, 5, 8)
+        c.launch(10)
+    torch.cuda.synchronize()
+    assert ref.r.check_capacity() and new.r.check_capacity()
+    ra, rb = ref.read_report().cpu(), new.read_report().cpu()
+    # (same lists, same per-pixel arithmetic; the gradient records are summed by float atomics in another order, and ten steps
+    # of Adam + line search amplify the last bits)
+    assert torch.equal(ra[:4], rb[:4]), (ra, rb)
+    assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
+    assert float((ref.r.viewmats - new.r.viewmats).abs().max()) < 5e-3

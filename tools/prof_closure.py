@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--light-rate", type=float, default=None, help="RenderPlan.LIGHT_RATE (A/B)")
     ap.add_argument("--cut-margin", type=float, default=None, help="RenderPlan.CUT_MARGIN of the in-rasteriser tile sort (A/B)")
     ap.add_argument("--no-defer-sort", action="store_true", help="stand-alone tile sort launch (A/B)")
+    ap.add_argument("--no-row-keys", action="store_true", help="count matrix scan + placement launch instead of row keys (A/B)")
     ap.add_argument("--no-near", action="store_true", help="every key placed (round-4 placement), sort inside the rasteriser (A/B)")
     ap.add_argument("--near-margin", type=float, default=None, help="RenderPlan.NEAR_MARGIN of the near placement (A/B)")
     args = ap.parse_args()
@@ -43,6 +44,9 @@ def main():
     if args.cut_margin is not None:
         import gslam_amd.plan as P3
         P3.RenderPlan.CUT_MARGIN = args.cut_margin
+    if args.no_row_keys:
+        import gslam_amd.plan as P9
+        P9.RenderPlan.enable_row_keys = lambda self: False
     if args.near_margin is not None:
         import gslam_amd.plan as P6
         P6.RenderPlan.NEAR_MARGIN = args.near_margin
@@ -91,6 +95,8 @@ def main():
         st4 = r.sort_stats.cpu().tolist()
         near, off = r.tile_near.cpu().numpy(), r.offsets.cpu().numpy()
         sizes = off[1:r.T + 1] - off[:r.T]
+        if getattr(r, "row_keys", False):
+            sizes = r.tile_span.cpu().numpy()[:, 1]
         if getattr(r, "near_place", False):
             print(f"near placement: {int(r.tile_placed.sum())} of {int(sizes.sum())} keys placed in the last closure, "
                   f"{st4[2]} tiles appended their far keys over all closures so far, {st4[3]} inconsistent")
