@@ -162,7 +162,7 @@ def in_graph_launch_us(plan, stage, resets, n_closures, frames=3):
     lib = _lib.lib
     fn = getattr(lib, stage)
     vrec_arg = {"gsx_raster_bwd": 16, "gsx_raster_track_fused": 16, "gsx_raster_track_fused_sorting": 16,
-                "gsx_raster_track_fused_rows": 15}.get(stage)
+                "gsx_raster_track_fused_rows": 16}.get(stage)
     scratch = torch.zeros_like(plan.r.v_rec) if vrec_arg is not None else None
     torch.cuda.synchronize()
 

@@ -115,7 +115,7 @@ PROTOTYPES = {
                                  vp, vp, f32, f32, i32, vp, i64, vp, vp, vp]),
     "gsx_raster_track_fused_lds_bytes": (i64, []),
     "gsx_front_rows_layout": (i32, [i64, i64, i32, i32, i64, C.POINTER(i64)]),
-    "gsx_raster_track_fused_rows": (i32, [vp, vp, vp, i64, i64, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, f32,
+    "gsx_raster_track_fused_rows": (i32, [vp, vp, vp, i64, i64, i64, i32, i32, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32,
                                           vp, vp, vp, vp, vp, vp, i64, vp]),
     "gsx_front_keys": (i32, [i64, i64, i32, i32, i64, i32, C.POINTER(i64)]),
     "gsx_front_workspace_bytes": (i64, [i64, i64, i32, i32, i64]),

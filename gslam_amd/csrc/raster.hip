@@ -130,7 +130,7 @@ struct Quad {
 __device__ __forceinline__ Quad make_quad(int tile_w, int tile_h, int W, int H, int tile = -1) {
     Quad q;
     const int tiles_per_cam = tile_w * tile_h;
-    q.tile = tile >= 0 ? tile : (int)blockIdx.x;
+    q.tile = tile >= 0 ? min(tile, (int)gridDim.x - 1) : (int)blockIdx.x;      // (a launch order is a permutation; garbage stays in range)
     q.c = q.tile / tiles_per_cam;
     const int tl = q.tile - q.c * tiles_per_cam;
     const int ty = tl / tile_w, tx = tl - ty * tile_w;
@@ -162,7 +162,7 @@ struct Half {
 __device__ __forceinline__ Half make_half(int tile_w, int tile_h, int W, int H, int tile = -1) {
     Half q;
     const int tiles_per_cam = tile_w * tile_h;
-    q.tile = tile >= 0 ? tile : (int)blockIdx.x;
+    q.tile = tile >= 0 ? min(tile, (int)gridDim.x - 1) : (int)blockIdx.x;      // (a launch order is a permutation; garbage stays in range)
     q.c = q.tile / tiles_per_cam;
     const int tl = q.tile - q.c * tiles_per_cam;
     const int ty = tl / tile_w, tx = tl - ty * tile_w;
@@ -413,7 +413,7 @@ extern "C" int gsx_raster_fwd_track_loss(const float *rec, const float *backgrou
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
     TrackLossArgs la;
     la.gt = gt; la.exposure = exposure; la.w_photo = w_photo; la.v_render = v_render; la.rows = loss_rows;
-    la.tile_work = tile_work;
+    la.tile_work = tile_work; la.refiner_loss = 0;
     hipLaunchKernelGGL((raster_fwd_kernel4q<4, 12, false, true>), dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, rec,
                        backgrounds, offsets, flatten_ids, M, offsets_has_end, W, H, tile_w, tile_h, 0.5f, render, alphas,
                        last_ids, (int32_t *)nullptr, tile_order, la);
@@ -433,7 +433,7 @@ extern "C" int gsx_raster_track_fused(const float *rec, const float *backgrounds
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
     TrackLossArgs la;
     la.gt = gt; la.exposure = exposure; la.w_photo = w_photo; la.v_render = v_render; la.rows = loss_rows;
-    la.tile_work = tile_work;
+    la.tile_work = tile_work; la.refiner_loss = 0;
     hipLaunchKernelGGL((raster_track_fused_kernel<12, false>), dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, rec,
                        backgrounds, offsets, const_cast<int32_t *>(flatten_ids), M, offsets_has_end, W, H, tile_w, tile_h, alphas,
                        last_ids, v_rec, tile_order, la, TileSortArgs{});
@@ -461,7 +461,7 @@ static int raster_track_fused_sorting_impl(const float *rec, const float *backgr
     GSX_CHECK_ARG(T < ((int64_t)1 << 31));
     TrackLossArgs la;
     la.gt = gt; la.exposure = exposure; la.w_photo = w_photo; la.v_render = v_render; la.rows = loss_rows;
-    la.tile_work = tile_work;
+    la.tile_work = tile_work; la.refiner_loss = 0;
     TileSortArgs ts;
     ts.keys = (unsigned long long *)keys; ts.sorted = (unsigned long long *)keys_sorted; ts.tile_cut = tile_cut;
     ts.tile_near = tile_near; ts.stats = sort_stats; ts.id_max = id_max; ts.margin = cut_margin;
@@ -523,12 +523,13 @@ extern "C" int64_t gsx_front_workspace_bytes(int64_t N, int64_t C, int tile_w, i
 
 extern "C" int gsx_raster_track_fused_rows(const float *rec, const float *backgrounds, int32_t *flatten_ids, int64_t M_cap,
                                            int64_t N, int64_t C, int W, int H, const float *gt, const float *exposure,
-                                           float w_photo, float *alphas, int32_t *last_ids, float *v_render, float *loss_rows,
-                                           float *v_rec, const int32_t *tile_order, int32_t *tile_work, uint32_t *tile_cut,
-                                           float cut_margin, int32_t *tile_near, int32_t *sort_stats, int32_t *tile_span,
-                                           int64_t *M_dev, int32_t *status, void *front_workspace, int64_t workspace_bytes,
-                                           void *stream) {
+                                           float w_photo, int loss_kind, float *alphas, int32_t *last_ids, float *v_render,
+                                           float *loss_rows, float *v_rec, const int32_t *tile_order, int32_t *tile_work,
+                                           uint32_t *tile_cut, float cut_margin, int32_t *tile_near, int32_t *sort_stats,
+                                           int32_t *tile_span, int64_t *M_dev, int32_t *status, void *front_workspace,
+                                           int64_t workspace_bytes, void *stream) {
     GSX_CHECK_ARG(rec && flatten_ids && gt && exposure && loss_rows && v_rec && M_dev && status && front_workspace);
+    GSX_CHECK_ARG(loss_kind == 0 || loss_kind == 1);
     GSX_CHECK_ARG(C >= 1 && C <= 255 && W > 0 && H > 0 && N >= 1 && M_cap >= 1 && M_cap < ((int64_t)1 << 31));
     GSX_CHECK_ARG(tile_cut && cut_margin >= 0.f && cut_margin < 16.f);
     const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
@@ -546,7 +547,7 @@ extern "C" int gsx_raster_track_fused_rows(const float *rec, const float *backgr
     char *ws = (char *)front_workspace;
     TrackLossArgs la;
     la.gt = gt; la.exposure = exposure; la.w_photo = w_photo; la.v_render = v_render; la.rows = loss_rows;
-    la.tile_work = tile_work;
+    la.tile_work = tile_work; la.refiner_loss = loss_kind;
     TileSortArgs ts;
     ts.keys = (unsigned long long *)(ws + kl[0]); ts.sorted = (unsigned long long *)(ws + kl[1]); ts.tile_cut = tile_cut;
     ts.tile_near = tile_near; ts.stats = sort_stats; ts.id_max = (uint32_t)kl[2]; ts.margin = cut_margin;

@@ -642,16 +642,18 @@ class RenderPlan:
     def launch_order(self):
         return self.balanced_order if self.balanced_order is not None else self.tile_order
 
-    def forward_track_fused(self, st: int, track_loss):
+    def forward_track_fused(self, st: int, track_loss, refiner_loss: bool = False):
         """front + gsx_raster_track_fused: the forward rasteriser, the tracking loss and the geometry-only rasteriser backward
         of every tile in one launch (pose-only CH = 4 plans); follow with backward(st, rasterised=True)"""
         assert self.CH == 4 and self.geom_only and self.n_touched is None and self.capacity > 0
+        assert not refiner_loss or (self.front and self.defer_sort and self.row_keys), "the refiner's loss: row-keys plans only"
         gt, exposure, w_photo, rows = track_loss
         if self.front and self.defer_sort and self.row_keys:
             self._front(st, defer_sort=True)
             check(lib.gsx_raster_track_fused_rows(
                 _p(self.rec), _p(self.backgrounds), _p(self.flat), self.capacity, self.N, self.C, self.W, self.H, _p(gt),
-                _p(exposure), float(w_photo), None, None, None, _p(rows), _p(self.v_rec), _p(self.launch_order),
+                _p(exposure), float(w_photo), 1 if refiner_loss else 0, None, None, None, _p(rows), _p(self.v_rec),
+                _p(self.balanced_order),      # (never self.tile_order: a front with row keys does not write the length-sorted order)
                 _p(self.tile_work), _p(self.tile_cut), float(self.cut_margin), _p(self.tile_near), _p(self.sort_stats),
                 _p(self.tile_span), _p(self.key_counters), _p(self.status), _p(self.isect_ws), self.isect_ws.numel(), st),
                 "gsx_raster_track_fused_rows")
@@ -1020,11 +1022,29 @@ class WindowClosure:
     pose parameters; the strong-Wolfe L-BFGS state machine (history 10, <= 80 parameters, csrc/window_opt.hip) advanced
     at its end.  Poses, exposure and images live in slots of the plan; ``load`` / ``store`` move a window in and out."""
 
-    def __init__(self, splats, cameras, learnable: Sequence[bool], active_gs: bool = True):
+    def __init__(self, splats, cameras, learnable: Sequence[bool], active_gs: bool = True, fused: Optional[bool] = None):
+        """fused (round 5): the closure on the tracking closure's machinery - fused front with records per
+        visible instance, row keys (no column scan, no placement launch), the tile sort inside the rasteriser up to the tile's
+        depth cut-off, forward + the refiner's loss + geometry-only backward of a tile in one launch
+        (gsx_raster_track_fused_rows, loss_kind 1), pose gradient over the visible instances: 6 launches for 12.  Parity-green
+        (tests/test_gpu_plans.py::test_window_closure_on_the_tracking_machinery_equals_the_generic_path) and, measured at
+        500 k x 8 cameras (tools/dbg/window_closure_run.py), SLOWER than the generic chain: 904.6 against 860.1 us per closure -
+        the projection workgroups walk 8 cameras one after the other (258 us against 57 + 64 for projection + placement) and the
+        9600 tiles collect their keys from 245 rows each (2.35 M stretches of ~6 keys; the fused launch 571 us against 139 + 76 +
+        308 for forward + sort + backward).  So the default is the generic chain; True asks for this one where the shape
+        qualifies (active_gs loss, the window's tiles fit the front's LDS plan)."""
         Cn = len(cameras)
         self.C = Cn
         Ks = torch.stack([c.intrinsics for c in cameras], dim=0)
-        self.r = RenderPlan(splats, Cn, cameras[0].width, cameras[0].height, render_depth=False, grads='pose')
+        self.fused = False
+        if active_gs and fused:
+            r = RenderPlan(splats, Cn, cameras[0].width, cameras[0].height, render_depth=False, grads='pose', front=True)
+            if r.front and r.compact and r.enable_map_records() and r.enable_defer_sort() and r.enable_row_keys():
+                self.r = r
+                self.fused = True
+                self.loss_rows = torch.zeros(r.T, 6, device=r.dev)
+        if not self.fused:
+            self.r = RenderPlan(splats, Cn, cameras[0].width, cameras[0].height, render_depth=False, grads='pose')
         self.r.Ks.copy_(Ks)
         dev = self.r.dev
         self.dev = dev
@@ -1062,6 +1082,8 @@ class WindowClosure:
         for i, x in enumerate(window):
             self.gt[i].copy_(x.img)
             self.exposure[i].copy_(x.exposure_params.detach().reshape(2))
+        if self.fused:
+            self.r.build_candidates()                   # records of the map as it is now (one launch per refinement)
 
     def store(self, window):
         self.slots.store([x.pose for x in window])
@@ -1069,14 +1091,26 @@ class WindowClosure:
     def enqueue(self, st: int, advance: bool = True):
         r = self.r
         self.slots.forward(r.viewmats, st)
-        r.forward(st)
-        denom = _photometric_loss(r, self.gt, self.exposure, self.mode, 1.0, self.map_ws, st, use_alphas=True)
-        r.backward(st)
-        self.slots.backward_partials(r, st)
-        pm = 1.0 / denom
-        c0 = (C.c_float * 5)(pm, pm, 0.0, 0.0, 0.0)
-        check(lib.gsx_loss_finish(_p(self.map_ws), r.C, r.H, r.W, None, 0, None, 0, c0, c0, 0.0, 0.0, None,
-                                  _p(self.g_exposure), _p(self.out2), st), "gsx_loss_finish")
+        if self.fused:
+            denom = r.C * r.H * r.W
+            r.forward_track_fused(st, (self.gt, self.exposure, 1.0 / denom, self.loss_rows), refiner_loss=True)
+            r.backward(st, rasterised=True)
+            self.slots.backward_partials(r, st)
+            pm = 1.0 / denom
+            c0 = (C.c_float * 5)(pm, pm, 0.0, 0.0, 0.0)
+            # the loss rows are one per TILE here, camera-major: gsx_loss_finish takes "rows per camera = ceil(H * W / 256)", so it is
+            # told an image of (tiles per camera) x 256 pixels
+            check(lib.gsx_loss_finish(_p(self.loss_rows), r.C, r.tile_w * r.tile_h, 256, None, 0, None, 0, c0, c0, 0.0, 0.0,
+                                      None, _p(self.g_exposure), _p(self.out2), st), "gsx_loss_finish")
+        else:
+            r.forward(st)
+            denom = _photometric_loss(r, self.gt, self.exposure, self.mode, 1.0, self.map_ws, st, use_alphas=True)
+            r.backward(st)
+            self.slots.backward_partials(r, st)
+            pm = 1.0 / denom
+            c0 = (C.c_float * 5)(pm, pm, 0.0, 0.0, 0.0)
+            check(lib.gsx_loss_finish(_p(self.map_ws), r.C, r.H, r.W, None, 0, None, 0, c0, c0, 0.0, 0.0, None,
+                                      _p(self.g_exposure), _p(self.out2), st), "gsx_loss_finish")
         if advance:
             check(lib.gsx_window_opt_advance(_p(self.state), self.n_tensors, self._ps, self._gs, self._ns, _p(self.out2),
                                              st), "gsx_window_opt_advance")
@@ -1111,6 +1145,8 @@ class WindowClosure:
                 break
         else:
             raise RuntimeError("tile-list capacity keeps overflowing during warm-up")
+        if self.fused:
+            self.r.build_candidates(st)                      # (the probe re-allocated the workspace the records live in)
         _drop_chains(self)
         self.graph.capture(self.stream, self.enqueue)
         self.r.stale = False

@@ -281,7 +281,11 @@ int gsx_front_rows_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t 
  * is the reference's list, entry for entry (gslam/rasterization.py:259-274).  status: the plan's sticky status word (bit 1: the
  * key buffer is full). */
 int gsx_raster_track_fused_rows(const float *rec, const float *backgrounds, int32_t *flatten_ids, int64_t M_cap, int64_t N,
-                                int64_t C, int W, int H, const float *gt, const float *exposure, float w_photo, float *alphas,
+                                int64_t C, int W, int H, const float *gt, const float *exposure, float w_photo,
+                                int loss_kind /* 0: the tracker's loss sum_k err_k^2 / beta^2 (gslam/frontend.py:113-138); 1: the
+                                                 window refiner's sum_k err_k^2 / (2 beta^2) + log(beta)^2 / 2 (gslam/backend.py:
+                                                 484-492), loss_rows column 1 = the log term */,
+                                float *alphas,
                                 int32_t *last_ids, float *v_render, float *loss_rows, float *v_rec, const int32_t *tile_order,
                                 int32_t *tile_work, uint32_t *tile_cut, float cut_margin, int32_t *tile_near,
                                 int32_t *sort_stats, int32_t *tile_span, int64_t *M_dev, int32_t *status,

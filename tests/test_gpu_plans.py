@@ -931,3 +931,68 @@ def test_tiles_collect_their_keys_from_the_projection_rows(dev, n_gauss, scale_u
     # (the optimiser's discrete decisions - when the line search stops - may flip on those bits: compared are where the two ended up)
     assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
     assert float((ref.r.viewmats - new.r.viewmats).abs().max()) < 5e-3
+
+
+@pytest.mark.parametrize("n_gauss,n_cams,W,H", [(60000, 3, 640, 480), (200000, 8, 640, 480), (30000, 2, 325, 245)])
+def test_window_closure_on_the_tracking_machinery_equals_the_generic_path(dev, n_gauss, n_cams, W, H):
+    """WindowClosure(fused=True) (round 5): the closure of Backend.optimize_poses_lbfgs (gslam/backend.py:465-504) on the fused front
+    with row keys, the tile sort inside the rasteriser and forward + the refiner's loss (err^2 / (2 beta^2) + log(beta)^2 / 2) +
+    geometry-only backward in one launch - against the generic chain (projection, binning, sort, rasteriser forward, gsx_map_loss,
+    rasteriser backward, projection backward): loss and the gradient of every pose parameter of every camera, at the window's
+    poses, at perturbed ones (cut-offs of the previous evaluation), with and without the map's records, on an image whose size
+    is no multiple of the tile; then the captured closures with the device L-BFGS: same place after six evaluations."""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.plan import WindowClosure, current_stream_ptr
+    from gslam_amd.primitives import Camera, Frame, PoseZhou
+    from gslam_amd.synthetic import make_intrinsics, make_scene, make_viewmat
+    sc = make_scene(n_gauss, 3)
+    sc["scales"] = sc["scales"] + 0.5
+    splats = GaussianSplattingData.from_dict(sc, dev)
+    cam = Camera(make_intrinsics(W, H).to(dev), H, W)
+    g = torch.Generator().manual_seed(5)
+    window = []
+    for i in range(n_cams):
+        pose = PoseZhou(make_viewmat(0.6 * i).to(dev)).to(dev)
+        window.append(Frame(img=torch.rand(H, W, 3, generator=g).to(dev), timestamp=float(i), camera=cam, pose=pose,
+                            gt_pose=make_viewmat(0.6 * i).to(dev), index=i,
+                            exposure_params=torch.tensor([0.03 * i, -0.01 * i], device=dev)))
+    learnable = [i > 0 for i in range(n_cams)]
+    ref = WindowClosure(splats, [cam] * n_cams, learnable, fused=False)
+    new = WindowClosure(splats, [cam] * n_cams, learnable, fused=True)
+    assert new.fused and not ref.fused and new.r.row_keys and new.r.map_records
+    st = current_stream_ptr(dev)
+    for c in (ref, new):
+        c.load(window)
+        c.slots.forward(c.r.viewmats, st)
+        c.r.probe()
+    for k in range(4):
+        if k == 2:
+            new.r.build_candidates()                     # (evaluations 0 and 1 ran without records of the map: full projection path)
+        if k:
+            with torch.no_grad():
+                for c in (ref, new):
+                    c.slots.dt[1:, 0] += 0.004 * k
+                    c.slots.dR[1:, 1] += 0.003
+        for c in (ref, new):
+            c.enqueue(st, advance=False)
+        torch.cuda.synchronize()
+        assert ref.r.check_capacity() and new.r.check_capacity()
+        la, lb = float(ref.out2[0]), float(new.out2[0])
+        assert abs(la - lb) <= 2e-6 * abs(la), (k, la, lb)
+        for name in ("v_dt", "v_dR"):
+            a, b = getattr(ref.slots, name), getattr(new.slots, name)
+            assert float(a.abs().max()) > 0
+            assert float((a - b).abs().max()) <= 3e-4 * float(a.abs().max()), (k, name, a, b)
+        assert new.r.candidate_stats()[1] == (1 if k >= 2 else 0)
+    # captured, with the device optimiser
+    for c in (ref, new):
+        c.load(window)
+        c.prepare()
+        c.load(window)
+        c.init_optimizer(8)
+        c.launch(6)
+    torch.cuda.synchronize()
+    assert ref.r.check_capacity() and new.r.check_capacity()
+    ra, rb = ref.read_report().cpu(), new.read_report().cpu()
+    assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
+    assert float((ref.r.viewmats - new.r.viewmats).abs().max()) < 5e-3

@@ -23,6 +23,14 @@ def main():
     for i, f in enumerate(frames):
         f.index = i
         f.exposure_params = f.exposure_params.detach()
+    if os.environ.get("FUSED"):                         # the closure on the tracking machinery instead of the generic chain - A/B
+        import gslam_amd.plan as P1
+        o1 = P1.WindowClosure.__init__
+
+        def p1(self, *a, **k):
+            k["fused"] = True
+            o1(self, *a, **k)
+        P1.WindowClosure.__init__ = p1
     if os.environ.get("FRONT"):                         # force the fused front (default: generic path when C * N >= 2^20)
         import gslam_amd.plan as P
         orig = P.RenderPlan.__init__
@@ -43,7 +51,8 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     print(f"refinement {el / reps * 1e3:.2f} ms = {ref.max_eval + 1} closures x {el / reps / (ref.max_eval + 1) * 1e6:.1f} us; "
-          f"front={ref.plan.r.front} compact={ref.plan.r.compact} M={ref.plan.r.last_M} ok={ref.capacity_ok()}")
+          f"fused={getattr(ref.plan, 'fused', False)} front={ref.plan.r.front} compact={ref.plan.r.compact} "
+          f"M={ref.plan.r.last_M} ok={ref.capacity_ok()}")
     del ref, splats, frames        # graphs are destroyed before the interpreter (and a profiler) shuts down
 
 
