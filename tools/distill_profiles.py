@@ -101,7 +101,7 @@ if os.path.isdir(g(f"pmc_sq1_{tag}")):
                    "kernels": sq}, f, indent=1)
 bench = json.loads(line)
 if dom is None:
-    dom = {"gsx_raster_track_fused": "raster_track_fused", "gsx_raster_track_fused_sorting": "raster_track_fused", "gsx_raster_bwd": "raster_bwd",
+    dom = {"gsx_raster_track_fused": "raster_track_fused", "gsx_raster_track_fused_sorting": "raster_track_fused", "gsx_raster_track_fused_rows": "raster_track_fused", "gsx_raster_bwd": "raster_bwd",
            "gsx_raster_fwd_track_loss": "raster_fwd"}.get(bench.get("roofline", {}).get("kernel", ""), "raster_bwd")
 hit = [r for r in rows if dom in r[0] and "4q<4" in r[0]] or [r for r in rows if dom in r[0]]
 if hit:
