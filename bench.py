@@ -973,6 +973,7 @@ def cpu_baseline_ba(N, W, H, budget_s=20.0):
     from oracle.oracle import Oracle
     from gslam_amd.synthetic import make_cameras, make_scene
     o = Oracle(np.float32, threads=True)
+    o.set_threads(cores)          # (torch.distributed.run starts every rank with OMP_NUM_THREADS=1: ask for the host's cores explicitly)
     try:
         torch.set_num_threads(1)
     except Exception:
