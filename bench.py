@@ -56,6 +56,13 @@ def parse():
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads of the 1-GPU line")
     ap.add_argument("--ba-only", action="store_true", help="1 GPU: run the G > 1 workload (configs[3]) on one GPU")
+    ap.add_argument("--exchange-ranges", type=int, default=0,
+                    help="G > 1: the ranged, overlapped gradient / parameter exchange with this many Gaussian ranges "
+                         "(gslam_amd.plan.MappingStep; 0 = the one-shot exchange, the default until measured on a node)")
+    ap.add_argument("--no-exchange-overlap", action="store_true", help="G > 1 with --exchange-ranges: one stream (A/B of the overlap)")
+    ap.add_argument("--exchange-ab", action="store_true",
+                    help="G > 1: after the main run, the same workload with the other exchange (ranged x4 overlapped, or one-shot "
+                         "when --exchange-ranges is given), reported as `exchange_ab` in the line")
     ap.add_argument("--full-cycle-only", action="store_true", help="1 GPU: only the full-mapping-cycle variant of the headline")
     ap.add_argument("--cfg5-only", action="store_true", help="1 GPU: only BASELINE.json configs[4] (5M SH-3 1080p render)")
     ap.add_argument("--diag", default="", help="DIAGNOSTIC runs of the headline with work left out (comma list of "
@@ -786,7 +793,8 @@ def run_full_cycle(dev, N, W, H, steps=60, warmup=10):
 # ------------------------------------------------------------------------------------------------------------------------
 # keyframe bundle adjustment (configs[3] strong scaling; configs[1] as an extra)
 # ------------------------------------------------------------------------------------------------------------------------
-def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=False, unsharded=False, min_warm_s=0.0):
+def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=False, unsharded=False, min_warm_s=0.0,
+           exchange_ranges=0, exchange_overlap=True):
     import torch.distributed as td
     from gslam_amd.map import GaussianSplattingData
     from gslam_amd.mapping import BundleAdjuster, MapConfig
@@ -796,7 +804,8 @@ def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=F
     window, _cam = make_frames(range(window_size), W, H, dev, gt_scene)
     del gt_scene
     torch.cuda.empty_cache()
-    ba = BundleAdjuster(splats, MapConfig(), capturable=True)
+    ba = BundleAdjuster(splats, MapConfig(), capturable=True, exchange_ranges=exchange_ranges,
+                        exchange_overlap=exchange_overlap)
     if unsharded:
         # the whole window on this rank although a process group exists: the 1-GPU point of the scaling curve, measured on
         # the same node right before the sharded run
@@ -841,7 +850,11 @@ def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=F
     # the collectives alone, same buffers: head all-reduce + reduce-scatter of the gradient bucket, and the all-gather of the
     # updated parameter chunks
     reduce_us = gather_us = None
-    if world > 1:
+    if world > 1 and plan.ranged:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t[0])
+    elif world > 1:
         barrier()
         t0 = time.perf_counter()
         for _ in range(10):
@@ -860,7 +873,9 @@ def run_ba(dev, rank, world, N, W, H, window_size, steps, warmup, stage_timing=F
            "reduce_us": reduce_us, "gather_us": gather_us, "bucket_bytes": int(plan.flat.numel() * 4),
            "head_bytes": int(plan.bucket.head.numel() * 4),
            "n_isects_local": int(plan.r.M_dev.item()) if plan.r is not None else 0, "local_cameras": len(plan.mine)}
-    if stage_timing and rank == 0 and plan.r is not None:
+    res["exchange"] = ("one-shot" if not getattr(plan, "ranged", False) else
+                       f"ranged x{plan.bucket.ranges}" + (", overlapped on a second stream" if plan.overlap else ", one stream"))
+    if stage_timing and rank == 0 and plan.r is not None and not getattr(plan, "ranged", False):
         from gslam_amd.plan import current_stream_ptr
         st = current_stream_ptr(dev)
         with StageTimer() as timer:
@@ -1098,7 +1113,16 @@ def main():
                                "right before the sharded run while the other ranks wait"}
             torch.cuda.empty_cache()
         td.barrier()
-    r = run_ba(dev, rank, world, N, W, H, WINDOW, steps, warmup, stage_timing=not args.no_stage_timing)
+    xr, xo = max(0, args.exchange_ranges), not args.no_exchange_overlap
+    r = run_ba(dev, rank, world, N, W, H, WINDOW, steps, warmup, stage_timing=not args.no_stage_timing,
+               exchange_ranges=xr, exchange_overlap=xo)
+    ab = None
+    if world > 1 and args.exchange_ab:
+        torch.cuda.empty_cache()
+        td.barrier()
+        r2 = run_ba(dev, rank, world, N, W, H, WINDOW, steps, warmup, exchange_ranges=0 if xr else 4, exchange_overlap=True)
+        ab = {"exchange": r2["exchange"], "keyframes_per_s": round(r2["keyframes_per_s"], 3),
+              "ms_per_ba_iteration": round(r2["ms_per_iter"], 4)}
     if rank == 0:
         line = {
             "metric": ba_metric(W, H, N),
@@ -1119,6 +1143,7 @@ def main():
                 "launch": "hip-graph replay (render+loss+backward | Adam on the rank's chunk) around the eager collectives"
                           if world > 1 else "hip-graph replay of the whole step",
             },
+            "exchange": r["exchange"], "exchange_ab": ab,
             "one_gpu_reference": one_gpu,
             "reduce_us": None if r["reduce_us"] is None else round(r["reduce_us"], 1),
             "gather_us": None if r.get("gather_us") is None else round(r["gather_us"], 1),

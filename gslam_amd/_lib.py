@@ -26,6 +26,8 @@ PROTOTYPES = {
     "gsx_project_bwd_workspace_bytes": (i64, [i64, i64]),
     "gsx_project_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, vp, i64, vp, vp, i64, vp,
                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "gsx_project_bwd_range": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, vp, i64, vp, vp, i64, vp,
+                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, vp]),
     "gsx_quat_scale_to_covar_preci": (i32, [vp, vp, i64, vp, vp, vp]),
     "gsx_pack_records": (i32, [vp, vp, vp, vp, i64, i64, i32, vp, vp]),
     "gsx_isect_count": (i32, [vp, vp, i64, i32, i32, vp, vp]),
@@ -76,6 +78,7 @@ PROTOTYPES = {
                                          vp, vp]),
     "gsx_counters_add_gated": (i32, [i32, C.POINTER(vp), i64, vp, vp]),
     "gsx_status_flag": (i32, [vp, i32, i32, vp, vp]),
+    "gsx_range_copy": (i32, [i32, C.POINTER(vp), C.POINTER(i64), i32, vp, i32, vp]),
     "gsx_track_opt_state_bytes": (i64, []),
     "gsx_track_opt_init": (i32, [vp, i32, i32, f32, C.c_double, i32, i32, i32, C.c_double, C.c_double, vp]),
     "gsx_track_opt_advance": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), vp, vp]),

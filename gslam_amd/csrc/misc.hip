@@ -584,6 +584,62 @@ extern "C" int gsx_adam_multi_steps_gated(int n_tensors, float *const *params, c
                        stream, decay_tensor, decay_mask, decay_min_count, decay, skip_if_positive);
 }
 
+// ---- staging copies of the ranged gradient / parameter exchange (gslam_amd.dist.StepBucket) ---------------------
+// The map's arrays are tensor-major in one flat buffer; the exchange of ONE Gaussian range wants, per rank, one contiguous
+// block [ its part of array 0 | its part of array 1 | ... ].  slice t = `parts` consecutive parts of part_len[t] floats at
+// slices[t]; the staging buffer holds `parts` blocks of L = sum part_len floats.  to_flat = 0: slices -> staging (before a
+// reduce-scatter, or with parts = 1 the owner's block before an all-gather); 1: staging -> slices (after the all-gather).
+namespace {
+constexpr int RANGE_COPY_MAX = 8;
+struct RangeCopyArgs {
+    float *slice[RANGE_COPY_MAX];
+    int64_t part_quads[RANGE_COPY_MAX];     // part_len / 4
+    int64_t off_quads[RANGE_COPY_MAX + 1];  // prefix sums of part_quads
+    int n;
+    int64_t total_quads;                    // parts * off_quads[n]
+};
+
+template <bool TO_FLAT>
+__global__ __launch_bounds__(256) void range_copy_kernel(RangeCopyArgs a, float4 *__restrict__ staging) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.total_quads) return;
+    const int64_t lq = a.off_quads[a.n];
+    const int64_t r = i / lq, j = i - r * lq;
+    int t = 0;
+#pragma unroll
+    for (int k = 1; k < RANGE_COPY_MAX; ++k) t += (k < a.n && j >= a.off_quads[k]) ? 1 : 0;
+    float4 *f = reinterpret_cast<float4 *>(a.slice[t]) + r * a.part_quads[t] + (j - a.off_quads[t]);
+    if (TO_FLAT) *f = staging[i];
+    else staging[i] = *f;
+}
+}  // namespace
+
+extern "C" int gsx_range_copy(int n_slices, float *const *slices, const int64_t *part_len, int parts, float *staging,
+                              int to_flat, void *stream) {
+    GSX_CHECK_ARG(n_slices >= 1 && n_slices <= RANGE_COPY_MAX && slices && part_len && parts >= 1 && staging);
+    GSX_CHECK_ARG((((uintptr_t)staging) & 15) == 0);
+    RangeCopyArgs a;
+    a.n = n_slices;
+    a.off_quads[0] = 0;
+    for (int t = 0; t < RANGE_COPY_MAX; ++t) {
+        const bool in = t < n_slices;
+        if (in) GSX_CHECK_ARG(slices[t] && part_len[t] >= 0 && part_len[t] % 4 == 0 && (((uintptr_t)slices[t]) & 15) == 0);
+        a.slice[t] = in ? slices[t] : nullptr;
+        a.part_quads[t] = in ? part_len[t] / 4 : 0;
+        a.off_quads[t + 1] = a.off_quads[t] + a.part_quads[t];
+    }
+    a.total_quads = (int64_t)parts * a.off_quads[n_slices];
+    if (a.total_quads == 0) return GSX_OK;
+    GSX_CHECK_ARG(a.total_quads < ((int64_t)1 << 31) * 256);
+    const unsigned blocks = (unsigned)((a.total_quads + 255) / 256);
+    if (to_flat)
+        hipLaunchKernelGGL(range_copy_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, (float4 *)staging);
+    else
+        hipLaunchKernelGGL(range_copy_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, (float4 *)staging);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
+
 extern "C" int gsx_status_flag(const int32_t *status, int n, int mask, float *flag, void *stream) {
     GSX_CHECK_ARG(status && flag && n >= 1 && n <= 4096);
     hipLaunchKernelGGL(status_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, status, n, mask, flag);

@@ -140,10 +140,11 @@ __global__ __launch_bounds__(PBWD_THREADS) void project_bwd_kernel(
     const float *__restrict__ v_comps, const float *__restrict__ logit_opacities,
     const float *__restrict__ logit_colors, const float *__restrict__ log_unc, const float *__restrict__ v_rec,
     int RS, float *__restrict__ v_means, float *__restrict__ v_quats, float *__restrict__ v_scales,
-    float *__restrict__ view_partials /*[gridDim.x][C][12] or null*/, float *__restrict__ v_logit_opac,
-    float *__restrict__ v_logit_colors, float *__restrict__ v_log_unc) {
+    float *__restrict__ view_partials /*[blocks of the whole map][C][12] or null*/, float *__restrict__ v_logit_opac,
+    float *__restrict__ v_logit_colors, float *__restrict__ v_log_unc, int block0 /*first block of this launch's range*/) {
     __shared__ float s_part[PBWD_THREADS / GSX_WAVE][12];
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int block = block0 + (int)blockIdx.x;
+    const int64_t g = (int64_t)block * blockDim.x + threadIdx.x;
     const bool active = g < N;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(PBWD_THREADS) void project_bwd_kernel(
                 float acc = 0.f;
 #pragma unroll
                 for (int w = 0; w < PBWD_THREADS / GSX_WAVE; ++w) acc += s_part[w][threadIdx.x];
-                view_partials[((int64_t)blockIdx.x * C + c) * 12 + threadIdx.x] = acc;
+                view_partials[((int64_t)block * C + c) * 12 + threadIdx.x] = acc;
             }
             __syncthreads();
         }
@@ -461,16 +462,22 @@ extern "C" int64_t gsx_project_bwd_workspace_bytes(int64_t N, int64_t C) {
     return gsx_align256(blocks * C * 12 * (int64_t)sizeof(float)) + 256;
 }
 
-extern "C" int gsx_project_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
-                               const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
-                               float far_plane, int flags, const int32_t *radii, const float *v_means2d,
-                               int64_t v_means2d_stride, const float *v_depths, const float *v_conics,
-                               int64_t v_conics_stride, const float *v_comps, const float *logit_opacities,
-                               const float *logit_colors, const float *log_uncertainties, const float *v_rec,
-                               float *v_means, float *v_quats, float *v_scales, float *v_viewmats,
-                               float *v_logit_opacities, float *v_logit_colors, float *v_log_unc, void *workspace,
-                               int64_t workspace_bytes, void *stream) {
+// g_begin .. g_end: the rows this launch covers (g_begin on a workgroup boundary); the pose partials keep the row numbering of
+// the whole map, so any set of ranges that tiles [0, N) leaves the workspace as ONE launch over [0, N) would.
+static int project_bwd_impl(const float *means, const float *quats, const float *scales, const float *viewmats,
+                            const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                            float far_plane, int flags, const int32_t *radii, const float *v_means2d,
+                            int64_t v_means2d_stride, const float *v_depths, const float *v_conics,
+                            int64_t v_conics_stride, const float *v_comps, const float *logit_opacities,
+                            const float *logit_colors, const float *log_uncertainties, const float *v_rec,
+                            float *v_means, float *v_quats, float *v_scales, float *v_viewmats,
+                            float *v_logit_opacities, float *v_logit_colors, float *v_log_unc, void *workspace,
+                            int64_t workspace_bytes, int64_t g_begin, int64_t g_end, void *stream) {
     GSX_CHECK_ARG(N >= 0 && C >= 1 && W > 0 && H > 0);
+    GSX_CHECK_ARG(g_begin >= 0 && g_begin <= g_end && g_end <= N && g_begin % PBWD_THREADS == 0);
+    GSX_CHECK_ARG(g_end == N || g_end % PBWD_THREADS == 0);     // a workgroup belongs to one range
+    const bool whole = g_begin == 0 && g_end == N;
+    GSX_CHECK_ARG(whole || (!v_viewmats && (flags & GSX_PROJ_VIEW_PARTIALS)));   // a range leaves partials, never the folded sum
     GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && radii && v_means2d && v_conics);
     const bool pose_only = !v_means && !v_quats && !v_scales;     // Gaussian gradients not wanted (tracking)
     const bool partials_only = (flags & GSX_PROJ_VIEW_PARTIALS) != 0;   // leave the pose partials for a fused consumer
@@ -485,7 +492,10 @@ extern "C" int gsx_project_bwd(const float *means, const float *quats, const flo
         if (v_viewmats && !gsx_zero_async(v_viewmats, 16 * C, st)) return GSX_E_LAUNCH;
         return GSX_OK;
     }
-    const unsigned blocks = (unsigned)((N + PBWD_THREADS - 1) / PBWD_THREADS);
+    const unsigned all_blocks = (unsigned)((N + PBWD_THREADS - 1) / PBWD_THREADS);
+    const int block0 = (int)(g_begin / PBWD_THREADS);
+    const unsigned blocks = (unsigned)((g_end + PBWD_THREADS - 1) / PBWD_THREADS) - (unsigned)block0;
+    if (blocks == 0) return GSX_OK;
     float *partials = nullptr;
     if (v_viewmats || partials_only) {
         if (workspace_bytes < gsx_project_bwd_workspace_bytes(N, C) || !workspace) {
@@ -497,7 +507,8 @@ extern "C" int gsx_project_bwd(const float *means, const float *quats, const flo
 #define GSX_PBWD_ARGS                                                                                                  \
     means, quats, scales, viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, flags, radii, v_means2d,        \
         v_means2d_stride, v_depths, v_conics, v_conics_stride, v_comps, logit_opacities, logit_colors,                 \
-        log_uncertainties, v_rec, 12, v_means, v_quats, v_scales, partials, v_logit_opacities, v_logit_colors, v_log_unc
+        log_uncertainties, v_rec, 12, v_means, v_quats, v_scales, partials, v_logit_opacities, v_logit_colors, v_log_unc, \
+        block0
     if (pose_only)
         hipLaunchKernelGGL(project_bwd_kernel<true>, dim3(blocks), dim3(PBWD_THREADS), 0, st, GSX_PBWD_ARGS);
     else
@@ -505,12 +516,43 @@ extern "C" int gsx_project_bwd(const float *means, const float *quats, const flo
 #undef GSX_PBWD_ARGS
     GSX_CHECK_LAUNCH();
     if (v_viewmats && !partials_only) {
-        hipLaunchKernelGGL(project_bwd_finish_kernel, dim3((unsigned)C), dim3(256), 0, st, partials, (int)blocks,
+        hipLaunchKernelGGL(project_bwd_finish_kernel, dim3((unsigned)C), dim3(256), 0, st, partials, (int)all_blocks,
                            (int)C, v_viewmats);
         GSX_CHECK_LAUNCH();
     }
     return GSX_OK;
 }
+
+#define GSX_PBWD_FORWARD                                                                                                \
+    means, quats, scales, viewmats, Ks, N, C, W, H, eps2d, near_plane, far_plane, flags, radii, v_means2d,               \
+        v_means2d_stride, v_depths, v_conics, v_conics_stride, v_comps, logit_opacities, logit_colors,                   \
+        log_uncertainties, v_rec, v_means, v_quats, v_scales, v_viewmats, v_logit_opacities, v_logit_colors, v_log_unc,  \
+        workspace, workspace_bytes
+
+extern "C" int gsx_project_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                               const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                               float far_plane, int flags, const int32_t *radii, const float *v_means2d,
+                               int64_t v_means2d_stride, const float *v_depths, const float *v_conics,
+                               int64_t v_conics_stride, const float *v_comps, const float *logit_opacities,
+                               const float *logit_colors, const float *log_uncertainties, const float *v_rec,
+                               float *v_means, float *v_quats, float *v_scales, float *v_viewmats,
+                               float *v_logit_opacities, float *v_logit_colors, float *v_log_unc, void *workspace,
+                               int64_t workspace_bytes, void *stream) {
+    return project_bwd_impl(GSX_PBWD_FORWARD, 0, N > 0 ? N : 0, stream);
+}
+
+extern "C" int gsx_project_bwd_range(const float *means, const float *quats, const float *scales, const float *viewmats,
+                                     const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                                     float far_plane, int flags, const int32_t *radii, const float *v_means2d,
+                                     int64_t v_means2d_stride, const float *v_depths, const float *v_conics,
+                                     int64_t v_conics_stride, const float *v_comps, const float *logit_opacities,
+                                     const float *logit_colors, const float *log_uncertainties, const float *v_rec,
+                                     float *v_means, float *v_quats, float *v_scales, float *v_viewmats,
+                                     float *v_logit_opacities, float *v_logit_colors, float *v_log_unc, void *workspace,
+                                     int64_t workspace_bytes, int64_t g_begin, int64_t g_end, void *stream) {
+    return project_bwd_impl(GSX_PBWD_FORWARD, g_begin, g_end, stream);
+}
+#undef GSX_PBWD_FORWARD
 
 extern "C" int gsx_quat_scale_to_covar_preci(const float *quats, const float *scales, int64_t n, float *covars,
                                              float *precis, void *stream) {

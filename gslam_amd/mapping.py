@@ -122,10 +122,14 @@ class BundleAdjuster:
       HIP graph (gslam_amd.plan.MappingStep), sharded over ranks when torch.distributed is initialised."""
 
     def __init__(self, splats: GaussianSplattingData, conf: Optional[MapConfig] = None, fused_loss: bool = True,
-                 capturable: bool = False, need_n_touched: Optional[bool] = None):
+                 capturable: bool = False, need_n_touched: Optional[bool] = None, exchange_ranges: int = 0,
+                 exchange_overlap: bool = True):
         """need_n_touched: keep the rasteriser's touched-pixel counts in ``last_outputs`` (read by visibility pruning
         only, backend.py:370-375); default = the configuration's ``enable_visibility_pruning`` (off, backend.py:94).
-        capturable: device-side Adam step counters (needed by ``plan()``)."""
+        capturable: device-side Adam step counters (needed by ``plan()``).
+        exchange_ranges / exchange_overlap (more than one rank): the ranged, overlapped gradient / parameter exchange of
+        gslam_amd.plan.MappingStep; 0 = the one-shot exchange (default until measured on a multi-GPU node)."""
+        self.exchange_ranges, self.exchange_overlap = int(exchange_ranges), bool(exchange_overlap)
         self.splats = splats
         self.conf = conf or MapConfig()
         self.need_n_touched = bool(getattr(self.conf, "enable_visibility_pruning", False)) \
@@ -162,7 +166,8 @@ class BundleAdjuster:
             if len(self._plans) >= 4:
                 self._plans.clear()
             p = MappingStep(self.splats, self.optimizers, window, self.conf, regularize=regularize, shard=self.shard,
-                            need_n_touched=self.need_n_touched, decay_opacity=decay_opacity)
+                            need_n_touched=self.need_n_touched, decay_opacity=decay_opacity,
+                            exchange_ranges=self.exchange_ranges, exchange_overlap=self.exchange_overlap)
             self._plans[key] = p
         return p
 

@@ -131,10 +131,12 @@ class AdamPack:
     ``gate``: a device float; the launches do nothing while gate[0] > 0 (gsx_adam_multi_steps_gated: no update from an
     iteration whose render overflowed its tile lists)."""
 
-    def __init__(self, optimizers, grad_of: dict, decay=None, gate: torch.Tensor | None = None, pieces=None):
+    def __init__(self, optimizers, grad_of: dict, decay=None, gate: torch.Tensor | None = None, pieces=None,
+                 bump: bool = True):
         """pieces (sharded update, gslam_amd.dist.StepBucket): explicit slices instead of whole parameters - a list of
         dicts {p, g, m, v: 1-D float32 views of equal length, lr, betas, eps, step: device int64 [1], group: the owning
         param group}; ``decay[0]`` then names one of the ``p`` views and the mask has one int32 per element of it."""
+        self._bump = bool(bump)
         self._gate = gate
         self._groups = []
         counters: dict = {}
@@ -181,7 +183,9 @@ class AdamPack:
                     key = (tuple(group["betas"]), float(group["eps"]), p.device)
                     classes.setdefault(key, []).append((p, g, st, float(group["lr"]), step_dev))
         self._keep = (counters, classes)
-        ctrs = list(counters.values())
+        # bump = False: the step counters of these pieces are advanced by ANOTHER pack launched before this one in the same
+        # iteration (one update cut into several launches: gslam_amd.plan.MappingStep's ranged exchange)
+        ctrs = list(counters.values()) if bump else []
         self._counter_calls = []
         for i in range(0, len(ctrs), _MAX_COUNTERS):
             part = ctrs[i:i + _MAX_COUNTERS]

@@ -728,15 +728,26 @@ class RenderPlan:
         six map gradients (overwritten, summed over cameras inside).  keep: leave the gradient records as accumulated
         (``as_output().means2d.grad`` reads them: densification) instead of zeroing each row once it has been consumed.
         rasterised: the gradient records are complete already (forward_track_fused ran the rasteriser's backward)"""
+        if not rasterised:
+            self.backward_raster(st)
+        self.backward_project(st, keep)
+
+    def backward_raster(self, st: int):
+        """the rasteriser's half of ``backward``: d loss / d render -> the gradient records of the visible pairs"""
+        assert self.grads != 'none'
+        check(lib.gsx_raster_bwd(_p(self.rec), self.CH, _p(self.backgrounds), _p(self.offsets), _p(self.flat),
+                                 self.capacity, 1, self.C, self.W, self.H, self.tile_w, self.tile_h, _p(self.alphas),
+                                 _p(self.last_ids), _p(self.v_render), None, _p(self.v_rec), None,
+                                 _p(self.launch_order), 1 if self.geom_only else 0, st), "gsx_raster_bwd")
+
+    def backward_project(self, st: int, keep: bool = False, rows=None):
+        """the projection's half of ``backward``.  rows = (g_begin, g_end), 'full' plans only: those rows of the map alone
+        (gsx_project_bwd_range; g_begin a multiple of 256, g_end a multiple of 256 or N) - calls over ranges that tile the map
+        leave the six gradients and the pose partials as one call does"""
         assert self.grads != 'none'
         reset = 0 if (keep or self.compact) else _RESET_V_REC
         if keep and not self.compact:
             self._v_rec_dirty = True
-        if not rasterised:
-            check(lib.gsx_raster_bwd(_p(self.rec), self.CH, _p(self.backgrounds), _p(self.offsets), _p(self.flat),
-                                     self.capacity, 1, self.C, self.W, self.H, self.tile_w, self.tile_h, _p(self.alphas),
-                                     _p(self.last_ids), _p(self.v_render), None, _p(self.v_rec), None,
-                                     _p(self.launch_order), 1 if self.geom_only else 0, st), "gsx_raster_bwd")
         m = self.map
         vr = self.v_rec.data_ptr()
         if self.grads == 'pose' and self.front:
@@ -752,6 +763,14 @@ class RenderPlan:
         else:
             v = self.v_map
             outs = (_p(v[0]), _p(v[1]), _p(v[2]), None, _p(v[3]), _p(v[4]), _p(v[5]))
+        if rows is not None:
+            assert self.grads == 'full'
+            check(lib.gsx_project_bwd_range(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C,
+                                            self.W, self.H, self.eps2d, self.near, self.far,
+                                            self.flags | _VIEW_PARTIALS | reset, _p(self.radii), vr, 12, None, vr + 8, 12,
+                                            None, _p(m[3]), _p(m[4]), _p(m[5]), vr, *outs, _p(self.pose_ws),
+                                            self.pose_ws.numel(), int(rows[0]), int(rows[1]), st), "gsx_project_bwd_range")
+            return
         check(lib.gsx_project_bwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                   self.H, self.eps2d, self.near, self.far, self.flags | _VIEW_PARTIALS | reset, _p(self.radii),
                                   vr, 12, None, vr + 8, 12, None, _p(m[3]), _p(m[4]), _p(m[5]), vr, *outs,
@@ -1182,7 +1201,13 @@ class MappingStep:
     here (the backend freezes them when it adds a keyframe, gslam_amd/backend.py add_keyframe)."""
 
     def __init__(self, splats, optimizers, window, conf, regularize: bool = True, shard=None,
-                 need_n_touched: bool = False, decay_opacity: bool = True):
+                 need_n_touched: bool = False, decay_opacity: bool = True, exchange_ranges: int = 0,
+                 exchange_overlap: bool = True):
+        """exchange_ranges = K > 0 (more than one rank): the RANGED exchange (gslam_amd.dist.StepBucket) - the projection backward
+        runs range by range and the reduce-scatter of a finished range is issued on a second stream while the next range is
+        computed; the update and the all-gather of the parameters likewise.  exchange_overlap = False keeps the ranged layout
+        and issues everything on one stream (the A/B of the overlap itself).  OFF by default: no multi-GPU node has been
+        available to measure it on; results are identical to the one-shot exchange (tests/test_gpu_multirank.py)."""
         self.splats, self.optimizers, self.conf = splats, optimizers, conf
         self.window = list(window)
         self.regularize = bool(regularize)
@@ -1202,7 +1227,10 @@ class MappingStep:
         self.dev, self.N = dev, N
         # ---- the bucket (gslam_amd.dist.StepBucket: map gradients | counts | pose rows | loss slots) -------------------
         from .dist import StepBucket
-        self.bucket = StepBucket([p.shape for p in params], Cw, dev, group=self.group, world=self.world, rank=self.rank)
+        self.bucket = StepBucket([p.shape for p in params], Cw, dev, group=self.group, world=self.world, rank=self.rank,
+                                 ranges=int(exchange_ranges))
+        self.ranged = self.bucket.ranges > 0
+        self.overlap = bool(exchange_overlap) and self.ranged
         self.flat = self.bucket.flat
         self.grad_views = dict(zip(GRAD_PARAMS, self.bucket.views))
         self.counts, self.g_dt, self.g_dR = self.bucket.counts, self.bucket.g_dt, self.bucket.g_dR
@@ -1272,16 +1300,32 @@ class MappingStep:
             groups = opt.param_groups                      # one group per array, in GRAD_PARAMS order (mapping.SPLAT_LRS)
             if opt._shared_step is None:
                 opt._shared_step = torch.full((1,), groups[0]["_host_step"], dtype=torch.int64, device=dev)
-            fs, pieces, decay = self.flat_state, [], None
-            for k, a, n_el, c_off in self.bucket.pieces():
-                o = self.bucket.offsets[k] + a
-                pc = dict(p=fs["pflat"][o:o + n_el], g=self.bucket.gchunk[c_off:c_off + n_el], m=fs["mflat"][o:o + n_el],
-                          v=fs["vflat"][o:o + n_el], lr=groups[k]["lr"], betas=groups[k]["betas"], eps=groups[k]["eps"],
-                          step=opt._shared_step, group=groups[k])
-                pieces.append(pc)
-                if decay_opacity and GRAD_PARAMS[k] == 'opacities':
-                    decay = (pc["p"], self.vis_i32[a:a + n_el], 1, float(conf.opacity_decay))
-            self.adam = AdamPack([optimizers.pose_opt], pose_grads, decay, gate=self.overflow, pieces=pieces)
+            fs = self.flat_state
+
+            def pieces_of(described):
+                pieces, decay = [], None
+                for k, a, n_el, c_off in described:
+                    o = self.bucket.offsets[k] + a
+                    pc = dict(p=fs["pflat"][o:o + n_el], g=self.bucket.gchunk[c_off:c_off + n_el], m=fs["mflat"][o:o + n_el],
+                              v=fs["vflat"][o:o + n_el], lr=groups[k]["lr"], betas=groups[k]["betas"], eps=groups[k]["eps"],
+                              step=opt._shared_step, group=groups[k])
+                    pieces.append(pc)
+                    if decay_opacity and GRAD_PARAMS[k] == 'opacities':
+                        decay = (pc["p"], self.bucket.vis_all[a:a + n_el], 1, float(conf.opacity_decay))
+                return pieces, decay
+
+            # ranged exchange: one update launch per range (range 0's also steps the window poses and the step counters), so
+            # that the all-gather of a range can follow its update while the next range is still being updated
+            self.adam_rest = []
+            if self.ranged:
+                pieces, decay = pieces_of(self.bucket.pieces_of_range(0))
+                self.adam = AdamPack([optimizers.pose_opt], pose_grads, decay, gate=self.overflow, pieces=pieces)
+                for k in range(1, self.bucket.ranges):
+                    pieces, decay = pieces_of(self.bucket.pieces_of_range(k))
+                    self.adam_rest.append(AdamPack([], {}, decay, gate=self.overflow, pieces=pieces, bump=False))
+            else:
+                pieces, decay = pieces_of(self.bucket.pieces())
+                self.adam = AdamPack([optimizers.pose_opt], pose_grads, decay, gate=self.overflow, pieces=pieces)
             for g_ in groups:                              # host bookkeeping follows all six arrays on every rank
                 if all(g_ is not h for h in self.adam._groups):
                     self.adam._groups.append(g_)
@@ -1289,6 +1333,11 @@ class MappingStep:
         self.stream = torch.cuda.Stream(device=dev)
         self.graph, self.graph2 = HipGraph(), HipGraph()
         self.steps = 0
+        if self.ranged:
+            K = self.bucket.ranges
+            self.comm = torch.cuda.Stream(device=dev) if self.overlap else None
+            self._ev = [torch.cuda.Event() for _ in range(2 * K + 4)]
+            self._rows = [(k * self.bucket.Nr, min(N, (k + 1) * self.bucket.Nr)) for k in range(K)]
 
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -1304,8 +1353,10 @@ class MappingStep:
         return (self.r is None or self.r.matches(splats)) and len(window) == self.Cw and \
             all(a is b for a, b in zip(window, self.window)) and int(splats.means.shape[0]) == self.N
 
-    def enqueue_render_backward(self, st: int, keep: bool = False):
-        """render + loss + backward of this rank's cameras: fills the bucket (map gradients, counts source, pose rows)"""
+    def enqueue_render_backward(self, st: int, keep: bool = False, project: bool = True):
+        """render + loss + backward of this rank's cameras: fills the bucket (map gradients, counts source, pose rows).
+        project = False (ranged exchange): everything but the projection backward and the PoseZhou backward that reads its
+        pose partials - those follow range by range (``_exchange_ranged``)"""
         conf = self.conf
         if self.world > 1:
             # rows of other ranks' cameras and the loss slots hold last iteration's sums: clear them (one small launch)
@@ -1340,11 +1391,11 @@ class MappingStep:
         check(lib.gsx_map_loss(_p(r.render), _p(r.alphas), _p(self.gt), _p(self.exposure), Cl, H, W, r.CH, r.depth_index,
                                r.betas_index, mode, w_photo / denom, w_tv, 0.4, _p(ssim_grad), None, _p(r.v_render),
                                None, _p(self.map_ws), self.map_ws.numel(), st), "gsx_map_loss")
-        r.backward(st, keep)
-        if any(self.learnable[i] for i in self.mine):
-            check(lib.gsx_pose_zhou_bwd_partials(Cl, self._Rt, self._dR, self._dt, self._flags, _p(r.pose_ws),
-                                                 r.pose_blocks, None, self._vdR, self._vdt, st),
-                  "gsx_pose_zhou_bwd_partials")
+        if project:
+            r.backward(st, keep)
+            self.enqueue_pose_partials(st)
+        else:
+            r.backward_raster(st)
         iso_ws, n_iso = None, 0
         if w_iso != 0.0:
             iso_ws, n_iso = self.iso_ws, self.N
@@ -1361,6 +1412,77 @@ class MappingStep:
         # this rank's share of the overflow flag: 1.0 if the render above truncated a tile list (sticky status bit 1), 1024.0 if
         # its tile counts were clamped as corrupt (bit 2): either gates the update on every rank (finish_step tells them apart)
         check(lib.gsx_status_flag(_p(r.status), 1, 3, _p(self.overflow), st), "gsx_status_flag")
+
+    def enqueue_pose_partials(self, st: int):
+        """pose partials of the projection backward -> this rank's rows of the window's pose gradients"""
+        r = self.r
+        if r is not None and any(self.learnable[i] for i in self.mine):
+            check(lib.gsx_pose_zhou_bwd_partials(r.C, self._Rt, self._dR, self._dt, self._flags, _p(r.pose_ws),
+                                                 r.pose_blocks, None, self._vdR, self._vdt, st),
+                  "gsx_pose_zhou_bwd_partials")
+
+    def _isotropic_rows(self, rows, st: int):
+        """the isotropic term of rows [g0, g1) added into the local scale gradients (rank 0 only: it enters the sum once)"""
+        w = self.conf.isotropic_regularization_weight
+        g0, g1 = rows
+        if self.rank != 0 or w == 0.0 or g1 <= g0:
+            return
+        sc, vs, gv = self.splats.scales.detach(), self.vis_i32, self.grad_views['scales']
+        check(lib.gsx_isotropic_loss_acc(sc.data_ptr() + 12 * g0, vs.data_ptr() + 4 * g0, g1 - g0, w, None,
+                                         gv.data_ptr() + 12 * g0, _p(self.iso_ws), self.iso_ws.numel(), st),
+              "gsx_isotropic_loss_acc")
+
+    def _exchange_ranged(self, st: int, keep: bool = False):
+        """projection backward range by range on the caller's stream, the gradient exchange of every finished range behind it
+        on the second one: [counts all-reduce] | range 0 .. K-1: (isotropic term, staging copy, reduce-scatter) | tail
+        all-reduce.  Returns with the caller's stream waiting for all of it."""
+        cur = torch.cuda.current_stream(self.dev)
+        comm = self.comm if self.overlap else cur
+        ev, b = self._ev, self.bucket
+
+        def on_comm(after, fn):
+            if comm is cur:
+                fn()
+                return
+            after.record(cur)
+            with torch.cuda.stream(comm):
+                comm.wait_event(after)
+                fn()
+
+        on_comm(ev[0], lambda: b.reduce_counts(None if self.r is None else self.r.vis_count))
+        for k, rows in enumerate(self._rows):
+            if self.r is not None:
+                self.r.backward_project(st, keep, rows=rows)
+
+            def send(k=k, rows=rows):
+                self._isotropic_rows(rows, current_stream_ptr(self.dev))
+                b.reduce_range(k)
+            on_comm(ev[1 + k], send)
+        self.enqueue_pose_partials(st)
+        on_comm(ev[1 + len(self._rows)], b.reduce_tail)
+        if comm is not cur:
+            ev[2 + len(self._rows)].record(comm)
+            cur.wait_event(ev[2 + len(self._rows)])
+
+    def _update_ranged(self, st: int):
+        """Adam range by range on the caller's stream, the all-gather of every updated range behind it on the second one"""
+        cur = torch.cuda.current_stream(self.dev)
+        comm = self.comm if self.overlap else cur
+        K, b = self.bucket.ranges, self.bucket
+        ev = self._ev[K + 3:]
+        for k, pack in enumerate([self.adam] + self.adam_rest):
+            pack.launch(st)
+            if comm is cur:
+                b.gather_range(self.flat_state["pflat"], k)
+                continue
+            ev[k].record(cur)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev[k])
+                b.gather_range(self.flat_state["pflat"], k)
+        if comm is not cur:
+            ev[K].record(comm)
+            cur.wait_event(ev[K])
+        self.flat_state["sharded"] = True
 
     def reduce(self):
         """the gradient exchange of an iteration (eager, on torch's current stream, between the two graphs): all-reduce of the
@@ -1417,6 +1539,8 @@ class MappingStep:
                 raise RuntimeError("tile-list capacity keeps overflowing during warm-up")
         if self.world == 1:
             self.graph.capture(self.stream, self._enqueue_all)
+        elif self.ranged:
+            self.graph.capture(self.stream, lambda st_: self.enqueue_render_backward(st_, project=False))
         else:
             self.graph.capture(self.stream, self.enqueue_render_backward)
             self.graph2.capture(self.stream, self.enqueue_update)
@@ -1451,6 +1575,17 @@ class MappingStep:
                                                 st), "gsx_pose_zhou_fwd")
                     self.r.probe()
                 self._enqueue_all(st)
+        elif self.ranged:
+            if graphed:
+                self.graph.launch(st)
+            else:
+                if self.r is not None and self.r.capacity == 0:
+                    check(lib.gsx_pose_zhou_fwd(self.r.C, self._Rt, self._dR, self._dt, self._flags, _p(self.r.viewmats),
+                                                st), "gsx_pose_zhou_fwd")
+                    self.r.probe()
+                self.enqueue_render_backward(st, project=False)
+            self._exchange_ranged(st)
+            self._update_ranged(st)
         else:
             if graphed:
                 self.graph.launch(st)
@@ -1480,6 +1615,10 @@ class MappingStep:
                   "gsx_pose_zhou_fwd")
             self.r.probe()
         # the gradient records stay as accumulated (densification reads means2d.grad out of them); the next step() cleans up
+        if self.ranged:
+            self.enqueue_render_backward(st, keep=True, project=False)
+            self._exchange_ranged(st, keep=True)
+            return self.out2[0], self.out2[1]
         self.enqueue_render_backward(st, keep=True)
         self.reduce()
         return self.out2[0], self.out2[1]

@@ -127,6 +127,19 @@ int gsx_project_bwd(const float *means, const float *quats, const float *scales,
                     const float *log_uncertainties, const float *v_rec, float *v_means, float *v_quats,
                     float *v_scales, float *v_viewmats, float *v_logit_opacities, float *v_logit_colors,
                     float *v_log_unc, void *workspace, int64_t workspace_bytes, void *stream);
+/* The same over the rows g_begin .. g_end of the map only (g_begin a multiple of 256, g_end a multiple of 256 or N; needs
+ * GSX_PROJ_VIEW_PARTIALS and v_viewmats = NULL): launches over ranges that tile [0, N) leave the gradients and the pose partials
+ * exactly as ONE gsx_project_bwd does.  New design (the reference is single-GPU): the multi-GPU BA step hands each
+ * finished range to the gradient exchange while the next one is still being computed (gslam_amd.dist.StepBucket). */
+int gsx_project_bwd_range(const float *means, const float *quats, const float *scales, const float *viewmats,
+                          const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                          float far_plane, int flags, const int32_t *radii, const float *v_means2d,
+                          int64_t v_means2d_stride, const float *v_depths, const float *v_conics, int64_t v_conics_stride,
+                          const float *v_comps, const float *logit_opacities, const float *logit_colors,
+                          const float *log_uncertainties, const float *v_rec, float *v_means, float *v_quats,
+                          float *v_scales, float *v_viewmats, float *v_logit_opacities, float *v_logit_colors,
+                          float *v_log_unc, void *workspace, int64_t workspace_bytes, int64_t g_begin, int64_t g_end,
+                          void *stream);
 
 /* ---- K10: gsplat.quat_scale_to_covar_preci (gslam/insertion.py:88-91) ------------------------------------------ */
 int gsx_quat_scale_to_covar_preci(const float *quats, const float *scales, int64_t n, float *covars /*[n,3,3]*/,
@@ -475,6 +488,12 @@ int gsx_adam_multi_steps_gated(int n_tensors, float *const *params, const float 
                                const float *skip_if_positive, void *stream);
 int gsx_counters_add_gated(int n, int64_t *const *counters, int64_t delta, const float *skip_if_positive, void *stream);
 int gsx_status_flag(const int32_t *status, int n, int mask, float *flag, void *stream);
+/* Staging copy of the ranged multi-GPU exchange (new design; gslam_amd.dist.StepBucket): slice t = `parts`
+ * consecutive parts of part_len[t] floats (a multiple of 4, 16-byte aligned) starting at slices[t]; staging = `parts` blocks of
+ * sum(part_len) floats, block r = [part r of slice 0 | part r of slice 1 | ...].  to_flat = 0: slices -> staging; 1: back.
+ * n_slices <= 8; host arrays of pointers / lengths. */
+int gsx_range_copy(int n_slices, float *const *slices, const int64_t *part_len, int parts, float *staging, int to_flat,
+                   void *stream);
 
 /* ---- device-resident tracking optimiser: the host logic of gslam/frontend.py:604-662 (10 torch.optim.Adam steps, then
  * ONE torch.optim.LBFGS(line_search_fn='strong_wolfe').step()) as a state machine advanced once per closure

@@ -145,6 +145,125 @@ def test_two_rank_ba_step_equals_one_rank(n_kf):
         assert same_poses and same_map                        # replicas stay bit-identical: no pose broadcast needed
 
 
+def _ranged_worker(rank, world, port, n_kf, overlap, q):
+    """the RANGED, overlapped exchange (MappingStep(exchange_ranges = K)) against the one-shot exchange, both on two
+    ranks that render different cameras (so their visible sets differ): (1) the exchange machinery alone on identical local
+    gradients - window-wide sums equal BIT FOR BIT; (2) whole iterations - parameters, poses, moments within the float-atomic
+    noise of two runs of the same backward, replicas bit-identical"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from gslam_amd import dist as gdist
+    from gslam_amd.mapping import BundleAdjuster
+    assert gdist.init_from_env(backend="gloo") == (rank, world)
+    names = ("means", "quats", "scales", "opacities", "colors", "log_uncertainties")
+    sA, wA = _build(dev, n_kf)
+    baA = BundleAdjuster(sA, capturable=True)
+    A = baA.plan(wA)
+    sB, wB = _build(dev, n_kf)
+    baB = BundleAdjuster(sB, capturable=True, exchange_ranges=3, exchange_overlap=overlap)
+    B = baB.plan(wB)
+    bA, bB = A.bucket, B.bucket
+    N = sA.means.shape[0]
+    ok = B.ranged and B.overlap == overlap and bB.ranges == 3 and bB.Nr == 2816 and not A.ranged
+    ok = ok and (B.comm is not None) == overlap and len(B.adam_rest) == 2
+    ok = ok and sB.means.data_ptr() == B.flat_state["pflat"].data_ptr()
+    ok = ok and sB.quats.data_ptr() == B.flat_state["pflat"].data_ptr() + 4 * bB.offsets[1] and bB.offsets[1] == 3 * 3 * 2816
+
+    def whole_sum(plan):
+        """the window-wide gradient sums, every rank's pieces put together: six [N * d] arrays"""
+        b = plan.bucket
+        w = torch.zeros(b.S_pad, device=dev)
+        for t, a, ln, c_off in b.pieces():
+            o = b.offsets[t] + a
+            w[o:o + ln] = b.gchunk[c_off:c_off + ln]
+        b.gather(w, torch.zeros(b.L, device=dev))
+        torch.cuda.synchronize()
+        return [w[o:o + k].clone() for o, k in zip(b.offsets, b.numels)], w
+
+    # ---- (1) the exchange alone, on the SAME local gradients ---------------------------------------------------------------
+    A.render_backward()
+    torch.cuda.synchronize()
+    sumA, _ = whole_sum(A)
+    vis_A = A.vis_i32.clone()
+    for vB, vA in zip(bB.views, bA.views):                  # A's local gradients (rank 0's already carry the isotropic term)
+        vB.copy_(vA)
+    rB, wiso = B.r, B.conf.isotropic_regularization_weight
+    B.r, B.conf.isotropic_regularization_weight = None, 0.0   # no projection launches, no second isotropic term
+    B._exchange_ranged(torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    B.r, B.conf.isotropic_regularization_weight = rB, wiso
+    sumB, wB_flat = whole_sum(B)
+    exact = all(torch.equal(x, y) for x, y in zip(sumA, sumB))
+    pad_zero = all(float(wB_flat[o + k:o + bB.ranges * bB.Nr * d].abs().sum()) == 0.0
+                   for o, k, d in zip(bB.offsets, bB.numels, bB.dims))
+    # ---- (2) whole iterations ----------------------------------------------------------------------------------------------
+    B.render_backward()
+    torch.cuda.synchronize()
+    ok = ok and B.capacity_ok() and A.capacity_ok()
+    sumB2, _ = whole_sum(B)
+    scale = max(float(x.abs().max()) for x in sumA)
+    d_grad = max(float((x - y).abs().max()) for x, y in zip(sumA, sumB2)) / scale
+    d_cnt = int((B.vis_i32 - vis_A).abs().max())
+    differ = int((A.r.vis_count != vis_A).sum()) if A.r is not None else -1      # this rank sees less than the window does
+    hA, hB = bA.head.clone(), bB.head.clone()
+    d_tail = float((hA[N:] - hB[N:]).abs().max()) / (float(hA[N:].abs().max()) + 1e-9)
+    for _ in range(3):
+        A.step()
+        B.step()
+    torch.cuda.synchronize()
+    ok = ok and A.capacity_ok() and B.capacity_ok() and B.graph.captured and not B.graph2.captured and B.flat_state["sharded"]
+    d_par = {k: float((getattr(sA, k) - getattr(sB, k)).abs().mean()) for k in names}
+    d_posepar = max(float((a.pose.dR - b_.pose.dR).abs().max()) for a, b_ in zip(wA, wB))
+    steps = (int(baA.optimizers.splat_opt._shared_step.item()), int(baB.optimizers.splat_opt._shared_step.item()))
+
+    def same(t):
+        t = t.detach().contiguous().cpu()
+        both = [torch.zeros_like(t) for _ in range(world)]
+        td.all_gather(both, t)
+        return all(torch.equal(both[0], b) for b in both[1:])
+
+    replicas = same(B.flat_state["pflat"]) and same(torch.cat([torch.cat([f.pose.dR, f.pose.dt]) for f in wB]))
+    baA.sync_moments()
+    baB.sync_moments()
+    torch.cuda.synchronize()
+    d_mom = 0.0
+    for k in names:
+        for mom in ("exp_avg", "exp_avg_sq"):
+            m1 = baA.optimizers.splat_opt.state[getattr(sA, k)][mom]
+            m2 = baB.optimizers.splat_opt.state[getattr(sB, k)][mom]
+            d_mom = max(d_mom, float((m1 - m2).abs().max()) / (float(m1.abs().max()) + 1e-12))
+    ok = ok and not B.flat_state["sharded"] and same(B.flat_state["mflat"]) and same(B.flat_state["vflat"])
+    q.put((rank, ok, exact, pad_zero, d_grad, d_cnt, differ, d_tail, d_par, d_posepar, steps, replicas, d_mom))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_kf,overlap", [(3, True), (3, False), (1, True)])
+def test_ranged_overlapped_exchange_equals_the_one_shot_exchange(n_kf, overlap):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ranged_worker, args=(r, 2, port, n_kf, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, exact, pad_zero, d_grad, d_cnt, differ, d_tail, d_par, d_posepar, steps, replicas, d_mom in res:
+        assert ok, rank
+        assert exact and pad_zero, (rank, exact, pad_zero)      # same local gradients in -> the same sums out, bit for bit
+        assert d_grad < 2e-4 and d_cnt == 0 and d_tail < 2e-3, (rank, d_grad, d_cnt, d_tail)
+        if n_kf == 3:
+            assert differ > 0, rank                              # the rank's own visible set is NOT the window's
+        for k, v in d_par.items():
+            assert v < 2e-5, (rank, k, v)
+        assert d_posepar < 2e-3 and steps == (3, 3) and replicas and d_mom < 2e-2, (rank, d_posepar, steps, replicas, d_mom)
+
+
 def _overflow_worker(rank, world, port, q):
     """rank 1's tile lists are sized with no head-room; the map then grows fatter on both replicas: rank 1's render overflows
     inside the replayed graph, rank 0's does not.  The flag travels in the iteration's all-reduce, the update launches are

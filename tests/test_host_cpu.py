@@ -239,6 +239,118 @@ def test_keyframe_sharded_ba_collectives_gloo_world2():
         assert ok and vis == 5 and mx == 1 and t == 1.0 and numel == 760          # six arrays of 50 rows, each padded to 16 bytes, in 2 chunks of 380 floats
 
 
+def _worker_ranged(rank, world, port, q):
+    """the RANGED exchange (StepBucket(ranges = K)) piece by piece, as MappingStep drives it: counts, ranges in order, tail;
+    then the all-gather range by range; then the same bucket through the one-shot API (reduce / gather)"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as td
+    from gslam_amd import dist as gdist
+    gdist.init_from_env(backend="gloo")
+    n, cw, K = 1300, 3, 3
+    shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 3), (n,)]
+    b = gdist.StepBucket(shapes, cw, "cpu", ranges=K)
+    offs, numels, s_pad, L, nr, k_eff, dims = gdist.ranged_layout(shapes, world, K)
+    ok = (b.ranges, b.Nr, b.S_pad, b.L) == (k_eff, nr, s_pad, L) == (3, 512, 1536 * 15, 1536 * 15 // 2)
+    ok = ok and b.gchunk.numel() == L and b.vis_all.numel() == 1536 and b.vis_i32.numel() == n
+    g = torch.Generator().manual_seed(7)
+    local = [torch.randn(s, generator=g) for s in shapes]       # both ranks draw the same numbers ...
+    for v, t in zip(b.views, local):
+        v.copy_(t * (rank + 1))                                  # ... and scale them by their rank: the sum is 3 x
+    b.g_dt[rank] = float(rank + 1)
+    b.out2[0] = 1.0
+    b.overflow[0] = float(rank)
+    b.reduce_counts(torch.full((n,), rank + 1, dtype=torch.int32))
+    ok = ok and torch.equal(b.vis_i32, torch.full((n,), 3, dtype=torch.int32)) and int(b.vis_all[n:].abs().sum()) == 0
+    ok = ok and float(b.g_dt[1 - rank, 0]) == 0.0               # the counts' all-reduce leaves the tail alone
+    for k in range(b.ranges):
+        b.reduce_range(k)
+    b.reduce_tail()
+    ok = ok and float(b.g_dt[0, 0]) == 1.0 and float(b.g_dt[1, 0]) == 2.0 and float(b.out2[0]) == 2.0
+    ok = ok and float(b.overflow[0]) == 1.0
+    padded = []
+    for t, d in zip(local, dims):
+        full = torch.zeros(1536 * d)
+        full[:n * d] = t.reshape(-1)
+        padded.append(full)
+    for k_t, a, ln, c_off in b.pieces():
+        ok = ok and torch.equal(b.gchunk[c_off:c_off + ln], padded[k_t][a:a + ln] * 1.0 + padded[k_t][a:a + ln] * 2.0)
+    # all-gather range by range: every rank "updates" its pieces of a flat buffer
+    whole = torch.full((s_pad,), -1.0)
+    for k_t, a, ln, c_off in b.pieces():
+        o = b.offsets[k_t] + a
+        whole[o:o + ln] = torch.arange(o, o + ln, dtype=torch.float32)
+    for k in range(b.ranges):
+        b.gather_range(whole, k)
+    ok = ok and torch.equal(whole, torch.arange(s_pad, dtype=torch.float32))
+    # the one-shot API on the ranged layout: same sums
+    first = b.gchunk.clone()
+    b.gchunk.zero_()
+    b.tail.zero_()
+    b.g_dt[rank] = float(rank + 1)
+    seen = []
+    b.reduce(torch.full((n,), rank + 1, dtype=torch.int32), between=lambda: seen.append(int(b.vis_i32[5])))
+    ok = ok and seen == [3] and torch.equal(b.gchunk, first)
+    whole2 = torch.full((s_pad,), -1.0)
+    for k_t, a, ln, c_off in b.pieces():
+        o = b.offsets[k_t] + a
+        whole2[o:o + ln] = torch.arange(o, o + ln, dtype=torch.float32)
+    b.gather(whole2, torch.zeros(1))
+    ok = ok and torch.equal(whole2, whole)
+    try:
+        b.chunk_range()
+        ok = False
+    except RuntimeError:
+        pass
+    q.put((rank, ok))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_ranged_exchange_collectives_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ranged, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_ranged_layout_partitions_the_padded_map_for_every_world_size():
+    """gslam_amd.dist.ranged_layout / StepBucket(ranges = K).pieces: ranges of whole projection workgroups, every rank's part of
+    every array of every range 16-byte aligned, every element of the PADDED arrays in exactly one rank's pieces, the pieces of a
+    range contiguous in the rank's gradient chunk - no process group needed"""
+    import torch
+    from gslam_amd import dist as gdist
+    for n in (1, 300, 1300, 5000, 100001):
+        shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 3), (n,)]
+        for world in (2, 3, 4, 6, 8):
+            for K in (1, 2, 4, 7):
+                offs, numels, s_pad, L, nr, k_eff, dims = gdist.ranged_layout(shapes, world, K)
+                assert dims == [3, 4, 3, 1, 3, 1] and nr % 256 == 0 and nr % (4 * world) == 0
+                assert 1 <= k_eff <= K and (k_eff - 1) * nr < n <= k_eff * nr and s_pad == 15 * k_eff * nr == world * L
+                cover = [torch.zeros(k_eff * nr * d, dtype=torch.int32) for d in dims]
+                for r in range(world):
+                    b = gdist.StepBucket(shapes, 8, "cpu", world=world, rank=r, ranges=K)
+                    assert b.ranges == k_eff and b.flat.numel() == s_pad and b.gchunk.numel() == L
+                    assert [tuple(v.shape) for v in b.views] == shapes
+                    last_end = 0
+                    for t, a, ln, c_off in b.pieces():
+                        cover[t][a:a + ln] += 1
+                        assert ln > 0 and a % 4 == 0 and c_off == last_end and c_off + ln <= L
+                        last_end = c_off + ln
+                    assert last_end == L
+                    for k in range(k_eff):
+                        assert b.pieces_of_range(k) == b.pieces()[6 * k:6 * k + 6]
+                assert all(bool((c == 1).all()) for c in cover), (n, world, K)
+
+
 def test_step_bucket_layout_partitions_the_map_for_every_world_size():
     """the sharded update's layout (gslam_amd.dist.bucket_layout / StepBucket.pieces) for the rank counts the scaling runs use
     and a few awkward ones: equal 16-byte-aligned chunks, every element of every per-Gaussian array in exactly one rank's
