@@ -996,3 +996,64 @@ def test_window_closure_on_the_tracking_machinery_equals_the_generic_path(dev, n
     ra, rb = ref.read_report().cpu(), new.read_report().cpu()
     assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
     assert float((ref.r.viewmats - new.r.viewmats).abs().max()) < 5e-3
+
+
+def test_projection_backward_range_by_range_equals_one_launch(dev):
+    """gsx_project_bwd_range over ranges that tile the map (what the ranged multi-GPU exchange issues) leaves the
+    six map gradients and the pose partials exactly as ONE gsx_project_bwd over the same gradient records - bit for bit (one
+    thread per Gaussian, no atomics); a range that is not made of whole workgroups is refused"""
+    from gslam_amd._lib import GsxError
+    from gslam_amd.mapping import BundleAdjuster
+    from gslam_amd.plan import current_stream_ptr
+    m, cam, frame = _world(dev, n=7000)
+    window = [frame(i, i) for i in range(3)]
+    plan = BundleAdjuster(m, capturable=True).plan(window)
+    plan.render_backward()                                    # keep = True: the gradient records stay as accumulated
+    torch.cuda.synchronize()
+    assert plan.capacity_ok()
+    r, st = plan.r, current_stream_ptr(dev)
+    r.backward_project(st, keep=True)                         # ONE launch over the records (no isotropic term on top)
+    torch.cuda.synchronize()
+    want = {k: v.clone() for k, v in plan.grad_views.items()}
+    want_pose = r.pose_ws.clone()
+    assert all(float(v.abs().max()) > 0 for v in want.values())
+    for rows_list in ([(0, 2816), (2816, 5632), (5632, 7000)], [(0, 256), (256, 6912), (6912, 7000)], [(0, 7000)]):
+        for v in plan.grad_views.values():
+            v.fill_(7.0)
+        r.pose_ws.fill_(3)
+        for rows in rows_list:
+            r.backward_project(st, keep=True, rows=rows)
+        torch.cuda.synchronize()
+        for k, v in plan.grad_views.items():
+            assert torch.equal(v, want[k]), (k, rows_list)
+        nb = r.pose_blocks * r.C * 12 * 4
+        assert torch.equal(r.pose_ws[:nb], want_pose[:nb]), rows_list
+    with pytest.raises(GsxError):
+        r.backward_project(st, keep=True, rows=(100, 7000))
+    with pytest.raises(GsxError):
+        r.backward_project(st, keep=True, rows=(0, 1000))
+
+
+def test_range_copy_gathers_and_scatters_the_parts_of_a_range(dev):
+    """gsx_range_copy (staging copies of the ranged exchange) against the same copy written with views"""
+    from gslam_amd import dist as gdist
+    n, world, K = 5000, 4, 3
+    shapes = [(n, 3), (n, 4), (n, 3), (n,), (n, 3), (n,)]
+    for rank in (0, 3):
+        b = gdist.StepBucket(shapes, 2, dev, world=world, rank=rank, ranges=K)
+        h = gdist.StepBucket(shapes, 2, "cpu", world=world, rank=rank, ranges=K)
+        whole = torch.randn(b.S_pad, generator=torch.Generator().manual_seed(rank))
+        for k in range(b.ranges):
+            for own in (False, True):
+                sd = torch.full(((1 if own else world) * b.Lk,), -1.0, device=dev)
+                sh = torch.full(((1 if own else world) * b.Lk,), -1.0)
+                b._range_copy(whole.to(dev), k, sd, own_only=own, to_flat=False)
+                h._range_copy(whole, k, sh, own_only=own, to_flat=False)
+                assert torch.equal(sd.cpu(), sh) and bool((sh != -1.0).all())
+                back_d, back_h = torch.zeros(b.S_pad, device=dev), torch.zeros(b.S_pad)
+                b._range_copy(back_d, k, sd, own_only=own, to_flat=True)
+                h._range_copy(back_h, k, sh, own_only=own, to_flat=True)
+                assert torch.equal(back_d.cpu(), back_h)
+                # what came back is the range's rows (all parts, or this rank's) and nothing else
+                mask = back_h != 0
+                assert torch.equal(back_h[mask], whole[mask]) and int(mask.sum()) >= (1 if own else world) * b.Lk - 8
