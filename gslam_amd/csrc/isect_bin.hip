@@ -61,6 +61,36 @@ __device__ __forceinline__ Rect tile_rect(float mx, float my, int32_t radius, in
     return r;
 }
 
+// ---- tight rectangle (GSX_PROJ_TILE_EXACT; the fused front of pose-only closures) --------------------------------------------------
+// The reference lists an instance in every tile of the square around its 3-sigma radius (gsplat isect_tiles through
+// gslam/rasterization.py:259-272) and its rasteriser then skips the instance at every pixel whose alpha = opacity exp(-sigma) stays
+// below 1/255.  sigma(d) = 0.5 (a dx^2 + c dy^2) + b dx dy <= L = ln(255 opacity) is an ellipse whose axis-aligned bounding box has
+// the half extents sqrt(2 L c / det), sqrt(2 L a / det): a tile none of whose pixel CENTRES lies in that box changes nothing in any
+// output of the render or its backward.  The square shrinks to its intersection with the box (never grows): on the headline's map
+// 28 % of the (instance, tile) pairs go - the minor-axis side of anisotropic splats, the rim of translucent ones, and whole
+// instances whose opacity is below 1/255.  Margins (1 % + 0.02 on L, 0.1 % + 0.01 px on the extents) cover the rounding of the
+// rasteriser's own evaluation.  (A per-tile test on top - is the quadratic's minimum over the tile below L? - drops 34 %, but costs
+// the projection more than the rasteriser gains: tools/experiments/r05_exact_tile_masks.patch)
+__device__ __forceinline__ Rect tighten_rect(Rect r, float mx, float my, float a, float b, float c, float opac) {
+    const float l = __logf(255.0f * opac);
+    const float two_l = 2.0f * (l + 0.01f * fabsf(l) + 0.02f);
+    const float det = a * c - b * b;
+    if (!(det > 0.0f) || !(two_l == two_l)) return r;          // degenerate conic / NaN opacity: the reference's square
+    if (two_l <= 0.0f) { r.x1 = r.x0; r.y1 = r.y0; return r; } // never reaches 1/255 anywhere
+    const float k = two_l / det;
+    const float ex = sqrtf(k * c) * 1.001f + 0.01f, ey = sqrtf(k * a) * 1.001f + 0.01f;
+    if (!(ex == ex) || !(ey == ey)) return r;
+    const float ts = (float)GSX_TILE, inv = 1.0f / (float)GSX_TILE;
+    // tile t holds the centres t * ts + 0.5 .. t * ts + ts - 0.5
+    const float fx0 = ceilf((mx - ex - (ts - 0.5f)) * inv), fx1 = floorf((mx + ex - 0.5f) * inv) + 1.0f;
+    const float fy0 = ceilf((my - ey - (ts - 0.5f)) * inv), fy1 = floorf((my + ey - 0.5f) * inv) + 1.0f;
+    r.x0 = max(r.x0, (int)fmaxf(fx0, -1.0e6f)); r.x1 = min(r.x1, (int)fminf(fx1, 1.0e6f));
+    r.y0 = max(r.y0, (int)fmaxf(fy0, -1.0e6f)); r.y1 = min(r.y1, (int)fminf(fy1, 1.0e6f));
+    if (r.x1 < r.x0) r.x1 = r.x0;
+    if (r.y1 < r.y0) r.y1 = r.y0;
+    return r;
+}
+
 __device__ __forceinline__ Rect load_rect(const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                                           int64_t idx, int tile_w, int tile_h, bool in_range) {
     Rect r = {0, 0, 0, 0};
@@ -1713,6 +1743,8 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
             const bool vis = radius_i > 0;
             Rect r = {0, 0, 0, 0};
             if (vis) r = tile_rect(mx, my, radius_i, a.tile_w, a.tile_h);
+            const int ref_area = (r.x1 > r.x0 && r.y1 > r.y0) ? (r.y1 - r.y0) * (r.x1 - r.x0) : 0;   // what the reference lists
+            if (vis && (a.flags & GSX_PROJ_TILE_EXACT)) r = tighten_rect(r, mx, my, con0, con1, con2, opac);
             const bool has = (r.x1 > r.x0) && (r.y1 > r.y0);
             // slot of this instance in the workgroup's segment of camera c: monotone in the flatten id (ordered compaction)
             const int run = s_ninst[c];
@@ -1723,7 +1755,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
             const int64_t slot = ((int64_t)c * a.R + blockIdx.x) * seg_cap + pos;
             if (active) {
                 if (a.radii) a.radii[idx] = radius_i;
-                if (a.tiles) a.tiles[idx] = has ? (r.y1 - r.y0) * (r.x1 - r.x0) : 0;
+                if (a.tiles) a.tiles[idx] = ref_area;
                 n_vis += vis ? 1 : 0;
                 const bool write_row = a.compact ? has : (vis || !skip_culled);
                 if (write_row) {

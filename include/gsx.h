@@ -75,6 +75,11 @@ extern "C" {
                                      keys (gsx_raster_track_fused_rows: tile t reserves its segment on counter t % 64, each counter
                                      over its own 64th of the key buffer); status bit 1 also reports a row that outgrew its segment
                                      (M_cap / rows keys) or a counter that outgrew its 64th. */
+#define GSX_PROJ_TILE_EXACT 2048   /* gsx_front_fwd (pose-only closures): an instance is listed only in the tiles of its 3-sigma square
+                                    * that hold a pixel centre inside the axis-aligned box of the ellipse alpha >= 1/255 (from the conic
+                                    * and the opacity, with margins).  The reference lists the whole square (gslam/rasterization.py:259-272)
+                                    * and its rasteriser skips the rest pixel by pixel: render, loss and gradients are unchanged, the tile
+                                    * lists a quarter shorter; tiles_per_gauss (if asked for) stays the reference's count. */
 #define GSX_PROJ_MAP_RECORDS 512   /* with GSX_PROJ_CANDIDATES, to gsx_front_candidates / gsx_front_fwd / gsx_front_pose_bwd: the
                                      candidate area holds the pose-independent record of EVERY Gaussian (slot = Gaussian
                                      index; margins ignored) and a packed cull row (mean, largest scale squared) each.  Valid

@@ -858,7 +858,7 @@ def test_tiles_collect_their_keys_from_the_projection_rows(dev, n_gauss, scale_u
     st = current_stream_ptr(dev)
     ref = TrackClosure(splats, cam, defer_sort=True, row_keys=False)
     new = TrackClosure(splats, cam, defer_sort=True)
-    assert new.r.row_keys and not ref.r.row_keys
+    assert new.r.row_keys and not ref.r.row_keys and new.r.tile_exact and ref.r.tile_exact
     for c in (ref, new):
         c.load(V0.to(dev), img, torch.tensor([0.02, -0.01], device=dev))
         c.r.probe()
@@ -931,6 +931,96 @@ def test_tiles_collect_their_keys_from_the_projection_rows(dev, n_gauss, scale_u
     # (the optimiser's discrete decisions - when the line search stops - may flip on those bits: compared are where the two ended up)
     assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
     assert float((ref.r.viewmats - new.r.viewmats).abs().max()) < 5e-3
+
+
+@pytest.mark.parametrize("n_gauss,scale_up,low_opacity", [(120000, 0.5, False), (300000, 0.9, False), (100000, 1.2, True)])
+def test_exact_tile_test_drops_only_pairs_no_pixel_can_see(dev, n_gauss, scale_up, low_opacity):
+    """GSX_PROJ_TILE_EXACT (round 5): the fused front of a pose-only closure lists an instance only in the tiles of its 3-sigma square
+    that hold a pixel centre inside the bounding box of its alpha >= 1/255 ellipse.  Against the same closure with every tile of the
+    square listed: the loss rows bit for bit (the forward composites the same entries in the same order), pose partials to
+    float-atomic noise, fewer keys; every tile's keys a sub-multiset of the full list's; and every pair that was dropped checked pixel
+    by pixel in float64 from its record - no pixel centre of the tile reaches 1/255 (with a scene of low opacities, where whole
+    instances vanish, too)."""
+    from gslam_amd.map import GaussianSplattingData
+    from gslam_amd.plan import TrackClosure, current_stream_ptr
+    from gslam_amd.primitives import Camera
+    from gslam_amd.synthetic import make_intrinsics, make_scene, make_viewmat
+    from gslam_amd._lib import lib as _l
+    W, H = 640, 480
+    sc = make_scene(n_gauss, 9)
+    sc["scales"] = sc["scales"] + scale_up
+    if low_opacity:
+        sc["opacities"] = sc["opacities"] - 4.0                # logits: most opacities between 0.002 and 0.1
+    splats = GaussianSplattingData.from_dict(sc, dev)
+    cam = Camera(make_intrinsics(W, H).to(dev), H, W)
+    img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(8)).to(dev)
+    st = current_stream_ptr(dev)
+    full = TrackClosure(splats, cam, defer_sort=True, tile_exact=False)
+    new = TrackClosure(splats, cam, defer_sort=True)
+    assert new.r.tile_exact and not full.r.tile_exact and full.r.row_keys
+    V0 = make_viewmat(2.0)
+    for c in (full, new):
+        c.load(V0.to(dev), img, torch.tensor([0.02, -0.01], device=dev))
+        c.r.probe()
+    lay = (C.c_int64 * 3)()
+    _l.gsx_front_keys(new.r.N, new.r.C, new.r.tile_w, new.r.tile_h, new.r.capacity, 32, lay)
+    for what in ("first closure", "second closure", "cut-offs too tight"):
+        if what == "cut-offs too tight":
+            for c in (full, new):
+                c.r.tile_cut.fill_(0x3a83126f)                 # depth 0.001: every tile scans its keys twice and keeps its own copy
+        a, b = _row_keys_outputs(full, st, H, W), _row_keys_outputs(new, st, H, W)
+        assert torch.equal(a[0], b[0]), what                   # loss rows
+        # (instances no tile lists any more have no slot: the workgroups of the pose backward cut the rest differently - the sums agree)
+        pa, pb = a[5].view(-1, 12).double().sum(0), b[5].view(-1, 12).double().sum(0)
+        assert float((pa - pb).abs().max()) < 2e-4 * float(pa.abs().max()) + 1e-12, (what, pa, pb)
+        sa, sb = full.r.tile_span.cpu().numpy(), new.r.tile_span.cpu().numpy()
+        assert (sb[:, 1] <= sa[:, 1]).all() and new.r.keys_total() == int(sb[:, 1].sum()), what
+        assert new.r.keys_total() < 0.9 * full.r.keys_total(), (what, new.r.keys_total(), full.r.keys_total())
+    near = b[4].cpu().numpy()
+    ka = full.r.isect_ws[int(lay[0]):int(lay[0]) + 8 * full.r.capacity].view(torch.int64).cpu().numpy()
+    kb = new.r.isect_ws[int(lay[0]):int(lay[0]) + 8 * new.r.capacity].view(torch.int64).cpu().numpy()
+    rec = full.r.rec.view(-1, 12).cpu().numpy().astype(np.float64)
+    px = np.arange(16) + 0.5
+    checked = dropped = 0
+    worst = 0.0
+    for t in range(0, new.r.T, 7):
+        if near[t] == 0:
+            continue
+        la = ka[sa[t, 0]:sa[t, 0] + sa[t, 1]]
+        lb = kb[sb[t, 0]:sb[t, 0] + sb[t, 1]]
+        da, db = np.sort(la >> 32), np.sort(lb >> 32)
+        # sub-multiset by depth bits
+        rest = list(da)
+        import collections
+        cnt_a, cnt_b = collections.Counter(da.tolist()), collections.Counter(db.tolist())
+        assert all(cnt_a[k] >= v for k, v in cnt_b.items()), t
+        tx, ty = t % new.r.tile_w, t // new.r.tile_w
+        gone = cnt_a - cnt_b
+        for key in la.tolist():
+            d = key >> 32
+            if gone.get(d, 0) > 0 and cnt_a[d] == gone[d]:      # (an unambiguous depth: this very key was dropped)
+                slot = key & 0xffffffff
+                mx, my, c0, c1, c2, op = rec[slot, :6]
+                dx, dy = tx * 16 + px - mx, ty * 16 + px - my
+                sig = 0.5 * (c0 * dx[None, :] ** 2 + c2 * dy[:, None] ** 2) + c1 * dx[None, :] * dy[:, None]
+                alpha = op * np.exp(-sig)
+                worst = max(worst, float(alpha.max()))
+                assert float(alpha.max()) < 1.0 / 255.0, (t, slot, float(alpha.max()))
+                dropped += 1
+        checked += 1
+    assert checked > 20 and dropped > 200, (checked, dropped)
+    # the whole closure, captured: where the optimiser ends up
+    for c in (full, new):
+        c.load(V0.to(dev), img, torch.tensor([0.02, -0.01], device=dev))
+        c.prepare()
+        c.load(V0.to(dev), img, torch.tensor([0.02, -0.01], device=dev))
+        c.init_optimizer(4, 1e-3, 5, 8)
+        c.launch(10)
+    torch.cuda.synchronize()
+    assert full.r.check_capacity() and new.r.check_capacity()
+    ra, rb = full.read_report().cpu(), new.read_report().cpu()
+    assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
+    assert float((full.r.viewmats - new.r.viewmats).abs().max()) < 5e-3
 
 
 @pytest.mark.parametrize("n_gauss,n_cams,W,H", [(60000, 3, 640, 480), (200000, 8, 640, 480), (30000, 2, 325, 245)])
