@@ -1123,6 +1123,7 @@ def main():
         r2 = run_ba(dev, rank, world, N, W, H, WINDOW, steps, warmup, exchange_ranges=0 if xr else 4, exchange_overlap=True)
         ab = {"exchange": r2["exchange"], "keyframes_per_s": round(r2["keyframes_per_s"], 3),
               "ms_per_ba_iteration": round(r2["ms_per_iter"], 4)}
+    backend = td.get_backend() if world > 1 else "none"
     if rank == 0:
         line = {
             "metric": ba_metric(W, H, N),
@@ -1138,8 +1139,8 @@ def main():
                                f"{r['head_bytes'] / 1e6:.1f} MB head (visibility counts, pose gradients, loss, overflow flag), "
                                f"reduce-scatter of the {r['bucket_bytes'] / 1e6:.1f} MB fp32 gradient bucket, Adam on each rank's "
                                f"1/{world} of the map, all-gather of the updated parameter chunks; torch.distributed backend: "
-                               f"{td.get_backend()}" + (" (= RCCL over xGMI)" if td.get_backend() == "nccl" else
-                                                        " (REHEARSAL: not RCCL)"),
+                               f"{backend}" + (" (= RCCL over xGMI)" if backend == "nccl" else
+                                                 " (one rank: no collective)" if world == 1 else " (REHEARSAL: not RCCL)"),
                 "launch": "hip-graph replay (render+loss+backward | Adam on the rank's chunk) around the eager collectives"
                           if world > 1 else "hip-graph replay of the whole step",
             },

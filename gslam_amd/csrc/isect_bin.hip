@@ -91,12 +91,23 @@ __device__ __forceinline__ Rect tighten_rect(Rect r, float mx, float my, float a
     return r;
 }
 
+// trec (nullable): the splat records [C * N][12] (xy, conic, opacity, ...) of the same projection - the rectangle is tightened
+// to the instance's alpha >= 1/255 box (tighten_rect; gsx_isect_bin_sort_tight)
 __device__ __forceinline__ Rect load_rect(const float *__restrict__ means2d, const int32_t *__restrict__ radii,
-                                          int64_t idx, int tile_w, int tile_h, bool in_range) {
+                                          int64_t idx, int tile_w, int tile_h, bool in_range,
+                                          const float *__restrict__ trec = nullptr) {
     Rect r = {0, 0, 0, 0};
     if (in_range) {
         const int32_t rad = radii[idx];
-        if (rad > 0) r = tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rad, tile_w, tile_h);
+        if (rad > 0) {
+            if (trec) {
+                const float4 *q = reinterpret_cast<const float4 *>(trec + idx * 12);
+                const float4 q0 = q[0], q1 = q[1];
+                r = tighten_rect(tile_rect(q0.x, q0.y, rad, tile_w, tile_h), q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+            } else {
+                r = tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rad, tile_w, tile_h);
+            }
+        }
     }
     return r;
 }
@@ -177,7 +188,8 @@ constexpr int GB_MAX = 640;           // workgroups per camera (the matrix in th
 __global__ __launch_bounds__(BIN_THREADS) void count_matrix_kernel(const float *__restrict__ means2d,
                                                                    const int32_t *__restrict__ radii, int64_t N,
                                                                    int tile_w, int tile_h, int items,
-                                                                   int32_t *__restrict__ cnt /*[C][gblocks][n_tiles]*/) {
+                                                                   int32_t *__restrict__ cnt /*[C][gblocks][n_tiles]*/,
+    const float *__restrict__ trec /* nullable: records for tight rectangles */) {
     extern __shared__ int s_cnt[];  // [n_tiles]
     const int c = blockIdx.y;
     const int n_tiles = tile_w * tile_h;
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(BIN_THREADS) void count_matrix_kernel(const float *
     __syncthreads();
     for (int it = 0; it < items; ++it) {
         const int64_t g = ((int64_t)blockIdx.x * items + it) * BIN_THREADS + threadIdx.x;
-        const Rect r = load_rect(means2d, radii, (int64_t)c * N + g, tile_w, tile_h, g < N);
+        const Rect r = load_rect(means2d, radii, (int64_t)c * N + g, tile_w, tile_h, g < N, trec);
         walk_rects(r, tile_w, 0u, 0u, [&](int tile, unsigned int, unsigned int) { atomicAdd(&s_cnt[tile], 1); });
     }
     __syncthreads();
@@ -325,7 +337,8 @@ __global__ __launch_bounds__(BIN_THREADS) void place_kernel(const float *__restr
                                                             int tile_h, int items, int64_t M_cap,
                                                             const int32_t *__restrict__ offsets,
                                                             const int32_t *__restrict__ cnt,
-                                                            unsigned long long *__restrict__ entries) {
+                                                            unsigned long long *__restrict__ entries,
+    const float *__restrict__ trec /* nullable: records for tight rectangles */) {
     extern __shared__ int s_cur[];  // [n_tiles]: this workgroup's absolute write cursor per tile
     const int c = blockIdx.y;
     const int n_tiles = tile_w * tile_h;
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(BIN_THREADS) void place_kernel(const float *__restr
     for (int it = 0; it < items; ++it) {
         const int64_t g = ((int64_t)blockIdx.x * items + it) * BIN_THREADS + threadIdx.x;
         const int64_t idx = (int64_t)c * N + g;
-        const Rect r = load_rect(means2d, radii, idx, tile_w, tile_h, g < N);
+        const Rect r = load_rect(means2d, radii, idx, tile_w, tile_h, g < N, trec);
         const bool has = (r.x1 > r.x0) && (r.y1 > r.y0);
         const unsigned int klo = (unsigned int)idx, khi = has ? __float_as_uint(depths[idx]) : 0u;
         place_rects(r, tile_w, klo, khi, s_cur, M_cap, entries);
@@ -362,14 +375,15 @@ struct PreRec {
 __global__ __launch_bounds__(BIN_THREADS) void coarse_count_kernel(const float *__restrict__ means2d,
                                                                    const int32_t *__restrict__ radii, int64_t N,
                                                                    int tile_w, int tile_h, int items, int sw, int S,
-                                                                   int32_t *__restrict__ cnt /*[C][gblocks][S]*/) {
+                                                                   int32_t *__restrict__ cnt /*[C][gblocks][S]*/,
+    const float *__restrict__ trec /* nullable: records for tight rectangles */) {
     extern __shared__ int s_cnt[];  // [S]
     const int c = blockIdx.y;
     for (int i = threadIdx.x; i < S; i += BIN_THREADS) s_cnt[i] = 0;
     __syncthreads();
     for (int it = 0; it < items; ++it) {
         const int64_t g = ((int64_t)blockIdx.x * items + it) * BIN_THREADS + threadIdx.x;
-        const Rect r = load_rect(means2d, radii, (int64_t)c * N + g, tile_w, tile_h, g < N);
+        const Rect r = load_rect(means2d, radii, (int64_t)c * N + g, tile_w, tile_h, g < N, trec);
         if (r.x1 > r.x0 && r.y1 > r.y0) atomicAdd(&s_cnt[(r.y0 / SUPER) * sw + r.x0 / SUPER], 1);
     }
     __syncthreads();
@@ -383,7 +397,8 @@ __global__ __launch_bounds__(BIN_THREADS) void coarse_place_kernel(const float *
                                                                    int tile_w, int tile_h, int items, int sw, int S,
                                                                    int64_t rec_cap, const int32_t *__restrict__ coff,
                                                                    const int32_t *__restrict__ cnt,
-                                                                   PreRec *__restrict__ recs) {
+                                                                   PreRec *__restrict__ recs,
+    const float *__restrict__ trec /* nullable: records for tight rectangles */) {
     extern __shared__ int s_cur[];  // [S]
     const int c = blockIdx.y;
     const int32_t *row = cnt + ((int64_t)c * gridDim.x + blockIdx.x) * S;
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(BIN_THREADS) void coarse_place_kernel(const float *
     for (int it = 0; it < items; ++it) {
         const int64_t g = ((int64_t)blockIdx.x * items + it) * BIN_THREADS + threadIdx.x;
         const int64_t idx = (int64_t)c * N + g;
-        const Rect r = load_rect(means2d, radii, idx, tile_w, tile_h, g < N);
+        const Rect r = load_rect(means2d, radii, idx, tile_w, tile_h, g < N, trec);
         if (r.x1 > r.x0 && r.y1 > r.y0) {
             const int pos = atomicAdd(&s_cur[(r.y0 / SUPER) * sw + r.x0 / SUPER], 1);
             if ((uint64_t)(uint32_t)pos < (uint64_t)rec_cap) {
@@ -1065,10 +1080,10 @@ extern "C" int64_t gsx_isect_bin_workspace_bytes_n(int64_t C, int64_t N, int til
     return bin_layout(C, tile_w, tile_h, M_cap).total + (C > 0 && N > 0 ? C * N * 16 : 0) + 256;
 }
 
-extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, const float *depths, int64_t N, int64_t C,
-                                  int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev,
-                                  int32_t *status, int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_order,
-                                  void *workspace, int64_t workspace_bytes, void *stream) {
+static int isect_bin_sort_impl(const float *means2d, const int32_t *radii, const float *depths, const float *trec, int64_t N,
+                               int64_t C, int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev,
+                               int32_t *status, int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_order,
+                               void *workspace, int64_t workspace_bytes, void *stream) {
     GSX_CHECK_ARG(means2d && radii && depths && offsets && M_dev && status && N >= 0 && C >= 1);
     GSX_CHECK_ARG(tile_w > 0 && tile_h > 0 && M_cap >= 0 && M_cap < ((int64_t)1 << 31));
     GSX_CHECK_ARG(M_cap == 0 || flatten_ids);
@@ -1111,7 +1126,7 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
             int64_t *n_inst = (int64_t *)diff;
             PreRec *recs = (PreRec *)(ws + L.total);         // the tail behind the base layout (256-byte aligned)
             hipLaunchKernelGGL(coarse_count_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(S * 4), st,
-                               means2d, radii, N, tile_w, tile_h, (int)items, sw, S, cnt);
+                               means2d, radii, N, tile_w, tile_h, (int)items, sw, S, cnt, trec);
             GSX_CHECK_LAUNCH();
             hipLaunchKernelGGL(column_scan_kernel<false>, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(64 * CS_GROUPS), 0,
                                st, cnt, (int)gblocks, S, coff, (int32_t *)nullptr);
@@ -1120,7 +1135,7 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
                                (int32_t *)nullptr);
             GSX_CHECK_LAUNCH();
             hipLaunchKernelGGL(coarse_place_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(S * 4), st,
-                               means2d, radii, depths, N, tile_w, tile_h, (int)items, sw, S, rec_cap, coff, cnt, recs);
+                               means2d, radii, depths, N, tile_w, tile_h, (int)items, sw, S, rec_cap, coff, cnt, recs, trec);
             GSX_CHECK_LAUNCH();
             // tile level: chunks of instances, at most GB_MAX of them over the record capacity
             int64_t chunk = BIN_THREADS * 4;
@@ -1152,7 +1167,7 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
             const unsigned gblocks = (unsigned)((N + BIN_THREADS * items - 1) / (BIN_THREADS * items));
             if (N > 0) {
                 hipLaunchKernelGGL(count_matrix_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS),
-                                   (size_t)(n_tiles * 4), st, means2d, radii, N, tile_w, tile_h, (int)items, cnt);
+                                   (size_t)(n_tiles * 4), st, means2d, radii, N, tile_w, tile_h, (int)items, cnt, trec);
                 GSX_CHECK_LAUNCH();
                 hipLaunchKernelGGL(column_scan_kernel<false>, dim3((unsigned)((n_tiles + 63) / 64), (unsigned)C),
                                    dim3(64 * CS_GROUPS), 0, st, cnt, (int)gblocks, (int)n_tiles, offsets, (int32_t *)nullptr);
@@ -1166,7 +1181,7 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
             if (N > 0 && M_cap > 0) {
                 hipLaunchKernelGGL(place_kernel, dim3(gblocks, (unsigned)C), dim3(BIN_THREADS), (size_t)(n_tiles * 4),
                                    st, means2d, radii, depths, N, tile_w, tile_h, (int)items, M_cap, offsets, cnt,
-                                   entries);
+                                   entries, trec);
                 GSX_CHECK_LAUNCH();
             }
         }
@@ -1191,6 +1206,26 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
         GSX_CHECK_LAUNCH();
     }
     return GSX_OK;
+}
+
+extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, const float *depths, int64_t N, int64_t C,
+                                  int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev,
+                                  int32_t *status, int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_order,
+                                  void *workspace, int64_t workspace_bytes, void *stream) {
+    return isect_bin_sort_impl(means2d, radii, depths, nullptr, N, C, tile_w, tile_h, M_cap, offsets, M_dev, status, isect_ids,
+                               flatten_ids, tile_order, workspace, workspace_bytes, stream);
+}
+
+// The same with TIGHT rectangles: rec = the splat records [C * N][12] the projection wrote for the same render (gsx_project_fwd:
+// xy, conic, opacity, ...); an instance is listed only in the tiles of its 3-sigma square that hold a pixel centre inside the box
+// of its alpha >= 1/255 ellipse (tighten_rect above).  For renders whose tile lists nobody but the rasteriser reads.
+extern "C" int gsx_isect_bin_sort_tight(const float *means2d, const int32_t *radii, const float *depths, const float *rec,
+                                        int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int32_t *offsets,
+                                        int64_t *M_dev, int32_t *status, int64_t *isect_ids, int32_t *flatten_ids,
+                                        int32_t *tile_order, void *workspace, int64_t workspace_bytes, void *stream) {
+    GSX_CHECK_ARG(rec != nullptr && (((uintptr_t)rec) & 15) == 0);
+    return isect_bin_sort_impl(means2d, radii, depths, rec, N, C, tile_w, tile_h, M_cap, offsets, M_dev, status, isect_ids,
+                               flatten_ids, tile_order, workspace, workspace_bytes, stream);
 }
 
 // =====================================================================================================================

@@ -214,6 +214,12 @@ class RenderPlan:
 
     GROW = 1.5
     ORDER_MAX_PER_TILE = 1000       # heaviest-first launch order (by list length) below this capacity per tile
+    # MappingStep / WindowClosure on the generic chain: tight rectangles in the binning too (gsx_isect_bin_sort_tight).  Built, exact
+    # (tests/test_gpu_plans.py) and OFF: measured at 500 k x 8 (tools/dbg/ab_tight.sh) the BA iteration keeps 84 % of its keys and
+    # takes 1124.7 against 1115.3 us (the rasterisers composite the same prefix of 1500-deep lists: 316.4 / 316.8 us backward; the
+    # binning reads 32 B more per instance twice), the refiner's closure 73 % and 853.3 against 862.9 us.  The tracking closure's
+    # fused front is where it pays (TrackClosure(tile_exact), on by default: -6.8 us of 147).
+    TIGHT_LISTS = False
 
     def __init__(self, splats, n_cams: int, width: int, height: int, *, render_depth: bool, grads: str = 'pose',
                  Ks: Optional[torch.Tensor] = None, capacity: Optional[int] = None, need_n_touched: bool = False,
@@ -309,6 +315,7 @@ class RenderPlan:
         self.tile_work = self.balanced_order = None
         # tile sort inside the fused tracking rasteriser (gsx_raster_track_fused_sorting): enable_defer_sort()
         self.defer_sort = False
+        self.tight_lists = False      # generic chain: the same tight rectangles (gsx_isect_bin_sort_tight); set by the optimisation plans
         self.tile_exact = False       # fused front: the instance's tiles are those of its alpha >= 1/255 box inside the 3-sigma square
         self.row_keys = False         # the front ends with the projection; the rasteriser's tiles collect their keys (enable_row_keys)
         self._rows_last = False       # the last front ran with row keys (M is the sum of self.key_counters then)
@@ -694,14 +701,27 @@ class RenderPlan:
             self._front(st)
         else:
             self._project(st)
-            check(lib.gsx_isect_bin_sort(_p(self.means2d), _p(self.radii), _p(self.depths), self.N, self.C, self.tile_w,
-                                         self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status),
-                                         None, _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
-                                         self.isect_ws.numel(), st), "gsx_isect_bin_sort")
+            self._isect(st)
         check(lib.gsx_raster_track_fused(_p(self.rec), _p(self.backgrounds), _p(self.offsets), _p(self.flat), self.capacity,
                                          1, self.C, self.W, self.H, _p(gt), _p(exposure), float(w_photo), None, None, None,
                                          _p(rows), _p(self.v_rec), _p(self.launch_order), _p(self.tile_work), st),
               "gsx_raster_track_fused")
+
+    def _isect(self, st: int):
+        """tile lists of the generic chain (after ``_project``).  tight_lists: an instance is listed only in the tiles of its 3-sigma
+        square that hold a pixel centre inside the box of its alpha >= 1/255 ellipse (gsx_isect_bin_sort_tight) - what the
+        rasteriser composites, and so every output of the render and its backward, is unchanged; ``offsets`` / ``flat`` are then
+        NOT gsplat's isect_offsets / flatten_ids (nobody outside gslam/rasterization.py reads those)"""
+        if self.tight_lists:
+            check(lib.gsx_isect_bin_sort_tight(_p(self.means2d), _p(self.radii), _p(self.depths), _p(self.rec), self.N, self.C,
+                                               self.tile_w, self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev),
+                                               _p(self.status), None, _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
+                                               self.isect_ws.numel(), st), "gsx_isect_bin_sort_tight")
+            return
+        check(lib.gsx_isect_bin_sort(_p(self.means2d), _p(self.radii), _p(self.depths), self.N, self.C, self.tile_w,
+                                     self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status),
+                                     None, _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
+                                     self.isect_ws.numel(), st), "gsx_isect_bin_sort")
 
     def forward(self, st: int, track_loss=None):
         """track_loss = (gt [C,H,W,3], exposure [C,2], w_photo, loss_rows [T,6]): the forward rasteriser evaluates the
@@ -713,10 +733,7 @@ class RenderPlan:
             self._front(st)
         else:
             self._project(st)
-            check(lib.gsx_isect_bin_sort(_p(self.means2d), _p(self.radii), _p(self.depths), self.N, self.C, self.tile_w,
-                                         self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status),
-                                         None, _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
-                                         self.isect_ws.numel(), st), "gsx_isect_bin_sort")
+            self._isect(st)
         if track_loss is not None:
             gt, exposure, w_photo, rows = track_loss
             assert self.CH == 4 and self.n_touched is None
@@ -887,6 +904,7 @@ class TrackClosure:
         # (RenderPlan.enable_tile_exact); None = wherever the fused front runs.  Results are identical either way.
         if tile_exact is None or tile_exact:
             self.r.enable_tile_exact()
+            self.r.tight_lists = not self.r.front
         dev = self.r.dev
         self.dev = dev
         self.slots = _PoseSlots(1, dev, [True])
@@ -1079,6 +1097,9 @@ class WindowClosure:
                 self.loss_rows = torch.zeros(r.T, 6, device=r.dev)
         if not self.fused:
             self.r = RenderPlan(splats, Cn, cameras[0].width, cameras[0].height, render_depth=False, grads='pose')
+            self.r.tight_lists = bool(RenderPlan.TIGHT_LISTS) and not self.r.front
+            if self.r.front and RenderPlan.TIGHT_LISTS:
+                self.r.enable_tile_exact()
         self.r.Ks.copy_(Ks)
         dev = self.r.dev
         self.dev = dev
@@ -1271,6 +1292,9 @@ class MappingStep:
         if Cl > 0:
             self.r = RenderPlan(splats, Cl, self.W, self.H, render_depth=True, grads='full', grad_out=self.grad_views,
                                 need_n_touched=need_n_touched)
+            self.r.tight_lists = bool(RenderPlan.TIGHT_LISTS) and not self.r.front
+            if self.r.front and RenderPlan.TIGHT_LISTS:
+                self.r.enable_tile_exact()
             self.r.Ks.copy_(torch.stack([self.window[i].camera.intrinsics for i in self.mine], dim=0))
             r = self.r
             self.gt = torch.empty(Cl, self.H, self.W, 3, device=dev)

@@ -185,6 +185,15 @@ int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, const float *
                        int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev, int32_t *status,
                        int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_order, void *workspace,
                        int64_t workspace_bytes, void *stream);
+/* gsx_isect_bin_sort with TIGHT rectangles (round 5): rec = the splat records [C*N][12] gsx_project_fwd wrote for the same render;
+ * an instance is listed only in the tiles of its 3-sigma square that hold a pixel centre inside the axis-aligned box of its
+ * alpha >= 1/255 ellipse.  The reference lists the whole square (gslam/rasterization.py:259-272) and its rasteriser skips the rest
+ * pixel by pixel: every output of the rasteriser and of its backward is unchanged, the lists are a quarter shorter.  For launch
+ * plans whose tile lists only the rasteriser reads (offsets / flatten_ids are NOT those of gsplat.isect_tiles). */
+int gsx_isect_bin_sort_tight(const float *means2d, const int32_t *radii, const float *depths, const float *rec, int64_t N,
+                             int64_t C, int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev,
+                             int32_t *status, int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_order, void *workspace,
+                             int64_t workspace_bytes, void *stream);
 
 /* ---- K1 + K3..K7 fused for the launch plans (csrc/isect_bin.hip, "fused front"): the gslam front-end projection of
  * gsx_project_fwd (flags: GSX_PROJ_LOG_SCALES implied by the caller's data, RENDER_DEPTH, BETAS, SKIP_CULLED; radius_clip 0)

@@ -1147,3 +1147,37 @@ def test_range_copy_gathers_and_scatters_the_parts_of_a_range(dev):
                 # what came back is the range's rows (all parts, or this rank's) and nothing else
                 mask = back_h != 0
                 assert torch.equal(back_h[mask], whole[mask]) and int(mask.sum()) >= (1 if own else world) * b.Lk - 8
+
+
+@pytest.mark.parametrize("n,n_cams", [(9000, 3), (150000, 8)])
+def test_tight_tile_lists_of_the_generic_chain_change_no_output(dev, n, n_cams):
+    """gsx_isect_bin_sort_tight (round 5) in the BA plan (direct binning at 9 k x 3, the spatial pre-sort at 150 k x 8): against the
+    plan with the reference's full 3-sigma squares - render, alphas and loss bit for bit (the same entries are composited in the
+    same order), all six map gradients and the pose gradients to float-atomic noise, fewer keys."""
+    from gslam_amd.mapping import BundleAdjuster
+    from gslam_amd.plan import RenderPlan
+    res = []
+    for tight in (False, True):
+        m, cam, frame = _world(dev, n=n)
+        window = [frame(i, i) for i in range(n_cams)]
+        old = RenderPlan.TIGHT_LISTS
+        RenderPlan.TIGHT_LISTS = tight
+        try:
+            plan = BundleAdjuster(m, capturable=True).plan(window)
+        finally:
+            RenderPlan.TIGHT_LISTS = old
+        assert plan.r.tight_lists == (tight and not plan.r.front) and plan.r.tile_exact == (tight and plan.r.front)
+        total, pm = plan.render_backward()
+        torch.cuda.synchronize()
+        assert plan.capacity_ok()
+        res.append((plan.r.render.clone(), plan.r.alphas.clone(), float(total), float(pm),
+                    {k: v.clone() for k, v in plan.grad_views.items()}, plan.g_dR.clone(), plan.g_dt.clone(),
+                    plan.r.keys_total(), plan.r.radii.clone()))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+    assert torch.equal(a[8], b[8])
+    for k in a[4]:
+        assert float((a[4][k] - b[4][k]).abs().max()) < 2e-4 * float(a[4][k].abs().max()) + 1e-10, k
+    assert float((a[5] - b[5]).abs().max()) < 1e-3 * float(a[5].abs().max()) + 1e-9
+    assert float((a[6] - b[6]).abs().max()) < 1e-3 * float(a[6].abs().max()) + 1e-9
+    assert b[7] < 0.9 * a[7], (a[7], b[7])
