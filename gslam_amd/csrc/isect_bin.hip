@@ -1840,6 +1840,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
         // ---- row keys: exclusive scan of the row's per-tile counts (its segment is grouped by tile), the words out, then the row's
         // instance records are walked a second time - they were written a few microseconds ago by this workgroup - and every key
         // goes to its tile's stretch of the row's segment through the LDS cursors.  Nothing waits for another workgroup.
+        GSX_FT(1, 0)
         const int TT = C * n_tiles;
         const int per = (TT + FRONT_THREADS - 1) / FRONT_THREADS;
         const int lo = min(TT, (int)threadIdx.x * per), hi = min(TT, lo + per);
@@ -1875,6 +1876,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
         }
         if (blockIdx.x == 0 && threadIdx.x < GSX_ROW_CURSORS) a.cursor[threadIdx.x] = 0ull;
         __syncthreads();
+        GSX_FT(1, 1)
         unsigned long long *seg_keys = a.row_keys + (int64_t)blockIdx.x * a.row_cap;
         for (int c = 0; c < C; ++c) {
             const int n = min(s_ninst[c], seg_cap);
@@ -1893,6 +1895,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void front_project_kernel(FrontArgs 
                 place_rects(r, a.tile_w, klo, khi, s_cnt, (int64_t)a.row_cap, seg_keys, c * n_tiles);
             }
         }
+        GSX_FT(1, 2)
     } else
     for (int i = threadIdx.x; i < C * n_tiles; i += FRONT_THREADS) {
         const int c = i / n_tiles, tl = i - c * n_tiles;
@@ -2173,7 +2176,10 @@ FrontLayout front_layout(int64_t N, int64_t C, int tile_w, int tile_h, int64_t M
     FrontLayout L;
     const int64_t T = C * tile_w * tile_h;
     int items = 1;
-    while ((N + (int64_t)FRONT_THREADS * items - 1) / ((int64_t)FRONT_THREADS * items) > 256 && items < 8) items *= 2;
+#ifndef GSX_FRONT_ROWS
+#define GSX_FRONT_ROWS 256            // projection workgroups the front aims for at most (one per CU); A/B: tools/dbg/ab_build.sh
+#endif
+    while ((N + (int64_t)FRONT_THREADS * items - 1) / ((int64_t)FRONT_THREADS * items) > GSX_FRONT_ROWS && items < 8) items *= 2;
     while ((N + (int64_t)FRONT_THREADS * items - 1) / ((int64_t)FRONT_THREADS * items) > GB_MAX) items *= 2;
     L.items = items;
     L.R = (int)((N + (int64_t)FRONT_THREADS * items - 1) / ((int64_t)FRONT_THREADS * items));

@@ -54,6 +54,8 @@ def main():
     assert setter(None) == 0
     a = buf.cpu().numpy().reshape(2, 4096, 8).astype(np.float64)
     for k, kern in enumerate(("front_project_kernel", "front_place_kernel")):
+        if k == 1 and tr.plan.r.row_keys:
+            continue
         rows = a[k][a[k][:, 0] > 0]
         t0 = rows[:, 0].min()
         print(f"{kern}: {len(rows)} workgroups stamped; microseconds after the first entry")
@@ -62,6 +64,15 @@ def main():
             v = (v[v > 0] - t0) / 100.0
             if len(v):
                 print(f"  {name:45s} n={len(v):5d}  min {v.min():6.2f}  p25 {np.percentile(v, 25):6.2f}  p50 {np.percentile(v, 50):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f}")
+    if tr.plan.r.row_keys:
+        # row keys: no placement launch; the projection workgroups stamp their tail on the second kernel's rows
+        rows0 = a[0][a[0][:, 0] > 0]
+        t0 = rows0[:, 0].min()
+        tail = a[1][:len(rows0)]
+        for j, name in enumerate(("row-keys tail entered", "row scanned, words written", "keys placed (issue)")):
+            v = (tail[:, j][tail[:, j] > 0] - t0) / 100.0
+            print(f"  {name:45s} n={len(v):5d}  min {v.min():6.2f}  p25 {np.percentile(v, 25):6.2f}  p50 {np.percentile(v, 50):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f}")
+        return
     ns = a[1][:len(a[0][a[0][:, 0] > 0]), 4]
     print(f"survivors of the cull per projection workgroup: min {ns.min():.0f}  p10 {np.percentile(ns, 10):.0f}  p50 {np.percentile(ns, 50):.0f}"
           f"  p90 {np.percentile(ns, 90):.0f}  max {ns.max():.0f}  sum {ns.sum():.0f};  workgroups with a second trip: {(ns > 1024).sum()}")
