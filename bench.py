@@ -94,7 +94,7 @@ class StageTimer:
     STAGES = ("gsx_pose_zhou_fwd", "gsx_project_fwd", "gsx_isect_bin_sort", "gsx_front_fwd", "gsx_front_pose_bwd",
               "gsx_raster_fwd", "gsx_raster_fwd_track_loss", "gsx_raster_track_fused", "gsx_raster_track_fused_sorting",
               "gsx_raster_track_fused_rows", "gsx_ssim_fwd",
-              "gsx_ssim_bwd", "gsx_map_loss", "gsx_raster_bwd", "gsx_project_bwd", "gsx_pose_zhou_bwd_partials",
+              "gsx_ssim_bwd", "gsx_ssim_bwd_map_loss", "gsx_map_loss", "gsx_raster_bwd", "gsx_project_bwd", "gsx_pose_zhou_bwd_partials",
               "gsx_isotropic_loss_acc", "gsx_loss_finish", "gsx_counters_add", "gsx_adam_multi_steps",
               "gsx_adam_multi_steps_decay", "gsx_track_opt_tail")
 
@@ -249,6 +249,9 @@ def algorithmic_bytes(N, C, M, P, CH, T, M_near=None, V=None, R=0):
         "gsx_project_bwd": C * N * (40 + 28 + 24) + N * 40 + C * 64,
         "gsx_ssim_fwd": 72 * P,
         "gsx_ssim_bwd": 72 * P,
+        # SSIM backward + loss block in one pass: the three derivative maps and both images in (36 + 12 + 4 CH + 4 for alpha), the
+        # gradient of the render out (4 CH); the planar SSIM gradient (12 out, 12 in) never exists
+        "gsx_ssim_bwd_map_loss": P * (36 + 12 + 4 * CH + 4 + 4 * CH),
         "gsx_adam_multi_steps": 420 * N,
         "gsx_adam_multi_steps_decay": 420 * N + 4 * N,
     }

@@ -79,6 +79,9 @@ PROTOTYPES = {
                                          vp, vp]),
     "gsx_counters_add_gated": (i32, [i32, C.POINTER(vp), i64, vp, vp]),
     "gsx_status_flag": (i32, [vp, i32, i32, vp, vp]),
+    "gsx_ssim_bwd_map_loss_rows": (i64, [i64, i32, i32]),
+    "gsx_ssim_bwd_map_loss": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, f32, f32, i32, vp, vp, vp, vp, f32, vp,
+                                    vp, i64, vp]),
     "gsx_range_copy": (i32, [i32, C.POINTER(vp), C.POINTER(i64), i32, vp, i32, vp]),
     "gsx_track_opt_state_bytes": (i64, []),
     "gsx_track_opt_init": (i32, [vp, i32, i32, f32, C.c_double, i32, i32, i32, C.c_double, C.c_double, vp]),

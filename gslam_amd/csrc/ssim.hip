@@ -10,6 +10,7 @@
 // renders of the rasteriser are consumed without a permute copy.  The map mean is reduced wave64 -> LDS -> one
 // partial per workgroup, then a single-block finishing kernel (deterministic, no atomics).
 #include "gsx_common.h"
+#include "loss_pixel.h"
 
 namespace {
 
@@ -251,7 +252,144 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float *__restrict__
     }
 }
 
+// ---- SSIM backward + the mapping loss block in one pass (round 5) ------------------------------------------------
+// ssim_bwd_kernel<3> holds, for its 32 x 16 output pixels, the colours of render and target in LDS and the SSIM gradient of the
+// three colours in registers - everything gsx_map_loss reads per pixel except depth / beta / alpha (same cache lines as the
+// colours).  Finishing the pixel here (loss_pixel.h: exposure affine, active-nerf photometric + log^2 beta, edge-aware depth TV,
+// SSIM gradient added last - the same expressions in the same order as map_loss_kernel, so d loss / d render comes out bit for bit)
+// takes the planar SSIM gradient's round trip through HBM (write 12 B, read 12 B per pixel), one more pass over render + target
+// and one launch out of the BA iteration.  One partial row of the loss sums per tile (gsx_ssim_bwd_map_loss_rows).
+__global__ __launch_bounds__(256) void ssim_bwd_loss_kernel(gsx_loss::LossArgs A, int crop, const float *__restrict__ dm_dmu1,
+                                                            const float *__restrict__ dm_ds1,
+                                                            const float *__restrict__ dm_ds12,
+                                                            const float *__restrict__ scale, float scale_mul, int gx_n,
+                                                            int gy_n, int gz_n) {
+    constexpr int NC = 3;
+    __shared__ float sm[3][INY][INX + 1];
+    __shared__ float hz[3][INY][TSX + 1];
+    __shared__ float s_xy[2][NC][TSY][TSX + 1];
+    __shared__ float s_part[4][gsx_loss::NPART];
+    const TileId tid = xcd_tile(gx_n, gy_n, gz_n);
+    const int b = tid.bz;                                     // camera
+    const int H = A.H, W = A.W, CH = A.CH;
+    const int x0 = tid.bx * TSX, y0 = tid.by * TSY;
+    const int t = threadIdx.x;
+    for (int i = t; i < TSY * TSX; i += 256) {
+        const int ly = i / TSX, lx = i - ly * TSX;
+        const int gy = y0 + ly, gx = x0 + lx;
+        const bool in = gy < H && gx < W;
+        const int64_t p = ((int64_t)b * H + gy) * W + gx;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            s_xy[0][k][ly][lx] = in ? A.render[p * CH + k] : 0.f;
+            s_xy[1][k][ly][lx] = in ? A.gt[p * 3 + k] : 0.f;
+        }
+    }
+    const float sc = scale[0] * scale_mul;
+    const int lx = t & 31, ly = (t >> 5) * 2;
+    const int gx = x0 + lx;
+    float g[2][3];
+    for (int kc = 0; kc < NC; ++kc) {
+        const int plane = b * 3 + kc;
+        __syncthreads();
+        for (int i = t; i < INY * INX; i += 256) {
+            const int yy = i / INX, xx = i - yy * INX;
+            const int gy = y0 + yy - HALO, gxx = x0 + xx - HALO;
+            float a = 0.f, c = 0.f, d = 0.f;
+            if (gxx >= crop && gxx < W - crop && gy >= crop && gy < H - crop) {
+                const int64_t o = ((int64_t)plane * H + gy) * W + gxx;
+                a = dm_dmu1[o]; c = dm_ds1[o]; d = dm_ds12[o];
+            }
+            sm[0][yy][xx] = a; sm[1][yy][xx] = c; sm[2][yy][xx] = d;
+        }
+        __syncthreads();
+        if (t < INY * (TSX / 4)) {
+            const int yy = t / (TSX / 4), xx = (t - yy * (TSX / 4)) * 4;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                float in[14];
+#pragma unroll
+                for (int k = 0; k < 14; ++k) in[k] = sm[m][yy][xx + k];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc += c_win[k] * in[o + k];
+                    hz[m][yy][xx + o] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const float v0 = hz[0][ly + r][lx], v1 = hz[1][ly + r][lx], v2 = hz[2][ly + r][lx];
+            if (r < 11) { const float w = c_win[r]; acc[0][0] += w * v0; acc[0][1] += w * v1; acc[0][2] += w * v2; }
+            if (r >= 1) { const float w = c_win[r - 1]; acc[1][0] += w * v0; acc[1][1] += w * v1; acc[1][2] += w * v2; }
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const float x = s_xy[0][kc][ly + o][lx], y = s_xy[1][kc][ly + o][lx];
+            const float v = sc * (acc[o][0] + 2.0f * x * acc[o][1] + y * acc[o][2]);
+            if (kc == 0) g[o][0] = v; else if (kc == 1) g[o][1] = v; else g[o][2] = v;
+        }
+    }
+    float part[gsx_loss::NPART] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int gy = y0 + ly + o;
+        if (gx < W && gy < H) {
+            float pp[gsx_loss::NPART] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            gsx_loss::map_loss_pixel(A, b, gx, gy, s_xy[0][0][ly + o][lx], s_xy[0][1][ly + o][lx], s_xy[0][2][ly + o][lx],
+                                     s_xy[1][0][ly + o][lx], s_xy[1][1][ly + o][lx], s_xy[1][2][ly + o][lx], true, g[o], pp);
+#pragma unroll
+            for (int k = 0; k < gsx_loss::NPART; ++k) part[k] += pp[k];
+        }
+    }
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int k = 0; k < gsx_loss::NPART; ++k) {
+        const float tot = gsx_wave_sum(part[k]);
+        if (lane == 0) s_part[wave][k] = tot;
+    }
+    __syncthreads();
+    if (t < gsx_loss::NPART)
+        A.partials[(((int64_t)b * gy_n + tid.by) * gx_n + tid.bx) * gsx_loss::NPART + t] =
+            (s_part[0][t] + s_part[1][t]) + (s_part[2][t] + s_part[3][t]);
+}
+
 }  // namespace
+
+extern "C" int64_t gsx_ssim_bwd_map_loss_rows(int64_t C, int H, int W) {
+    return C * ((H + TSY - 1) / TSY) * ((W + TSX - 1) / TSX);
+}
+
+extern "C" int gsx_ssim_bwd_map_loss(const float *render, const float *alphas, const float *gt, const float *exposure, int64_t C,
+                                     int H, int W, int CH, int depth_index, int beta_index, int mode, float w_photo, float w_tv,
+                                     float mask_thresh, int crop, const float *dm_dmu1, const float *dm_dsigma1_sq,
+                                     const float *dm_dsigma12, const float *scale, float scale_mul, float *v_render,
+                                     void *workspace, int64_t workspace_bytes, void *stream) {
+    GSX_CHECK_ARG(render && gt && exposure && v_render && C >= 1 && C < 65536 && H > 0 && W > 0 && CH >= 3);
+    GSX_CHECK_ARG(mode >= 0 && mode <= 2 && (mode == 1 || (beta_index >= 3 && beta_index < CH)));
+    GSX_CHECK_ARG(w_tv == 0.f || (alphas && depth_index >= 3 && depth_index < CH));
+    GSX_CHECK_ARG(dm_dmu1 && dm_dsigma1_sq && dm_dsigma12 && scale && crop >= 0);
+    const int64_t rows = gsx_ssim_bwd_map_loss_rows(C, H, W);
+    if (!workspace || workspace_bytes < rows * gsx_loss::NPART * (int64_t)sizeof(float)) {
+        gsx_set_error("gsx_ssim_bwd_map_loss: workspace too small");
+        return GSX_E_WORKSPACE;
+    }
+    gsx_loss::LossArgs A;
+    A.render = render; A.alphas = alphas; A.gt = gt; A.exposure = exposure; A.ssim_grad = nullptr;
+    A.v_render = v_render; A.partials = (float *)workspace;
+    A.H = H; A.W = W; A.CH = CH; A.depth_index = depth_index; A.beta_index = beta_index; A.mode = mode;
+    A.w_photo = w_photo; A.w_tv = w_tv; A.mask_thresh = mask_thresh;
+    const int gx = (W + TSX - 1) / TSX, gy = (H + TSY - 1) / TSY, gz = (int)C;
+    GSX_CHECK_ARG((int64_t)gx * gy * gz < ((int64_t)1 << 31));
+    hipLaunchKernelGGL(ssim_bwd_loss_kernel, dim3((unsigned)(gx * gy * gz)), dim3(256), 0, (hipStream_t)stream, A, crop, dm_dmu1,
+                       dm_dsigma1_sq, dm_dsigma12, scale, scale_mul, gx, gy, gz);
+    GSX_CHECK_LAUNCH();
+    return GSX_OK;
+}
 
 extern "C" int64_t gsx_ssim_workspace_bytes(int64_t B, int CH, int H, int W) {
     const int64_t blocks = B * CH * ((H + TSY - 1) / TSY) * ((W + TSX - 1) / TSX);

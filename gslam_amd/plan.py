@@ -1236,6 +1236,8 @@ class MappingStep:
     ``optimizers``: mapping.MapOptimizers built with capturable=True.  Exposure parameters of keyframes are constants
     here (the backend freezes them when it adds a keyframe, gslam_amd/backend.py add_keyframe)."""
 
+    FUSE_SSIM_LOSS = True       # SSIM backward + loss block in one launch (gsx_ssim_bwd_map_loss); False: two launches (A/B, tests)
+
     def __init__(self, splats, optimizers, window, conf, regularize: bool = True, shard=None,
                  need_n_touched: bool = False, decay_opacity: bool = True, exchange_ranges: int = 0,
                  exchange_overlap: bool = True):
@@ -1312,7 +1314,9 @@ class MappingStep:
             self.ssim_grad = torch.empty(Cl, 3, H, W, device=dev)
             self.ssim_ws = torch.empty(int(lib.gsx_ssim_workspace_bytes(Cl, 3, H, W)), dtype=torch.uint8, device=dev)
             self.n_ssim = int(lib.gsx_ssim_partials(Cl, 3, H, W))
-            self.map_ws = torch.empty(int(lib.gsx_map_loss_workspace_bytes(Cl, H, W)), dtype=torch.uint8, device=dev)
+            self.loss_rows_fused = int(lib.gsx_ssim_bwd_map_loss_rows(Cl, H, W))
+            self.map_ws = torch.empty(max(int(lib.gsx_map_loss_workspace_bytes(Cl, H, W)), self.loss_rows_fused * 24 + 256),
+                                      dtype=torch.uint8, device=dev)
             self._one = torch.ones(1, device=dev)
             self._s_r = (C.c_int64 * 4)(H * W * r.CH, 1, W * r.CH, r.CH)
             self._s_g = (C.c_int64 * 4)(H * W * 3, 1, W * 3, 3)
@@ -1422,14 +1426,25 @@ class MappingStep:
             check(lib.gsx_ssim_fwd(_p(r.render), _p(self.gt), Cl, 3, H, W, self._s_r, self._s_g, 5, None,
                                    _p(self.dm[0]), _p(self.dm[1]), _p(self.dm[2]), _p(self.ssim_ws),
                                    self.ssim_ws.numel(), st), "gsx_ssim_fwd")
-            check(lib.gsx_ssim_bwd(_p(r.render), _p(self.gt), Cl, 3, H, W, self._s_r, self._s_g, 5, _p(self.dm[0]),
-                                   _p(self.dm[1]), _p(self.dm[2]), _p(self._one), -w_ssim / numel_ssim,
-                                   _p(self.ssim_grad), st), "gsx_ssim_bwd")
-            ssim_grad = self.ssim_grad
+            if not self.FUSE_SSIM_LOSS:
+                check(lib.gsx_ssim_bwd(_p(r.render), _p(self.gt), Cl, 3, H, W, self._s_r, self._s_g, 5, _p(self.dm[0]),
+                                       _p(self.dm[1]), _p(self.dm[2]), _p(self._one), -w_ssim / numel_ssim,
+                                       _p(self.ssim_grad), st), "gsx_ssim_bwd")
+                ssim_grad = self.ssim_grad
         denom = Cl * H * W * (3 if mode == 1 else 1)
-        check(lib.gsx_map_loss(_p(r.render), _p(r.alphas), _p(self.gt), _p(self.exposure), Cl, H, W, r.CH, r.depth_index,
-                               r.betas_index, mode, w_photo / denom, w_tv, 0.4, _p(ssim_grad), None, _p(r.v_render),
-                               None, _p(self.map_ws), self.map_ws.numel(), st), "gsx_map_loss")
+        loss_hw = (H, W)
+        if n_ssim and self.FUSE_SSIM_LOSS:
+            # SSIM backward and the loss block in one pass: the planar SSIM gradient never goes through memory, render and target
+            # are read once less, one launch less (csrc/ssim.hip ssim_bwd_loss_kernel); one partial row per 32 x 16 tile
+            check(lib.gsx_ssim_bwd_map_loss(_p(r.render), _p(r.alphas), _p(self.gt), _p(self.exposure), Cl, H, W, r.CH,
+                                            r.depth_index, r.betas_index, mode, w_photo / denom, w_tv, 0.4, 5, _p(self.dm[0]),
+                                            _p(self.dm[1]), _p(self.dm[2]), _p(self._one), -w_ssim / numel_ssim,
+                                            _p(r.v_render), _p(self.map_ws), self.map_ws.numel(), st), "gsx_ssim_bwd_map_loss")
+            loss_hw = (self.loss_rows_fused // Cl, 256)
+        else:
+            check(lib.gsx_map_loss(_p(r.render), _p(r.alphas), _p(self.gt), _p(self.exposure), Cl, H, W, r.CH, r.depth_index,
+                                   r.betas_index, mode, w_photo / denom, w_tv, 0.4, _p(ssim_grad), None, _p(r.v_render),
+                                   None, _p(self.map_ws), self.map_ws.numel(), st), "gsx_map_loss")
         if project:
             r.backward(st, keep)
             self.enqueue_pose_partials(st)
@@ -1445,8 +1460,8 @@ class MappingStep:
         c0 = (C.c_float * 5)(w_photo * pm, w_photo * pm, w_tv, -w_ssim / numel_ssim if n_ssim else 0.0,
                              w_iso if iso_ws is not None else 0.0)
         c1 = (C.c_float * 5)(shard * pm, shard * pm, 0.0, 0.0, 0.0)
-        check(lib.gsx_loss_finish(_p(self.map_ws), Cl, H, W, _p(self.ssim_ws) if n_ssim else None, n_ssim, _p(iso_ws),
-                                  n_iso, c0, c1, w_ssim if n_ssim else 0.0, 0.0, None, _p(self.g_exposure),
+        check(lib.gsx_loss_finish(_p(self.map_ws), Cl, loss_hw[0], loss_hw[1], _p(self.ssim_ws) if n_ssim else None, n_ssim,
+                                  _p(iso_ws), n_iso, c0, c1, w_ssim if n_ssim else 0.0, 0.0, None, _p(self.g_exposure),
                                   _p(self.out2), st), "gsx_loss_finish")
         # this rank's share of the overflow flag: 1.0 if the render above truncated a tile list (sticky status bit 1), 1024.0 if
         # its tile counts were clamped as corrupt (bit 2): either gates the update on every rank (finish_step tells them apart)

@@ -415,6 +415,18 @@ int gsx_map_loss(const float *render, const float *alphas, const float *gt, cons
                  int W, int CH, int depth_index, int beta_index, int mode, float w_photo, float w_tv,
                  float mask_thresh, const float *ssim_grad, float *sums, float *v_render, float *v_exposure,
                  void *workspace, int64_t workspace_bytes, void *stream);
+/* gsx_ssim_bwd(scale_mul) + gsx_map_loss(ssim_grad = its output) in ONE pass (round 5): render [C,H,W,CH] (colours first), gt
+ * [C,H,W,3], the three derivative maps gsx_ssim_fwd left ([C,3,H,W] planar), crop as given to it; the other arguments and
+ * v_render as gsx_map_loss.  d loss / d render comes out bit for bit as from the two launches (same expressions, same order;
+ * csrc/loss_pixel.h); the planar SSIM gradient never exists.  Leaves gsx_ssim_bwd_map_loss_rows(C, H, W) rows of 6 partial sums
+ * in `workspace` (>= rows * 24 bytes): finish with gsx_loss_finish(workspace, C, rows / C, 256, ...) - it reads one row per 256
+ * "pixels" of an H x W = (rows / C) x 256 image. */
+int64_t gsx_ssim_bwd_map_loss_rows(int64_t C, int H, int W);
+int gsx_ssim_bwd_map_loss(const float *render, const float *alphas, const float *gt, const float *exposure, int64_t C, int H,
+                          int W, int CH, int depth_index, int beta_index, int mode, float w_photo, float w_tv,
+                          float mask_thresh, int crop, const float *dm_dmu1, const float *dm_dsigma1_sq,
+                          const float *dm_dsigma12, const float *scale, float scale_mul, float *v_render, void *workspace,
+                          int64_t workspace_bytes, void *stream);
 /* isotropic regulariser (backend.py:287-296): sum_out[0] = sum over visible g of sum_j |exp(s_j) - exp(mean s)|;
  * v_log_scales [N,3] = weight * d/ds (mean detached), zero rows for invisible Gaussians. */
 int64_t gsx_isotropic_workspace_bytes(int64_t N);

@@ -1181,3 +1181,36 @@ def test_tight_tile_lists_of_the_generic_chain_change_no_output(dev, n, n_cams):
     assert float((a[5] - b[5]).abs().max()) < 1e-3 * float(a[5].abs().max()) + 1e-9
     assert float((a[6] - b[6]).abs().max()) < 1e-3 * float(a[6].abs().max()) + 1e-9
     assert b[7] < 0.9 * a[7], (a[7], b[7])
+
+
+@pytest.mark.parametrize("W,H,n_cams", [(320, 240, 3), (325, 245, 2), (640, 480, 1)])
+def test_ssim_backward_and_loss_block_in_one_launch_equal_the_two_launches(dev, W, H, n_cams):
+    """gsx_ssim_bwd_map_loss (round 5) against gsx_ssim_bwd + gsx_map_loss inside the BA plan: d loss / d render bit for bit (the
+    pixel's expressions are shared, csrc/loss_pixel.h), loss values and exposure gradients to the rounding of a different grouping
+    of the partial sums (one row per 32 x 16 tile instead of one per 256 pixels), map gradients to float-atomic noise - also on an
+    image that is not made of whole tiles"""
+    from gslam_amd.mapping import BundleAdjuster
+    from gslam_amd.plan import MappingStep
+    res = []
+    for fused in (False, True):
+        m, cam, frame = _world(dev, n=8000, W=W, H=H)
+        window = [frame(i, i) for i in range(n_cams)]
+        for i, f in enumerate(window):
+            f.exposure_params = torch.tensor([0.03 * i, -0.02 * i], device=dev)
+        old = MappingStep.FUSE_SSIM_LOSS
+        MappingStep.FUSE_SSIM_LOSS = fused
+        try:
+            plan = BundleAdjuster(m, capturable=True).plan(window)
+            total, pm = plan.render_backward()
+            torch.cuda.synchronize()
+        finally:
+            MappingStep.FUSE_SSIM_LOSS = old
+        assert plan.capacity_ok() and plan.conf.ssim_weight > 0
+        res.append((plan.r.v_render.clone(), float(total), float(pm), plan.g_exposure.clone(),
+                    {k: v.clone() for k, v in plan.grad_views.items()}))
+    a, b = res
+    assert float(a[0].abs().max()) > 0 and torch.equal(a[0], b[0])
+    assert abs(a[1] - b[1]) <= 2e-6 * abs(a[1]) and abs(a[2] - b[2]) <= 2e-6 * abs(a[2]), (a[1], b[1], a[2], b[2])
+    assert float((a[3] - b[3]).abs().max()) <= 1e-5 * float(a[3].abs().max()) + 1e-12
+    for k in a[4]:
+        assert float((a[4][k] - b[4][k]).abs().max()) < 2e-4 * float(a[4][k].abs().max()) + 1e-10, k

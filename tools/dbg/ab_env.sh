@@ -11,5 +11,5 @@ $patch
 sys.argv = ['bench.py'] + '''$BENCH_ARGS'''.split()
 runpy.run_path('bench.py', run_name='__main__')
 PY
-  python3 -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'], d['closure']['us'], d['ba_iteration']['us'])" gpurun_out/ab_env_$v.json
+  python3 -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'], d.get('closure', {}).get('us'), d.get('ba_iteration', {}).get('us'), d.get('stage_us'))" gpurun_out/ab_env_$v.json
 done
