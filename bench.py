@@ -193,7 +193,7 @@ def in_graph_launch_us(plan, stage, resets, n_closures, frames=3):
     for si, reset in enumerate([resets[0]] + list(resets)):   # the first sample is taken twice: its first take only warms up
         totals = {0: [], 1: []}
         for i in range(2 * frames + 2):
-            which = i & 1
+            which = (i + 1) & 1                              # ends on the PLAIN graph: the key counters read below are one closure's
             reset()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

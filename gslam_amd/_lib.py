@@ -79,6 +79,9 @@ PROTOTYPES = {
                                          vp, vp]),
     "gsx_counters_add_gated": (i32, [i32, C.POINTER(vp), i64, vp, vp]),
     "gsx_status_flag": (i32, [vp, i32, i32, vp, vp]),
+    "gsx_front_pose_bwd_tail_words": (i64, []),
+    "gsx_front_pose_bwd_tail": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp,
+                                      vp, vp, vp, i64, f32, vp, vp]),
     "gsx_ssim_bwd_map_loss_rows": (i64, [i64, i32, i32]),
     "gsx_ssim_bwd_map_loss": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, f32, f32, i32, vp, vp, vp, vp, f32, vp,
                                     vp, i64, vp]),

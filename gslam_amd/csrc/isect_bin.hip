@@ -1251,6 +1251,9 @@ extern "C" int gsx_isect_bin_sort_tight(const float *means2d, const int32_t *rad
 // =====================================================================================================================
 #include "project_core.h"
 #include "pose_chain.h"
+#include "pose_math.h"
+#include "track_opt.h"
+#include "track_tail.h"
 
 // DIAGNOSTIC build only (-DGSX_WG_TRACE, tools/dbg/front_trace.sh): thread 0 of every workgroup of the two front kernels stamps
 // s_memrealtime (100 MHz) at its phase boundaries.  Nothing of this is compiled into the product library.
@@ -2102,12 +2105,21 @@ constexpr int FPB_THREADS = 256;
 // +0.4, 8: 10.2 / +0.8)
 constexpr int FPB_SPLIT = GSX_FPB_SPLIT;
 
+// TAIL (round 5; gsx_front_pose_bwd_tail, one camera): the closure's tail - the sum of the partial rows, PoseZhou backward, one
+// step of the tracking optimiser, the next view matrix (track_tail.h) - is run by the LAST workgroup of this launch to finish
+// instead of by a launch of its own (~5 us of dependent-launch latency per closure).  Who is last: a two-level ticket - workgroup
+// w arrives at counter w % 32, the last arrival of each counter at the top counter (one counter for all would serve ~500 atomics on
+// one address one after the other).  The rows travel by agent-scope stores, each followed by a fence, before the workgroup's ticket;
+// the last workgroup reads them with agent-scope loads.  The counters end the launch at zero.
+constexpr int FPB_TICKETS = 32;
+template <bool TAIL>
 __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
     const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ viewmats, const float *__restrict__ Ks, int64_t N, int C, int W, int H, float eps2d,
     float near_p, float far_p, int flags, const float *__restrict__ v_rec, const PreRec *__restrict__ recs,
     const int32_t *__restrict__ n_inst, int R, int seg_cap, float *__restrict__ partials /*[R][C][12]*/, int compact,
-    const CandRec *__restrict__ cand, const float *__restrict__ cand_hdr) {
+    const CandRec *__restrict__ cand, const float *__restrict__ cand_hdr, TrackOptState *state, ToTailArgs tail,
+    unsigned int *__restrict__ tickets /*[FPB_TICKETS + 1], zero between launches*/) {
     __shared__ float s_part[FPB_THREADS / 64][12];
     // candidate mode of THIS closure (left by its projection): the instance records name candidate records, not flatten ids
     const bool use_cand = cand != nullptr && cand_hdr[CAND_MAX_CAMS * 12 + 4] > 0.5f;
@@ -2162,7 +2174,40 @@ __global__ __launch_bounds__(FPB_THREADS) void front_pose_bwd_kernel(
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < FPB_THREADS / 64; ++w) sum += s_part[w][t];
-        partials[(((int64_t)row * FPB_SPLIT + blockIdx.z) * C + c) * 12 + t] = sum;
+        float *dst = partials + (((int64_t)row * FPB_SPLIT + blockIdx.z) * C + c) * 12 + t;
+        if constexpr (TAIL) {
+            // write-through store (agent scope) and a wait for its acknowledgement: the row is out before this workgroup's ticket is
+            // drawn.  NOT a release fence: that writes back and invalidates the whole L2 of the XCD (buffer_wbl2 / buffer_inv sc1) -
+            // once per workgroup, 490 times per launch, under the workgroups still at work (measured: 34 us for this launch)
+            __hip_atomic_store(dst, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            *dst = sum;
+        }
+    }
+    if constexpr (TAIL) {
+        __shared__ int s_last;
+        __shared__ __attribute__((aligned(16))) ToTailLds<FPB_THREADS> s_tail;
+        __syncthreads();
+        if (t == 0) {
+            const unsigned n_wgs = gridDim.x * gridDim.y * gridDim.z;
+            const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const unsigned grp = wg % FPB_TICKETS, n_grps = n_wgs < FPB_TICKETS ? n_wgs : (unsigned)FPB_TICKETS;
+            const unsigned grp_n = (n_wgs - grp + FPB_TICKETS - 1) / FPB_TICKETS;          // workgroups that arrive at this counter
+            int last = 0;
+            if (__hip_atomic_fetch_add(&tickets[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == grp_n - 1) {
+                __hip_atomic_store(&tickets[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_add(&tickets[FPB_TICKETS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_grps - 1) {
+                    __hip_atomic_store(&tickets[FPB_TICKETS], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = 1;
+                }
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (s_last) {                                         // (workgroup-uniform; the rows are read with agent-scope loads)
+            to_tail_body<FPB_THREADS, true>(state, tail, s_tail);
+        }
     }
 }
 
@@ -2419,10 +2464,11 @@ extern "C" int64_t gsx_front_rows(int64_t N, int64_t C, int tile_w, int tile_h) 
     return front_layout(N, C, tile_w, tile_h, 1).R * FPB_SPLIT;       // partial rows gsx_front_pose_bwd leaves
 }
 
-extern "C" int gsx_front_pose_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
-                                  const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
-                                  float far_plane, int flags, const float *v_rec, int64_t M_cap, const void *workspace,
-                                  int64_t workspace_bytes, float *partials, void *stream) {
+static int front_pose_bwd_impl(const float *means, const float *quats, const float *scales, const float *viewmats,
+                               const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                               float far_plane, int flags, const float *v_rec, int64_t M_cap, const void *workspace,
+                               int64_t workspace_bytes, float *partials, void *tail_state, const ToTailArgs *tail_args,
+                               unsigned int *tickets, void *stream) {
     GSX_CHECK_ARG(N >= 1 && C >= 1 && C <= 255 && W > 0 && H > 0 && M_cap >= 1);
     GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && v_rec && partials);
     const int tile_w = (W + GSX_TILE - 1) / GSX_TILE, tile_h = (H + GSX_TILE - 1) / GSX_TILE;
@@ -2438,14 +2484,55 @@ extern "C" int gsx_front_pose_bwd(const float *means, const float *quats, const 
         gsx_set_error("gsx_front_pose_bwd: GSX_PROJ_CANDIDATES needs the candidate area");
         return GSX_E_WORKSPACE;
     }
-    hipLaunchKernelGGL(front_pose_bwd_kernel, dim3((unsigned)L.R, (unsigned)C, FPB_SPLIT), dim3(FPB_THREADS), 0, (hipStream_t)stream,
-                       means, quats, scales, viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, flags, v_rec,
-                       (const PreRec *)(ws + L.recs_off), (const int32_t *)(ws + L.ninst_off), L.R,
-                       FRONT_THREADS * L.items, partials, (flags & GSX_PROJ_COMPACT) ? 1 : 0,
-                       cand_on ? (const CandRec *)(ws + L.cand_off) : (const CandRec *)nullptr,
-                       cand_on ? (const float *)(ws + L.cand_hdr_off) : (const float *)nullptr);
+    ToTailArgs none = {};
+    if (tail_state == nullptr) {
+        hipLaunchKernelGGL(front_pose_bwd_kernel<false>, dim3((unsigned)L.R, (unsigned)C, FPB_SPLIT), dim3(FPB_THREADS), 0,
+                           (hipStream_t)stream, means, quats, scales, viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane,
+                           flags, v_rec, (const PreRec *)(ws + L.recs_off), (const int32_t *)(ws + L.ninst_off), L.R,
+                           FRONT_THREADS * L.items, partials, (flags & GSX_PROJ_COMPACT) ? 1 : 0,
+                           cand_on ? (const CandRec *)(ws + L.cand_off) : (const CandRec *)nullptr,
+                           cand_on ? (const float *)(ws + L.cand_hdr_off) : (const float *)nullptr, (TrackOptState *)nullptr, none,
+                           (unsigned int *)nullptr);
+    } else {
+        ToTailArgs ta = *tail_args;
+        ta.partials = partials;
+        ta.n_blocks = L.R * FPB_SPLIT;
+        hipLaunchKernelGGL(front_pose_bwd_kernel<true>, dim3((unsigned)L.R, (unsigned)C, FPB_SPLIT), dim3(FPB_THREADS), 0,
+                           (hipStream_t)stream, means, quats, scales, viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane,
+                           flags, v_rec, (const PreRec *)(ws + L.recs_off), (const int32_t *)(ws + L.ninst_off), L.R,
+                           FRONT_THREADS * L.items, partials, (flags & GSX_PROJ_COMPACT) ? 1 : 0,
+                           cand_on ? (const CandRec *)(ws + L.cand_off) : (const CandRec *)nullptr,
+                           cand_on ? (const float *)(ws + L.cand_hdr_off) : (const float *)nullptr, (TrackOptState *)tail_state, ta,
+                           tickets);
+    }
     GSX_CHECK_LAUNCH();
     return GSX_OK;
+}
+
+extern "C" int gsx_front_pose_bwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                                  const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                                  float far_plane, int flags, const float *v_rec, int64_t M_cap, const void *workspace,
+                                  int64_t workspace_bytes, float *partials, void *stream) {
+    return front_pose_bwd_impl(means, quats, scales, viewmats, Ks, N, C, W, H, eps2d, near_plane, far_plane, flags, v_rec, M_cap,
+                               workspace, workspace_bytes, partials, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int64_t gsx_front_pose_bwd_tail_words(void) { return FPB_TICKETS + 1; }
+
+// gsx_front_pose_bwd followed by gsx_track_opt_tail (one camera, loss rows given) as ONE launch: see front_pose_bwd_kernel<true>
+extern "C" int gsx_front_pose_bwd_tail(const float *means, const float *quats, const float *scales, const float *viewmats,
+                                       const float *Ks, int64_t N, int W, int H, float eps2d, float near_plane, float far_plane,
+                                       int flags, const float *v_rec, int64_t M_cap, const void *workspace, int64_t workspace_bytes,
+                                       float *partials, void *state, const float *Rt, float *dt, float *dR, float *exposure,
+                                       float *viewmat, const void *loss_rows, int64_t n_loss_rows, float loss_coef,
+                                       uint32_t *tickets, void *stream) {
+    GSX_CHECK_ARG(state && Rt && dt && dR && exposure && viewmat && loss_rows && tickets);
+    GSX_CHECK_ARG(n_loss_rows >= 1 && n_loss_rows < ((int64_t)1 << 31));
+    ToTailArgs ta = {};
+    ta.Rt = Rt; ta.dt = dt; ta.dR = dR; ta.exposure = exposure; ta.v_exposure = nullptr; ta.loss = nullptr; ta.viewmat = viewmat;
+    ta.loss_rows = (const float *)loss_rows; ta.n_loss_rows = (int)n_loss_rows; ta.loss_coef = loss_coef;
+    return front_pose_bwd_impl(means, quats, scales, viewmats, Ks, N, 1, W, H, eps2d, near_plane, far_plane, flags, v_rec, M_cap,
+                               workspace, workspace_bytes, partials, state, &ta, tickets, stream);
 }
 
 // out4 = { rows R, slots per (camera, row) segment, byte offset of the instance records in the workspace, byte offset of the

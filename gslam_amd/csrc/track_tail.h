@@ -56,23 +56,42 @@ __device__ __forceinline__ void to_tail_body(TrackOptState *state, const ToTailA
     if (t >= 95 && t < 97) L.p[9 + t - 95] = a.exposure[t - 95];
     float c0 = 0.f, c1 = 0.f, c3 = 0.f, c4 = 0.f;
     if (a.loss_rows) {                                       // issued first: independent of the partial rows below
-        for (int i = t; i < a.n_loss_rows; i += THREADS) {
-            const float *row = a.loss_rows + (int64_t)i * 6;
-            c0 += ld(row); c1 += ld(row + 1); c3 += ld(row + 3); c4 += ld(row + 4);
+        // (written by an EARLIER launch in both callers - the rasteriser's tiles - so plain loads; eight rows per thread in
+        // flight at once: a 256-thread caller walks 1200 rows in one trip instead of five dependent ones)
+        for (int i0 = t; i0 < a.n_loss_rows; i0 += 8 * THREADS) {
+            float v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * THREADS;
+                const bool in = i < a.n_loss_rows;
+                const float *row = a.loss_rows + (int64_t)(in ? i : 0) * 6;
+                v[u][0] = in ? row[0] : 0.f; v[u][1] = in ? row[1] : 0.f; v[u][2] = in ? row[3] : 0.f; v[u][3] = in ? row[4] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { c0 += v[u][0]; c1 += v[u][1]; c3 += v[u][2]; c4 += v[u][3]; }
         }
     }
     {
         const int k = t % 12, r = t / 12;
         if (r < ROWS) {
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int b = r; b < a.n_blocks; b += 8 * ROWS) {             // always 8 loads in flight, the ragged end too
+            // loads in flight per thread: 8 (cached rows of an earlier launch) or 24 (COHERENT: every load goes to memory, ~2 us a
+            // round trip - 490 rows over 21 row-strided accumulators are ONE trip of 24 instead of three of 8)
+            constexpr int FLY = COHERENT ? 24 : 8;
+            float acc[FLY];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < FLY; ++u) acc[u] = 0.f;
+            for (int b = r; b < a.n_blocks; b += FLY * ROWS) {           // always FLY loads in flight, the ragged end too
+#pragma unroll
+                for (int u = 0; u < FLY; ++u) {
                     const int bb = b + u * ROWS;
                     acc[u] += bb < a.n_blocks ? ld(a.partials + (int64_t)bb * 12 + k) : 0.f;
                 }
             }
-            L.acc[r][k] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            float tot = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+            for (int u = 8; u < FLY; u += 8)
+                tot += ((acc[u] + acc[u + 1]) + (acc[u + 2] + acc[u + 3])) + ((acc[u + 4] + acc[u + 5]) + (acc[u + 6] + acc[u + 7]));
+            L.acc[r][k] = tot;
         }
     }
     if (a.loss_rows) {

@@ -750,14 +750,14 @@ class RenderPlan:
                                  _p(self.render), _p(self.alphas), _p(self.last_ids), _p(self.n_touched),
                                  _p(self.tile_order), st), "gsx_raster_fwd")
 
-    def backward(self, st: int, keep: bool = False, rasterised: bool = False):
+    def backward(self, st: int, keep: bool = False, rasterised: bool = False, tail=None):
         """from ``self.v_render`` (filled by the loss launch) to the pose partials in ``self.pose_ws`` and, for 'full', the
         six map gradients (overwritten, summed over cameras inside).  keep: leave the gradient records as accumulated
         (``as_output().means2d.grad`` reads them: densification) instead of zeroing each row once it has been consumed.
         rasterised: the gradient records are complete already (forward_track_fused ran the rasteriser's backward)"""
         if not rasterised:
             self.backward_raster(st)
-        self.backward_project(st, keep)
+        self.backward_project(st, keep, tail=tail)
 
     def backward_raster(self, st: int):
         """the rasteriser's half of ``backward``: d loss / d render -> the gradient records of the visible pairs"""
@@ -767,7 +767,7 @@ class RenderPlan:
                                  _p(self.last_ids), _p(self.v_render), None, _p(self.v_rec), None,
                                  _p(self.launch_order), 1 if self.geom_only else 0, st), "gsx_raster_bwd")
 
-    def backward_project(self, st: int, keep: bool = False, rows=None):
+    def backward_project(self, st: int, keep: bool = False, rows=None, tail=None):
         """the projection's half of ``backward``.  rows = (g_begin, g_end), 'full' plans only: those rows of the map alone
         (gsx_project_bwd_range; g_begin a multiple of 256, g_end a multiple of 256 or N) - calls over ranges that tile the map
         leave the six gradients and the pose partials as one call does"""
@@ -778,13 +778,22 @@ class RenderPlan:
         m = self.map
         vr = self.v_rec.data_ptr()
         if self.grads == 'pose' and self.front:
+            flags = self.flags | reset | (_COMPACT if self.compact else 0) | self._cand_flags()
+            if tail is not None:
+                # the closure's tail inside this launch (its last workgroup runs it): gsx_front_pose_bwd_tail
+                state, slots, exposure, loss_rows, n_rows, coef, tickets = tail
+                check(lib.gsx_front_pose_bwd_tail(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.W,
+                                                  self.H, self.eps2d, self.near, self.far, flags, vr, self.capacity,
+                                                  _p(self.isect_ws), self.isect_ws.numel(), _p(self.pose_ws), _p(state),
+                                                  _p(slots.Rt), _p(slots.dt), _p(slots.dR), _p(exposure), _p(self.viewmats),
+                                                  _p(loss_rows), n_rows, coef, _p(tickets), st), "gsx_front_pose_bwd_tail")
+                return
             check(lib.gsx_front_pose_bwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C,
-                                         self.W, self.H, self.eps2d, self.near, self.far,
-                                         self.flags | reset | (_COMPACT if self.compact else 0) | self._cand_flags(),
-                                         vr, self.capacity,
+                                         self.W, self.H, self.eps2d, self.near, self.far, flags, vr, self.capacity,
                                          _p(self.isect_ws), self.isect_ws.numel(), _p(self.pose_ws), st),
                   "gsx_front_pose_bwd")
             return
+        assert tail is None
         if self.grads == 'pose':
             outs = (None,) * 3 + (None,) + (None,) * 3
         else:
@@ -872,11 +881,19 @@ class TrackClosure:
     PoseZhou backward, loss finish, optimiser advance).  'host': stops at the gradients (``g_dt, g_dR, g_exposure``,
     ``loss``) for an optimiser on the host."""
 
+    # default of ``merge_tail``.  OFF: built, parity-green, measured SLOWER (prof_closure, 253 closures, same box): the pose backward
+    # with the tail inside 22.9-23.1 us against 10.6 + 10.0 us for the two launches.  With release / acquire fences around the ticket
+    # it was 34 us (every workgroup's fence writes back and invalidates its XCD's L2 under the workgroups still at work); without
+    # them - write-through stores, an acknowledged-store wait, relaxed tickets, agent-scope loads - the last workgroup still pays two
+    # dependent atomic round trips to memory and reads 490 rows past every cache: ~12 us for what a launch of its own does in 10
+    # including its launch.
+    MERGE_TAIL = False
     CAND_MARGINS = (0.02, 0.02)    # |R R0^T - I|_F (~0.8 degrees) and metres the closures of a frame may move from its first pose
 
     def __init__(self, splats, camera, tail: str = 'fused', fuse_raster: bool = True, front: Optional[bool] = None,
                  candidates: bool = False, defer_sort: Optional[bool] = None, map_records: Optional[bool] = None,
-                 near_place: Optional[bool] = None, row_keys: Optional[bool] = None, tile_exact: Optional[bool] = None):
+                 near_place: Optional[bool] = None, row_keys: Optional[bool] = None, tile_exact: Optional[bool] = None,
+                 merge_tail: Optional[bool] = None):
         """near_place: the front leaves the keys behind a tile's depth cut-off out of the placement (RenderPlan.enable_near_placement).
         OFF by default - built, exact and measured in round 5: with 31 % of the keys written the placement launch is
         as long as before (26.5 against 25.1 us: it is a chain of latencies, not of stores), the projection pays 1.5 us for the
@@ -920,6 +937,10 @@ class TrackClosure:
         self.n_rows = (self.r.H * self.r.W + 255) // 256
         # fused tail: the loss is evaluated in the forward rasteriser's epilogue, one row of partials per tile
         self.loss_rows = torch.zeros(self.r.T, 6, device=dev)
+        # merge_tail: the closure's tail is run by the last workgroup of the pose backward launch (gsx_front_pose_bwd_tail); None =
+        # where it applies (fused tail + fused rasteriser + fused front); False keeps gsx_track_opt_tail as its own launch
+        self.merge_tail = bool(self.MERGE_TAIL if merge_tail is None else merge_tail) and self.fuse_raster and bool(self.r.front)
+        self.tail_tickets = torch.zeros(int(lib.gsx_front_pose_bwd_tail_words()), dtype=torch.int32, device=dev)
         if tail == 'fused':
             self.r.enable_balance()       # the fused forward leaves the tiles' work counters: CU-balanced launch order
         # the 36 closures of a frame re-project the same map for poses that differ by fractions of a pixel: the map is culled
@@ -1005,6 +1026,12 @@ class TrackClosure:
         r = self.r
         if self.tail == 'fused':
             denom = r.C * r.H * r.W
+            if self.fuse_raster and self.merge_tail:
+                # the tail runs inside the pose backward launch (its last workgroup): three launches per closure
+                r.forward_track_fused(st, (self.img, self.exposure, 1.0 / denom, self.loss_rows))
+                r.backward(st, rasterised=True, tail=(self.state, self.slots, self.exposure, self.loss_rows, r.T, 1.0 / denom,
+                                                      self.tail_tickets))
+                return
             if self.fuse_raster:
                 r.forward_track_fused(st, (self.img, self.exposure, 1.0 / denom, self.loss_rows))
                 r.backward(st, rasterised=True)

@@ -246,6 +246,17 @@ int gsx_front_pose_bwd(const float *means, const float *quats, const float *scal
                        const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
                        float far_plane, int flags, const float *v_rec, int64_t M_cap, const void *workspace,
                        int64_t workspace_bytes, float *partials, void *stream);
+/* gsx_front_pose_bwd followed by gsx_track_opt_tail(loss_rows given) as ONE launch (round 5; one camera): the closure's tail - sum
+ * of the partial rows, PoseZhou backward, one step of the tracking optimiser on (dt, dR, exposure), the next view matrix - is run
+ * by the LAST workgroup of the pose backward to finish (two-level ticket in `tickets`: gsx_front_pose_bwd_tail_words() uint32,
+ * zero before the first launch, left at zero by every launch).  Same arguments as the two calls; `partials` still receives the
+ * rows.  gslam/frontend.py:621-658. */
+int64_t gsx_front_pose_bwd_tail_words(void);
+int gsx_front_pose_bwd_tail(const float *means, const float *quats, const float *scales, const float *viewmats, const float *Ks,
+                            int64_t N, int W, int H, float eps2d, float near_plane, float far_plane, int flags,
+                            const float *v_rec, int64_t M_cap, const void *workspace, int64_t workspace_bytes, float *partials,
+                            void *state, const float *Rt, float *dt, float *dR, float *exposure, float *viewmat,
+                            const void *loss_rows, int64_t n_loss_rows, float loss_coef, uint32_t *tickets, void *stream);
 
 /* ---- K8: gsplat(fork) rasterize_to_pixels fwd (gslam/rasterization.py:325-339; fork: + n_touched) ----------------
  * rec: splat records [C*N, gsx_record_stride(CH)].  render [C,H,W,CH], alphas [C,H,W], last_ids [C,H,W] (global

@@ -1214,3 +1214,48 @@ def test_ssim_backward_and_loss_block_in_one_launch_equal_the_two_launches(dev, 
     assert float((a[3] - b[3]).abs().max()) <= 1e-5 * float(a[3].abs().max()) + 1e-12
     for k in a[4]:
         assert float((a[4][k] - b[4][k]).abs().max()) < 2e-4 * float(a[4][k].abs().max()) + 1e-10, k
+
+
+def test_closure_tail_inside_the_pose_backward_launch_equals_the_tail_launch(dev):
+    """gsx_front_pose_bwd_tail (round 5): the closure's tail run by the last workgroup of the pose backward launch, against
+    gsx_front_pose_bwd + gsx_track_opt_tail.  One closure from the same state: loss, pose gradient (the optimiser's g), the new
+    parameters and the next view matrix agree to the rounding of a different summation tree over the partial rows; the ticket
+    counters are back at zero; 30 captured closures (Adam warm-up + line search): same end point to the tolerance of the other
+    closure tests; the state machine's counters equal."""
+    from gslam_amd.plan import TrackClosure, current_stream_ptr
+    splats, _ = _track_closure(dev, 150000, 3, candidates=False)
+    from gslam_amd.primitives import Camera
+    from gslam_amd.synthetic import make_intrinsics, make_viewmat
+    W, H = 640, 480
+    cam = Camera(make_intrinsics(W, H).to(dev), H, W)
+    img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(8)).to(dev)
+    V0 = make_viewmat(2.0).to(dev)
+    a = TrackClosure(splats, cam, merge_tail=False)
+    b = TrackClosure(splats, cam, merge_tail=True)
+    assert b.merge_tail and not a.merge_tail and b.r.row_keys
+    st = current_stream_ptr(dev)
+    out = []
+    for c in (a, b):
+        c.load(V0, img, torch.tensor([0.02, -0.01], device=dev))
+        c.prepare()
+        c.load(V0, img, torch.tensor([0.02, -0.01], device=dev))
+        c.init_optimizer(4, 1e-3, 5, 25)
+        c.enqueue(st)
+        torch.cuda.synchronize()
+        out.append((c.read_report().cpu().clone(), c.r.viewmats.clone(), c.slots.dt.clone(), c.slots.dR.clone(), c.exposure.clone()))
+    ra, rb = out[0][0], out[1][0]
+    assert abs(float(ra[4]) - float(rb[4])) <= 1e-5 * abs(float(ra[4])), (ra, rb)          # the closure's loss
+    assert torch.equal(ra[:4], rb[:4]) and float(ra[7]) == float(rb[7])                        # phase, evaluations, iterations, Adam step
+    for k in (1, 2, 3, 4):
+        d = float((out[0][k] - out[1][k]).abs().max())
+        assert d <= 1e-5 * float(out[0][k].abs().max()) + 1e-7, (k, d)
+    assert int(b.tail_tickets.abs().sum()) == 0
+    for c in (a, b):
+        c.load(V0, img, torch.tensor([0.02, -0.01], device=dev))
+        c.init_optimizer(4, 1e-3, 5, 25)
+        c.launch(30)
+    torch.cuda.synchronize()
+    assert a.r.check_capacity() and b.r.check_capacity() and int(b.tail_tickets.abs().sum()) == 0
+    ra, rb = a.read_report().cpu(), b.read_report().cpu()
+    assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
+    assert float((a.r.viewmats - b.r.viewmats).abs().max()) < 5e-3

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--no-defer-sort", action="store_true", help="stand-alone tile sort launch (A/B)")
     ap.add_argument("--no-row-keys", action="store_true", help="count matrix scan + placement launch instead of row keys (A/B)")
     ap.add_argument("--no-tile-exact", action="store_true", help="every tile of the 3-sigma square listed (A/B of GSX_PROJ_TILE_EXACT)")
+    ap.add_argument("--merge-tail", action="store_true", help="the closure's tail inside the pose backward launch (A/B; off by default)")
     ap.add_argument("--no-near", action="store_true", help="every key placed (round-4 placement), sort inside the rasteriser (A/B)")
     ap.add_argument("--near-margin", type=float, default=None, help="RenderPlan.NEAR_MARGIN of the near placement (A/B)")
     args = ap.parse_args()
@@ -51,6 +52,9 @@ def main():
     if args.no_tile_exact:
         import gslam_amd.plan as P10
         P10.RenderPlan.enable_tile_exact = lambda self, on=True: False
+    if args.merge_tail:
+        import gslam_amd.plan as P11
+        P11.TrackClosure.MERGE_TAIL = True
     if args.near_margin is not None:
         import gslam_amd.plan as P6
         P6.RenderPlan.NEAR_MARGIN = args.near_margin
