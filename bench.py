@@ -348,6 +348,7 @@ def run_headline(args, dev):
     plan = ba.plan(keyframes)
     # the frame's output render (frontend.py:228-231): forward only, RGB + depth
     out_render = RenderPlan(frontend_map, 1, W, H, render_depth=True, grads='none', Ks=cam.intrinsics)
+    out_render.enable_tight_lists(RenderPlan.TIGHT_LISTS)     # (forward only; its lists are read by its own rasteriser alone)
     out_graph = HipGraph()
     out_stream = torch.cuda.Stream()
 
@@ -683,6 +684,7 @@ def run_full_cycle(dev, N, W, H, steps=60, warmup=10):
             state["map"] = new_map
             state["tracker"] = GraphedTracker(new_map, cam, conf, device_optimizer=True, max_eval=MAX_EVAL)
             r = RenderPlan(new_map, 1, W, H, render_depth=True, grads='none', Ks=cam.intrinsics)
+            r.enable_tight_lists(RenderPlan.TIGHT_LISTS)
             state["out"] = (r, HipGraph(), False)
             state["recaptures"] += 1
 

@@ -23,6 +23,8 @@ PROTOTYPES = {
     "gsx_read_i64": (i32, [vp, C.POINTER(i64), vp]),
     "gsx_project_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp,
                               i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "gsx_project_fwd_rects": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp,
+                              i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gsx_project_bwd_workspace_bytes": (i64, [i64, i64]),
     "gsx_project_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, f32, f32, i32, vp, vp, i64, vp, vp, i64, vp,
                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
@@ -38,7 +40,7 @@ PROTOTYPES = {
     "gsx_isect_bin_workspace_bytes": (i64, [i64, i32, i32, i64]),
     "gsx_isect_bin_workspace_bytes_n": (i64, [i64, i64, i32, i32, i64]),
     "gsx_isect_bin_sort": (i32, [vp, vp, vp, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
-    "gsx_isect_bin_sort_tight": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "gsx_isect_bin_sort_rects": (i32, [vp, vp, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "gsx_raster_fwd": (i32, [vp, i32, vp, vp, vp, i64, i32, i64, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
     "gsx_raster_bwd": (i32, [vp, i32, vp, vp, vp, i64, i32, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "gsx_sh_fwd": (i32, [i32, vp, vp, vp, i64, i64, i32, vp, vp]),

@@ -49,7 +49,7 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 def _compile(src: str, extra: list[str], force: bool) -> str:
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    deps = [os.path.join(HERE, src), os.path.join(HERE, "gsx_common.h"), os.path.join(HERE, "raster_v4.inc"), os.path.join(HERE, "raster_fwd_state.inc"), os.path.join(HERE, "raster_fwd_chunks.inc"), os.path.join(HERE, "raster_fwd_finish.inc"), os.path.join(HERE, "tile_sort_lds.h"), os.path.join(HERE, "raster_bwd_loop.inc"), os.path.join(HERE, "raster_bwd_loop_tc.inc"), os.path.join(HERE, "track_opt.h"), os.path.join(HERE, "track_opt_impl.inc"), os.path.join(HERE, "track_tail.h"), os.path.join(HERE, "pose_chain.h"), os.path.join(HERE, "loss_pixel.h"), os.path.join(HERE, "pose_math.h"), os.path.join(HERE, "project_core.h"), os.path.join(HERE, "tile_balance.h"),
+    deps = [os.path.join(HERE, src), os.path.join(HERE, "gsx_common.h"), os.path.join(HERE, "raster_v4.inc"), os.path.join(HERE, "raster_fwd_state.inc"), os.path.join(HERE, "raster_fwd_chunks.inc"), os.path.join(HERE, "raster_fwd_finish.inc"), os.path.join(HERE, "tile_sort_lds.h"), os.path.join(HERE, "raster_bwd_loop.inc"), os.path.join(HERE, "raster_bwd_loop_tc.inc"), os.path.join(HERE, "track_opt.h"), os.path.join(HERE, "track_opt_impl.inc"), os.path.join(HERE, "track_tail.h"), os.path.join(HERE, "pose_chain.h"), os.path.join(HERE, "loss_pixel.h"), os.path.join(HERE, "tile_rect.h"), os.path.join(HERE, "pose_math.h"), os.path.join(HERE, "project_core.h"), os.path.join(HERE, "tile_balance.h"),
             os.path.join(PKG, "..", "include", "gsx.h"), os.path.abspath(__file__)]
     if force or _stale(obj, deps):
         cmd = ["hipcc", "-c", os.path.join(HERE, src), "-o", obj] + COMMON + extra

@@ -28,8 +28,11 @@
 
 #include "gsx_common.h"
 #include "tile_balance.h"
+#include "tile_rect.h"
 
 namespace {
+
+using namespace gsx_rect;
 
 #ifndef GSX_FAST_CULL
 #define GSX_FAST_CULL 1
@@ -39,75 +42,16 @@ constexpr int BIN_ITEMS = 4;          // Gaussians per thread of the coarse pre-
 constexpr int SORT_THREADS = 512;
 constexpr int COOP_AREA = 16;         // rectangles with more tiles than this are walked by the whole wavefront
 
-__device__ __forceinline__ uint32_t sat_u32(float f) {
-    if (!(f > 0.0f)) return 0u;
-    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
-    return (uint32_t)f;
-}
-
-struct Rect {
-    int x0, y0, x1, y1;
-};
-
-
-__device__ __forceinline__ Rect tile_rect(float mx, float my, int32_t radius, int tile_w, int tile_h) {
-    const float ts = (float)GSX_TILE;
-    const float tr = (float)radius / ts, tx = mx / ts, ty = my / ts;
-    Rect r;
-    r.x0 = (int)min(sat_u32(floorf(tx - tr)), (uint32_t)tile_w);
-    r.y0 = (int)min(sat_u32(floorf(ty - tr)), (uint32_t)tile_h);
-    r.x1 = (int)min(sat_u32(ceilf(tx + tr)), (uint32_t)tile_w);
-    r.y1 = (int)min(sat_u32(ceilf(ty + tr)), (uint32_t)tile_h);
-    return r;
-}
-
-// ---- tight rectangle (GSX_PROJ_TILE_EXACT; the fused front of pose-only closures) --------------------------------------------------
-// The reference lists an instance in every tile of the square around its 3-sigma radius (gsplat isect_tiles through
-// gslam/rasterization.py:259-272) and its rasteriser then skips the instance at every pixel whose alpha = opacity exp(-sigma) stays
-// below 1/255.  sigma(d) = 0.5 (a dx^2 + c dy^2) + b dx dy <= L = ln(255 opacity) is an ellipse whose axis-aligned bounding box has
-// the half extents sqrt(2 L c / det), sqrt(2 L a / det): a tile none of whose pixel CENTRES lies in that box changes nothing in any
-// output of the render or its backward.  The square shrinks to its intersection with the box (never grows): on the headline's map
-// 28 % of the (instance, tile) pairs go - the minor-axis side of anisotropic splats, the rim of translucent ones, and whole
-// instances whose opacity is below 1/255.  Margins (1 % + 0.02 on L, 0.1 % + 0.01 px on the extents) cover the rounding of the
-// rasteriser's own evaluation.  (A per-tile test on top - is the quadratic's minimum over the tile below L? - drops 34 %, but costs
-// the projection more than the rasteriser gains: tools/experiments/r05_exact_tile_masks.patch)
-__device__ __forceinline__ Rect tighten_rect(Rect r, float mx, float my, float a, float b, float c, float opac) {
-    const float l = __logf(255.0f * opac);
-    const float two_l = 2.0f * (l + 0.01f * fabsf(l) + 0.02f);
-    const float det = a * c - b * b;
-    if (!(det > 0.0f) || !(two_l == two_l)) return r;          // degenerate conic / NaN opacity: the reference's square
-    if (two_l <= 0.0f) { r.x1 = r.x0; r.y1 = r.y0; return r; } // never reaches 1/255 anywhere
-    const float k = two_l / det;
-    const float ex = sqrtf(k * c) * 1.001f + 0.01f, ey = sqrtf(k * a) * 1.001f + 0.01f;
-    if (!(ex == ex) || !(ey == ey)) return r;
-    const float ts = (float)GSX_TILE, inv = 1.0f / (float)GSX_TILE;
-    // tile t holds the centres t * ts + 0.5 .. t * ts + ts - 0.5
-    const float fx0 = ceilf((mx - ex - (ts - 0.5f)) * inv), fx1 = floorf((mx + ex - 0.5f) * inv) + 1.0f;
-    const float fy0 = ceilf((my - ey - (ts - 0.5f)) * inv), fy1 = floorf((my + ey - 0.5f) * inv) + 1.0f;
-    r.x0 = max(r.x0, (int)fmaxf(fx0, -1.0e6f)); r.x1 = min(r.x1, (int)fminf(fx1, 1.0e6f));
-    r.y0 = max(r.y0, (int)fmaxf(fy0, -1.0e6f)); r.y1 = min(r.y1, (int)fminf(fy1, 1.0e6f));
-    if (r.x1 < r.x0) r.x1 = r.x0;
-    if (r.y1 < r.y0) r.y1 = r.y0;
-    return r;
-}
-
-// trec (nullable): the splat records [C * N][12] (xy, conic, opacity, ...) of the same projection - the rectangle is tightened
-// to the instance's alpha >= 1/255 box (tighten_rect; gsx_isect_bin_sort_tight)
+// rects (nullable): the rectangle of every (camera, Gaussian) packed by the projection (gsx_project_fwd_rects, tile_rect.h) - read
+// INSTEAD of means2d + radius (4 bytes for 12), and tight if the projection was asked for that (gsx_isect_bin_sort_rects)
 __device__ __forceinline__ Rect load_rect(const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                                           int64_t idx, int tile_w, int tile_h, bool in_range,
-                                          const float *__restrict__ trec = nullptr) {
+                                          const uint32_t *__restrict__ rects = nullptr) {
     Rect r = {0, 0, 0, 0};
     if (in_range) {
+        if (rects) return unpack_rect(rects[idx]);
         const int32_t rad = radii[idx];
-        if (rad > 0) {
-            if (trec) {
-                const float4 *q = reinterpret_cast<const float4 *>(trec + idx * 12);
-                const float4 q0 = q[0], q1 = q[1];
-                r = tighten_rect(tile_rect(q0.x, q0.y, rad, tile_w, tile_h), q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-            } else {
-                r = tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rad, tile_w, tile_h);
-            }
-        }
+        if (rad > 0) r = tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rad, tile_w, tile_h);
     }
     return r;
 }
@@ -189,7 +133,7 @@ __global__ __launch_bounds__(BIN_THREADS) void count_matrix_kernel(const float *
                                                                    const int32_t *__restrict__ radii, int64_t N,
                                                                    int tile_w, int tile_h, int items,
                                                                    int32_t *__restrict__ cnt /*[C][gblocks][n_tiles]*/,
-    const float *__restrict__ trec /* nullable: records for tight rectangles */) {
+    const uint32_t *__restrict__ trec /* nullable: packed rectangles of the projection */) {
     extern __shared__ int s_cnt[];  // [n_tiles]
     const int c = blockIdx.y;
     const int n_tiles = tile_w * tile_h;
@@ -338,7 +282,7 @@ __global__ __launch_bounds__(BIN_THREADS) void place_kernel(const float *__restr
                                                             const int32_t *__restrict__ offsets,
                                                             const int32_t *__restrict__ cnt,
                                                             unsigned long long *__restrict__ entries,
-    const float *__restrict__ trec /* nullable: records for tight rectangles */) {
+    const uint32_t *__restrict__ trec /* nullable: packed rectangles of the projection */) {
     extern __shared__ int s_cur[];  // [n_tiles]: this workgroup's absolute write cursor per tile
     const int c = blockIdx.y;
     const int n_tiles = tile_w * tile_h;
@@ -376,7 +320,7 @@ __global__ __launch_bounds__(BIN_THREADS) void coarse_count_kernel(const float *
                                                                    const int32_t *__restrict__ radii, int64_t N,
                                                                    int tile_w, int tile_h, int items, int sw, int S,
                                                                    int32_t *__restrict__ cnt /*[C][gblocks][S]*/,
-    const float *__restrict__ trec /* nullable: records for tight rectangles */) {
+    const uint32_t *__restrict__ trec /* nullable: packed rectangles of the projection */) {
     extern __shared__ int s_cnt[];  // [S]
     const int c = blockIdx.y;
     for (int i = threadIdx.x; i < S; i += BIN_THREADS) s_cnt[i] = 0;
@@ -398,7 +342,7 @@ __global__ __launch_bounds__(BIN_THREADS) void coarse_place_kernel(const float *
                                                                    int64_t rec_cap, const int32_t *__restrict__ coff,
                                                                    const int32_t *__restrict__ cnt,
                                                                    PreRec *__restrict__ recs,
-    const float *__restrict__ trec /* nullable: records for tight rectangles */) {
+    const uint32_t *__restrict__ trec /* nullable: packed rectangles of the projection */) {
     extern __shared__ int s_cur[];  // [S]
     const int c = blockIdx.y;
     const int32_t *row = cnt + ((int64_t)c * gridDim.x + blockIdx.x) * S;
@@ -1080,7 +1024,7 @@ extern "C" int64_t gsx_isect_bin_workspace_bytes_n(int64_t C, int64_t N, int til
     return bin_layout(C, tile_w, tile_h, M_cap).total + (C > 0 && N > 0 ? C * N * 16 : 0) + 256;
 }
 
-static int isect_bin_sort_impl(const float *means2d, const int32_t *radii, const float *depths, const float *trec, int64_t N,
+static int isect_bin_sort_impl(const float *means2d, const int32_t *radii, const float *depths, const uint32_t *trec, int64_t N,
                                int64_t C, int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev,
                                int32_t *status, int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_order,
                                void *workspace, int64_t workspace_bytes, void *stream) {
@@ -1216,16 +1160,17 @@ extern "C" int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, co
                                flatten_ids, tile_order, workspace, workspace_bytes, stream);
 }
 
-// The same with TIGHT rectangles: rec = the splat records [C * N][12] the projection wrote for the same render (gsx_project_fwd:
-// xy, conic, opacity, ...); an instance is listed only in the tiles of its 3-sigma square that hold a pixel centre inside the box
-// of its alpha >= 1/255 ellipse (tighten_rect above).  For renders whose tile lists nobody but the rasteriser reads.
-extern "C" int gsx_isect_bin_sort_tight(const float *means2d, const int32_t *radii, const float *depths, const float *rec,
-                                        int64_t N, int64_t C, int tile_w, int tile_h, int64_t M_cap, int32_t *offsets,
-                                        int64_t *M_dev, int32_t *status, int64_t *isect_ids, int32_t *flatten_ids,
-                                        int32_t *tile_order, void *workspace, int64_t workspace_bytes, void *stream) {
-    GSX_CHECK_ARG(rec != nullptr && (((uintptr_t)rec) & 15) == 0);
-    return isect_bin_sort_impl(means2d, radii, depths, rec, N, C, tile_w, tile_h, M_cap, offsets, M_dev, status, isect_ids,
-                               flatten_ids, tile_order, workspace, workspace_bytes, stream);
+// The same over rectangles the PROJECTION prepared: rects = uint32 [C * N] packed by gsx_project_fwd_rects (tile_rect.h) - the
+// reference's squares, or tight ones (an instance listed only in the tiles of its 3-sigma square that hold a pixel centre inside
+// the box of its alpha >= 1/255 ellipse) if the projection ran with GSX_PROJ_TILE_EXACT.  means2d / radii are not read.
+extern "C" int gsx_isect_bin_sort_rects(const uint32_t *rects, const float *depths, int64_t N, int64_t C, int tile_w, int tile_h,
+                                        int64_t M_cap, int32_t *offsets, int64_t *M_dev, int32_t *status, int64_t *isect_ids,
+                                        int32_t *flatten_ids, int32_t *tile_order, void *workspace, int64_t workspace_bytes,
+                                        void *stream) {
+    GSX_CHECK_ARG(rects != nullptr && depths != nullptr && tile_w < 256 && tile_h < 256);
+    // (means2d / radii only pass the argument check of the shared body)
+    return isect_bin_sort_impl((const float *)rects, (const int32_t *)rects, depths, rects, N, C, tile_w, tile_h, M_cap, offsets,
+                               M_dev, status, isect_ids, flatten_ids, tile_order, workspace, workspace_bytes, stream);
 }
 
 // =====================================================================================================================

@@ -12,6 +12,7 @@
 // written per (camera, Gaussian).
 #include "gsx_common.h"
 #include "project_core.h"
+#include "tile_rect.h"
 
 namespace {
 
@@ -44,7 +45,8 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     float *__restrict__ means2d, float *__restrict__ depths, float *__restrict__ conics, float *__restrict__ comps,
     int32_t *__restrict__ tiles_per_gauss, int tile_w, int tile_h, const float *__restrict__ logit_opacities,
     const float *__restrict__ logit_colors, const float *__restrict__ log_unc, float *__restrict__ rec,
-    int32_t *__restrict__ vis_count, float *__restrict__ v_rec_clear) {
+    int32_t *__restrict__ vis_count, float *__restrict__ v_rec_clear,
+    uint32_t *__restrict__ rects /* nullable (RS > 0): packed tile rectangle per (camera, Gaussian) for gsx_isect_bin_sort_rects */) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     int n_vis = 0;
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         depths[idx] = depth;
         if (conics) { conics[3 * idx] = con0; conics[3 * idx + 1] = con1; conics[3 * idx + 2] = con2; }
         if (comps) comps[idx] = comp;
-        if (tiles_per_gauss) tiles_per_gauss[idx] = radius_i > 0 ? tile_count(mx, my, radius_i, tile_w, tile_h) : 0;
+        if (tiles_per_gauss && !(RS > 0 && rects))
+            tiles_per_gauss[idx] = radius_i > 0 ? tile_count(mx, my, radius_i, tile_w, tile_h) : 0;
         if (RS > 0) {
             float *r = rec + idx * RS;
             float ch[6] = {col[0], col[1], col[2], 0.f, 0.f, 0.f};
@@ -115,6 +118,17 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             if (v_rec_clear) {                               // the backward's accumulation rows, cleared while we are here
                 float4 *z = reinterpret_cast<float4 *>(v_rec_clear + idx * RS);
                 z[0] = z[1] = z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (rects) {
+                gsx_rect::Rect tr = {0, 0, 0, 0};
+                if (vis) {
+                    tr = gsx_rect::tile_rect(mx, my, radius_i, tile_w, tile_h);
+                    if (flags & GSX_PROJ_TILE_EXACT) tr = gsx_rect::tighten_rect(tr, mx, my, con0, con1, con2, opac);
+                }
+                rects[idx] = gsx_rect::pack_rect(tr);
+                // (with packed rectangles the count is that of the rectangle the binning will walk: what a capacity probe sums)
+                if (tiles_per_gauss)
+                    tiles_per_gauss[idx] = (tr.x1 > tr.x0 && tr.y1 > tr.y0) ? (tr.y1 - tr.y0) * (tr.x1 - tr.x0) : 0;
             }
         }
     }
@@ -421,14 +435,15 @@ extern "C" int gsx_record_stride(int CH) {
     return GSX_E_UNSUPPORTED;
 }
 
-extern "C" int gsx_project_fwd(const float *means, const float *quats, const float *scales, const float *viewmats,
-                               const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
-                               float far_plane, float radius_clip, int flags, int32_t *radii, float *means2d,
-                               float *depths, float *conics, float *comps, int32_t *tiles_per_gauss, int tile_w,
-                               int tile_h, const float *logit_opacities, const float *logit_colors,
-                               const float *log_uncertainties, float *rec, int32_t *vis_count, float *v_rec_clear,
-                               void *stream) {
+static int project_fwd_impl(const float *means, const float *quats, const float *scales, const float *viewmats,
+                            const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                            float far_plane, float radius_clip, int flags, int32_t *radii, float *means2d,
+                            float *depths, float *conics, float *comps, int32_t *tiles_per_gauss, int tile_w,
+                            int tile_h, const float *logit_opacities, const float *logit_colors,
+                            const float *log_uncertainties, float *rec, int32_t *vis_count, float *v_rec_clear,
+                            uint32_t *rects, void *stream) {
     GSX_CHECK_ARG(N >= 0 && C >= 1 && W > 0 && H > 0);
+    if (rects) GSX_CHECK_ARG(rec && tile_w > 0 && tile_h > 0 && tile_w < 256 && tile_h < 256);
     GSX_CHECK_ARG(!v_rec_clear || rec);
     GSX_CHECK_ARG(means && quats && scales && viewmats && Ks && radii && means2d && depths);
     GSX_CHECK_ARG(conics || rec);                             // the conic is in the record as well (columns 2..4)
@@ -445,14 +460,41 @@ extern "C" int gsx_project_fwd(const float *means, const float *quats, const flo
         hipLaunchKernelGGL((project_fwd_kernel<12>), dim3(blocks), dim3(threads), 0, st, means, quats, scales,
                            viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, radius_clip, flags, radii,
                            means2d, depths, conics, comps, tiles_per_gauss, tile_w, tile_h, logit_opacities,
-                           logit_colors, log_uncertainties, rec, vis_count, v_rec_clear);
+                           logit_colors, log_uncertainties, rec, vis_count, v_rec_clear, rects);
     else
         hipLaunchKernelGGL((project_fwd_kernel<0>), dim3(blocks), dim3(threads), 0, st, means, quats, scales,
                            viewmats, Ks, N, (int)C, W, H, eps2d, near_plane, far_plane, radius_clip, flags, radii,
                            means2d, depths, conics, comps, tiles_per_gauss, tile_w, tile_h, logit_opacities,
-                           logit_colors, log_uncertainties, rec, vis_count, v_rec_clear);
+                           logit_colors, log_uncertainties, rec, vis_count, v_rec_clear, rects);
     GSX_CHECK_LAUNCH();
     return GSX_OK;
+}
+
+extern "C" int gsx_project_fwd(const float *means, const float *quats, const float *scales, const float *viewmats,
+                               const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                               float far_plane, float radius_clip, int flags, int32_t *radii, float *means2d,
+                               float *depths, float *conics, float *comps, int32_t *tiles_per_gauss, int tile_w,
+                               int tile_h, const float *logit_opacities, const float *logit_colors,
+                               const float *log_uncertainties, float *rec, int32_t *vis_count, float *v_rec_clear,
+                               void *stream) {
+    return project_fwd_impl(means, quats, scales, viewmats, Ks, N, C, W, H, eps2d, near_plane, far_plane, radius_clip, flags, radii,
+                            means2d, depths, conics, comps, tiles_per_gauss, tile_w, tile_h, logit_opacities, logit_colors,
+                            log_uncertainties, rec, vis_count, v_rec_clear, nullptr, stream);
+}
+
+// gsx_project_fwd that also packs, per (camera, Gaussian), the rectangle of tiles the instance is listed in (tile_rect.h: one
+// uint32; the reference's 3-sigma square, or - flags & GSX_PROJ_TILE_EXACT - the tight one) for gsx_isect_bin_sort_rects
+extern "C" int gsx_project_fwd_rects(const float *means, const float *quats, const float *scales, const float *viewmats,
+                                     const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                                     float far_plane, float radius_clip, int flags, int32_t *radii, float *means2d,
+                                     float *depths, float *conics, float *comps, int32_t *tiles_per_gauss, int tile_w,
+                                     int tile_h, const float *logit_opacities, const float *logit_colors,
+                                     const float *log_uncertainties, float *rec, int32_t *vis_count, float *v_rec_clear,
+                                     uint32_t *rects, void *stream) {
+    GSX_CHECK_ARG(rects != nullptr);
+    return project_fwd_impl(means, quats, scales, viewmats, Ks, N, C, W, H, eps2d, near_plane, far_plane, radius_clip, flags, radii,
+                            means2d, depths, conics, comps, tiles_per_gauss, tile_w, tile_h, logit_opacities, logit_colors,
+                            log_uncertainties, rec, vis_count, v_rec_clear, rects, stream);
 }
 
 extern "C" int64_t gsx_project_bwd_blocks(int64_t N) { return (N + PBWD_THREADS - 1) / PBWD_THREADS; }

@@ -214,12 +214,15 @@ class RenderPlan:
 
     GROW = 1.5
     ORDER_MAX_PER_TILE = 1000       # heaviest-first launch order (by list length) below this capacity per tile
-    # MappingStep / WindowClosure on the generic chain: tight rectangles in the binning too (gsx_isect_bin_sort_tight).  Built, exact
-    # (tests/test_gpu_plans.py) and OFF: measured at 500 k x 8 (tools/dbg/ab_tight.sh) the BA iteration keeps 84 % of its keys and
-    # takes 1124.7 against 1115.3 us (the rasterisers composite the same prefix of 1500-deep lists: 316.4 / 316.8 us backward; the
-    # binning reads 32 B more per instance twice), the refiner's closure 73 % and 853.3 against 862.9 us.  The tracking closure's
-    # fused front is where it pays (TrackClosure(tile_exact), on by default: -6.8 us of 147).
-    TIGHT_LISTS = False
+    # MappingStep / WindowClosure on the generic chain: the projection packs every instance's TIGHT tile rectangle into one word
+    # (gsx_project_fwd_rects | GSX_PROJ_TILE_EXACT) and the binning reads that instead of means2d + radius
+    # (gsx_isect_bin_sort_rects).  Same render, same gradients (tests/test_gpu_plans.py); measured (tools/dbg/ab_tight.sh, same box):
+    # BA iteration 500 k x 8 1106.4 -> 1079.6 us (84 % of the keys), 2 M x 8 2213.3 -> 2099.9 us; the refiner's closure 866.0 ->
+    # 821.7 us and 1902 -> 1713 us.  (First form - the binning itself tightening from the 48-byte records: 32 B more per instance,
+    # twice - was slower than doing nothing: 1124.7 against 1115.3 us, 2303.9 against 2212.1.)  RECT_LISTS: the packed REFERENCE
+    # rectangles (the lists gsplat builds; 4 bytes read for 12): 1100.1 / 2177.0 us - what TIGHT_LISTS = False leaves on.
+    TIGHT_LISTS = True
+    RECT_LISTS = True               # the binning reads packed rectangles the projection wrote (4 bytes for 12; the reference's lists)
 
     def __init__(self, splats, n_cams: int, width: int, height: int, *, render_depth: bool, grads: str = 'pose',
                  Ks: Optional[torch.Tensor] = None, capacity: Optional[int] = None, need_n_touched: bool = False,
@@ -315,7 +318,9 @@ class RenderPlan:
         self.tile_work = self.balanced_order = None
         # tile sort inside the fused tracking rasteriser (gsx_raster_track_fused_sorting): enable_defer_sort()
         self.defer_sort = False
-        self.tight_lists = False      # generic chain: the same tight rectangles (gsx_isect_bin_sort_tight); set by the optimisation plans
+        self.rects = None             # uint32 [C,N]: the projection's packed tile rectangles (tight_lists / rect_lists)
+        self.rect_lists = False       # generic chain: the binning reads the projection's packed rectangles (reference squares; same lists)
+        self.tight_lists = False      # generic chain: tight rectangles packed by the projection (gsx_project_fwd_rects -> gsx_isect_bin_sort_rects)
         self.tile_exact = False       # fused front: the instance's tiles are those of its alpha >= 1/255 box inside the 3-sigma square
         self.row_keys = False         # the front ends with the projection; the rasteriser's tiles collect their keys (enable_row_keys)
         self._rows_last = False       # the last front ran with row keys (M is the sum of self.key_counters then)
@@ -528,6 +533,20 @@ class RenderPlan:
     def _project(self, st: int, tiles: bool = False):
         """tiles: also write tiles_per_gauss [C,N] (the capacity probe sums it; a render does not need it)"""
         m = self.map
+        tight = self.tight_lists or (bool(self.front) and self.tile_exact)
+        if (tight or self.rect_lists) and max(self.tile_w, self.tile_h) < 256:
+            # the projection packs every instance's tile rectangle (4 bytes; tight under tight_lists) for the binning to read
+            # instead of means2d + radius (12 bytes, twice).  (A fused-front plan comes here for its capacity probe only: the
+            # count then is that of the tight rectangles its front will list.)
+            if self.rects is None:
+                self.rects = torch.zeros(self.C, self.N, dtype=torch.int32, device=self.dev)
+            check(lib.gsx_project_fwd_rects(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
+                                            self.H, self.eps2d, self.near, self.far, 0.0,
+                                            self.flags | (_TILE_EXACT if tight else 0), _p(self.radii),
+                                            _p(self.means2d), _p(self.depths), None, None, _p(self.tiles) if tiles else None,
+                                            self.tile_w, self.tile_h, _p(m[3]), _p(m[4]), _p(m[5]), _p(self.rec),
+                                            _p(self.vis_count), self._clear_ptr(), _p(self.rects), st), "gsx_project_fwd_rects")
+            return
         check(lib.gsx_project_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                   self.H, self.eps2d, self.near, self.far, 0.0, self.flags, _p(self.radii),
                                   _p(self.means2d), _p(self.depths), None, None, _p(self.tiles) if tiles else None, self.tile_w,
@@ -583,6 +602,13 @@ class RenderPlan:
             self.near_place = True
             self.tile_placed = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
         return True
+
+    def enable_tight_lists(self, on: bool = True) -> bool:
+        """plans on the generic chain whose tile lists only their own rasteriser reads (an output render, a BA window): tight
+        rectangles packed by the projection (RenderPlan.TIGHT_LISTS says what was measured).  -> whether it applies"""
+        ok = bool(on) and not self.front and max(self.tile_w, self.tile_h) < 256
+        self.tight_lists = ok
+        return ok
 
     def enable_tile_exact(self, on: bool = True) -> bool:
         """Fused-front plans (GSX_PROJ_TILE_EXACT): the projection lists an instance only in the tiles of its 3-sigma square that hold a
@@ -709,14 +735,15 @@ class RenderPlan:
 
     def _isect(self, st: int):
         """tile lists of the generic chain (after ``_project``).  tight_lists: an instance is listed only in the tiles of its 3-sigma
-        square that hold a pixel centre inside the box of its alpha >= 1/255 ellipse (gsx_isect_bin_sort_tight) - what the
+        square that hold a pixel centre inside the box of its alpha >= 1/255 ellipse (gsx_project_fwd_rects | GSX_PROJ_TILE_EXACT ->
+        gsx_isect_bin_sort_rects) - what the
         rasteriser composites, and so every output of the render and its backward, is unchanged; ``offsets`` / ``flat`` are then
         NOT gsplat's isect_offsets / flatten_ids (nobody outside gslam/rasterization.py reads those)"""
-        if self.tight_lists:
-            check(lib.gsx_isect_bin_sort_tight(_p(self.means2d), _p(self.radii), _p(self.depths), _p(self.rec), self.N, self.C,
-                                               self.tile_w, self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev),
-                                               _p(self.status), None, _p(self.flat), _p(self.tile_order), _p(self.isect_ws),
-                                               self.isect_ws.numel(), st), "gsx_isect_bin_sort_tight")
+        if self.tight_lists or self.rect_lists:
+            check(lib.gsx_isect_bin_sort_rects(_p(self.rects), _p(self.depths), self.N, self.C, self.tile_w, self.tile_h,
+                                               self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status), None,
+                                               _p(self.flat), _p(self.tile_order), _p(self.isect_ws), self.isect_ws.numel(), st),
+                  "gsx_isect_bin_sort_rects")
             return
         check(lib.gsx_isect_bin_sort(_p(self.means2d), _p(self.radii), _p(self.depths), self.N, self.C, self.tile_w,
                                      self.tile_h, self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status),
@@ -1124,7 +1151,8 @@ class WindowClosure:
                 self.loss_rows = torch.zeros(r.T, 6, device=r.dev)
         if not self.fused:
             self.r = RenderPlan(splats, Cn, cameras[0].width, cameras[0].height, render_depth=False, grads='pose')
-            self.r.tight_lists = bool(RenderPlan.TIGHT_LISTS) and not self.r.front
+            self.r.tight_lists = bool(RenderPlan.TIGHT_LISTS) and not self.r.front and max(self.r.tile_w, self.r.tile_h) < 256
+            self.r.rect_lists = bool(RenderPlan.RECT_LISTS) and not self.r.front and max(self.r.tile_w, self.r.tile_h) < 256
             if self.r.front and RenderPlan.TIGHT_LISTS:
                 self.r.enable_tile_exact()
         self.r.Ks.copy_(Ks)
@@ -1321,7 +1349,8 @@ class MappingStep:
         if Cl > 0:
             self.r = RenderPlan(splats, Cl, self.W, self.H, render_depth=True, grads='full', grad_out=self.grad_views,
                                 need_n_touched=need_n_touched)
-            self.r.tight_lists = bool(RenderPlan.TIGHT_LISTS) and not self.r.front
+            self.r.tight_lists = bool(RenderPlan.TIGHT_LISTS) and not self.r.front and max(self.r.tile_w, self.r.tile_h) < 256
+            self.r.rect_lists = bool(RenderPlan.RECT_LISTS) and not self.r.front and max(self.r.tile_w, self.r.tile_h) < 256
             if self.r.front and RenderPlan.TIGHT_LISTS:
                 self.r.enable_tile_exact()
             self.r.Ks.copy_(torch.stack([self.window[i].camera.intrinsics for i in self.mine], dim=0))

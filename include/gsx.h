@@ -75,7 +75,7 @@ extern "C" {
                                      keys (gsx_raster_track_fused_rows: tile t reserves its segment on counter t % 64, each counter
                                      over its own 64th of the key buffer); status bit 1 also reports a row that outgrew its segment
                                      (M_cap / rows keys) or a counter that outgrew its 64th. */
-#define GSX_PROJ_TILE_EXACT 2048   /* gsx_front_fwd (pose-only closures): an instance is listed only in the tiles of its 3-sigma square
+#define GSX_PROJ_TILE_EXACT 2048   /* gsx_front_fwd (pose-only closures) and gsx_project_fwd_rects: an instance is listed only in the tiles of its 3-sigma square
                                     * that hold a pixel centre inside the axis-aligned box of the ellipse alpha >= 1/255 (from the conic
                                     * and the opacity, with margins).  The reference lists the whole square (gslam/rasterization.py:259-272)
                                     * and its rasteriser skips the rest pixel by pixel: render, loss and gradients are unchanged, the tile
@@ -112,6 +112,15 @@ int gsx_project_fwd(const float *means, const float *quats, const float *scales,
                     float *v_rec_clear /*[C,N,12] nullable (needs rec): zero-filled on the way, for gsx_raster_bwd's
                                          accumulation - saves the separate clear in front of every backward */,
                     void *stream);
+/* gsx_project_fwd (rec given) that also packs the tile rectangle of every (camera, Gaussian) into rects uint32 [C,N] for
+ * gsx_isect_bin_sort_rects: the reference's 3-sigma square, or the tight one under flags | GSX_PROJ_TILE_EXACT;
+ * tiles_per_gauss (if asked for) counts the tiles of THAT rectangle */
+int gsx_project_fwd_rects(const float *means, const float *quats, const float *scales, const float *viewmats,
+                          const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
+                          float far_plane, float radius_clip, int flags, int32_t *radii, float *means2d, float *depths,
+                          float *conics, float *comps, int32_t *tiles_per_gauss, int tile_w, int tile_h,
+                          const float *logit_opacities, const float *logit_colors, const float *log_uncertainties,
+                          float *rec, int32_t *vis_count, float *v_rec_clear, uint32_t *rects, void *stream);
 
 /* ---- K2: projection bwd (autograd of K1; pose gradient used at gslam/frontend.py:627-646, backend.py:665-670) --
  * v_means2d / v_conics are read with a row stride in floats (2 / 3 when dense, the record stride when they alias
@@ -185,15 +194,16 @@ int gsx_isect_bin_sort(const float *means2d, const int32_t *radii, const float *
                        int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev, int32_t *status,
                        int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_order, void *workspace,
                        int64_t workspace_bytes, void *stream);
-/* gsx_isect_bin_sort with TIGHT rectangles (round 5): rec = the splat records [C*N][12] gsx_project_fwd wrote for the same render;
- * an instance is listed only in the tiles of its 3-sigma square that hold a pixel centre inside the axis-aligned box of its
- * alpha >= 1/255 ellipse.  The reference lists the whole square (gslam/rasterization.py:259-272) and its rasteriser skips the rest
- * pixel by pixel: every output of the rasteriser and of its backward is unchanged, the lists are a quarter shorter.  For launch
- * plans whose tile lists only the rasteriser reads (offsets / flatten_ids are NOT those of gsplat.isect_tiles). */
-int gsx_isect_bin_sort_tight(const float *means2d, const int32_t *radii, const float *depths, const float *rec, int64_t N,
-                             int64_t C, int tile_w, int tile_h, int64_t M_cap, int32_t *offsets, int64_t *M_dev,
-                             int32_t *status, int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_order, void *workspace,
-                             int64_t workspace_bytes, void *stream);
+/* gsx_isect_bin_sort over rectangles the PROJECTION prepared (round 5): rects = uint32 [C*N] packed by gsx_project_fwd_rects
+ * (x0 | x1 << 8 | y0 << 16 | y1 << 24 in tiles, 0 = lists nowhere; tile grids below 256 x 256) - read instead of means2d + radii.
+ * With GSX_PROJ_TILE_EXACT on the projection the rectangles are TIGHT: an instance is listed only in the tiles of its 3-sigma square
+ * that hold a pixel centre inside the axis-aligned box of its alpha >= 1/255 ellipse.  The reference lists the whole square
+ * (gslam/rasterization.py:259-272) and its rasteriser skips the rest pixel by pixel: every output of the rasteriser and of its
+ * backward is unchanged, the lists are shorter - for launch plans whose tile lists only the rasteriser reads (offsets /
+ * flatten_ids are then NOT those of gsplat.isect_tiles). */
+int gsx_isect_bin_sort_rects(const uint32_t *rects, const float *depths, int64_t N, int64_t C, int tile_w, int tile_h,
+                             int64_t M_cap, int32_t *offsets, int64_t *M_dev, int32_t *status, int64_t *isect_ids,
+                             int32_t *flatten_ids, int32_t *tile_order, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- K1 + K3..K7 fused for the launch plans (csrc/isect_bin.hip, "fused front"): the gslam front-end projection of
  * gsx_project_fwd (flags: GSX_PROJ_LOG_SCALES implied by the caller's data, RENDER_DEPTH, BETAS, SKIP_CULLED; radius_clip 0)

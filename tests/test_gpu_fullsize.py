@@ -300,7 +300,16 @@ def test_ba_step_2m_window8_graph_equals_eager(dev):
     torch.cuda.synchronize()
 
     sb, wb, ba_b = build(True)
-    plan = ba_b.plan(wb)
+    # (the tile lists are compared entry for entry below: the plan lists the reference's 3-sigma squares here - through the packed
+    # rectangles of the projection, RECT_LISTS - not the tight ones it uses by default, which drop what no pixel can see)
+    from gslam_amd.plan import RenderPlan
+    tight_default = RenderPlan.TIGHT_LISTS
+    RenderPlan.TIGHT_LISTS = False
+    try:
+        plan = ba_b.plan(wb)
+    finally:
+        RenderPlan.TIGHT_LISTS = tight_default
+    assert plan.r.rect_lists and not plan.r.tight_lists
     plan.prepare()                       # capacity probe + one eager render / loss / backward WITHOUT update + capture
     assert plan.graph.captured
     tb, pb = plan.step()                 # ONE graph launch: the whole iteration
