@@ -1151,7 +1151,7 @@ def test_range_copy_gathers_and_scatters_the_parts_of_a_range(dev):
 
 @pytest.mark.parametrize("n,n_cams", [(9000, 3), (150000, 8)])
 def test_tight_tile_lists_of_the_generic_chain_change_no_output(dev, n, n_cams):
-    """gsx_isect_bin_sort_tight (round 5) in the BA plan (direct binning at 9 k x 3, the spatial pre-sort at 150 k x 8): against the
+    """gsx_project_fwd_rects | GSX_PROJ_TILE_EXACT -> gsx_isect_bin_sort_rects (round 5) in the BA plan (direct binning at 9 k x 3, the spatial pre-sort at 150 k x 8): against the
     plan with the reference's full 3-sigma squares - render, alphas and loss bit for bit (the same entries are composited in the
     same order), all six map gradients and the pose gradients to float-atomic noise, fewer keys."""
     from gslam_amd.mapping import BundleAdjuster
