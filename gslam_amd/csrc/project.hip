@@ -94,6 +94,17 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         }
         radii[idx] = radius_i;
         n_vis += radius_i > 0 ? 1 : 0;
+        if (RS > 0 && rects && radius_i == 0 && (flags & GSX_PROJ_SKIP_CULLED)) {
+            // nobody reads the other columns of a culled row (the binning reads the packed rectangle, the projection backward the
+            // radius): 60 bytes of zeros per culled (camera, Gaussian) not written - three quarters of the rows of a 2 M x 8 window
+            rects[idx] = 0u;
+            if (tiles_per_gauss) tiles_per_gauss[idx] = 0;
+            if (v_rec_clear) {
+                float4 *z = reinterpret_cast<float4 *>(v_rec_clear + idx * RS);
+                z[0] = z[1] = z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            continue;
+        }
         means2d[2 * idx] = mx; means2d[2 * idx + 1] = my;
         depths[idx] = depth;
         if (conics) { conics[3 * idx] = con0; conics[3 * idx + 1] = con1; conics[3 * idx + 2] = con2; }

@@ -222,6 +222,11 @@ class RenderPlan:
     # twice - was slower than doing nothing: 1124.7 against 1115.3 us, 2303.9 against 2212.1.)  RECT_LISTS: the packed REFERENCE
     # rectangles (the lists gsplat builds; 4 bytes read for 12): 1100.1 / 2177.0 us - what TIGHT_LISTS = False leaves on.
     TIGHT_LISTS = True
+    # with packed rectangles the projection can write radii = 0 / rects = 0 for a culled row and nothing else (lean_rows; as_output()
+    # restores the reference's zeros with one projection launch on demand).  Built, exact, OFF: measured SLOWER, same box - BA
+    # iteration 2 M x 8 2177.5 against 2123.1 us, 500 k x 8 1048.7 against 1038.6: three quarters of the rows not written turn the
+    # projection's full-line streaming stores into scattered 48-byte ones (partial lines at the memory side cost more than zeros).
+    LEAN_ROWS = False
     RECT_LISTS = True               # the binning reads packed rectangles the projection wrote (4 bytes for 12; the reference's lists)
 
     def __init__(self, splats, n_cams: int, width: int, height: int, *, render_depth: bool, grads: str = 'pose',
@@ -318,6 +323,7 @@ class RenderPlan:
         self.tile_work = self.balanced_order = None
         # tile sort inside the fused tracking rasteriser (gsx_raster_track_fused_sorting): enable_defer_sort()
         self.defer_sort = False
+        self.lean_rows = False        # generic chain with packed rectangles: culled rows get radii = 0, rects = 0 and nothing else
         self.rects = None             # uint32 [C,N]: the projection's packed tile rectangles (tight_lists / rect_lists)
         self.rect_lists = False       # generic chain: the binning reads the projection's packed rectangles (reference squares; same lists)
         self.tight_lists = False      # generic chain: tight rectangles packed by the projection (gsx_project_fwd_rects -> gsx_isect_bin_sort_rects)
@@ -489,6 +495,10 @@ class RenderPlan:
         if self.v_rec is not None:
             means2d = self.means2d.view(self.C, self.N, 2)
             means2d.grad = self.v_rec[..., 0:2]
+        if not self.front and self.lean_rows:
+            # the renders of this plan left the culled rows of means2d / depths / records as they were (lean_rows): the reference
+            # has zeros there (gslam/rasterization.py:153-170) - one projection launch with every row written, on demand
+            self._project(current_stream_ptr(self.dev), full_rows=True)
         if not self.front:
             # the projection of a render leaves tiles_per_gauss out (16 MB at 500 k x 8 that only this view reads)
             check(lib.gsx_isect_count(_p(self.means2d), _p(self.radii), self.C * self.N, self.tile_w, self.tile_h,
@@ -530,8 +540,9 @@ class RenderPlan:
             check(lib.gsx_zero_words(_p(self.v_rec), self.v_rec.numel(), st), "gsx_zero_words")
             self._v_rec_dirty = False
 
-    def _project(self, st: int, tiles: bool = False):
-        """tiles: also write tiles_per_gauss [C,N] (the capacity probe sums it; a render does not need it)"""
+    def _project(self, st: int, tiles: bool = False, full_rows: bool = False):
+        """tiles: also write tiles_per_gauss [C,N] (the capacity probe sums it; a render does not need it).  full_rows: write
+        the culled rows' zeros even in a plan that leaves them out (lean_rows; as_output() asks for it)"""
         m = self.map
         tight = self.tight_lists or (bool(self.front) and self.tile_exact)
         if (tight or self.rect_lists) and max(self.tile_w, self.tile_h) < 256:
@@ -542,16 +553,17 @@ class RenderPlan:
                 self.rects = torch.zeros(self.C, self.N, dtype=torch.int32, device=self.dev)
             check(lib.gsx_project_fwd_rects(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                             self.H, self.eps2d, self.near, self.far, 0.0,
-                                            self.flags | (_TILE_EXACT if tight else 0), _p(self.radii),
+                                            self.flags | (_TILE_EXACT if tight else 0) | (
+                                                _SKIP_CULLED if self.lean_rows and not full_rows else 0), _p(self.radii),
                                             _p(self.means2d), _p(self.depths), None, None, _p(self.tiles) if tiles else None,
                                             self.tile_w, self.tile_h, _p(m[3]), _p(m[4]), _p(m[5]), _p(self.rec),
-                                            _p(self.vis_count), self._clear_ptr(), _p(self.rects), st), "gsx_project_fwd_rects")
+                                            _p(self.vis_count), (None if full_rows else self._clear_ptr()), _p(self.rects), st), "gsx_project_fwd_rects")
             return
         check(lib.gsx_project_fwd(_p(m[0]), _p(m[1]), _p(m[2]), _p(self.viewmats), _p(self.Ks), self.N, self.C, self.W,
                                   self.H, self.eps2d, self.near, self.far, 0.0, self.flags, _p(self.radii),
                                   _p(self.means2d), _p(self.depths), None, None, _p(self.tiles) if tiles else None, self.tile_w,
                                   self.tile_h, _p(m[3]), _p(m[4]), _p(m[5]), _p(self.rec), _p(self.vis_count),
-                                  self._clear_ptr(), st), "gsx_project_fwd")
+                                  (None if full_rows else self._clear_ptr()), st), "gsx_project_fwd")
 
     def _front(self, st: int, defer_sort: bool = False):
         m = self.map
@@ -1153,6 +1165,7 @@ class WindowClosure:
             self.r = RenderPlan(splats, Cn, cameras[0].width, cameras[0].height, render_depth=False, grads='pose')
             self.r.tight_lists = bool(RenderPlan.TIGHT_LISTS) and not self.r.front and max(self.r.tile_w, self.r.tile_h) < 256
             self.r.rect_lists = bool(RenderPlan.RECT_LISTS) and not self.r.front and max(self.r.tile_w, self.r.tile_h) < 256
+            self.r.lean_rows = bool(RenderPlan.LEAN_ROWS) and (self.r.tight_lists or self.r.rect_lists)
             if self.r.front and RenderPlan.TIGHT_LISTS:
                 self.r.enable_tile_exact()
         self.r.Ks.copy_(Ks)
@@ -1351,6 +1364,7 @@ class MappingStep:
                                 need_n_touched=need_n_touched)
             self.r.tight_lists = bool(RenderPlan.TIGHT_LISTS) and not self.r.front and max(self.r.tile_w, self.r.tile_h) < 256
             self.r.rect_lists = bool(RenderPlan.RECT_LISTS) and not self.r.front and max(self.r.tile_w, self.r.tile_h) < 256
+            self.r.lean_rows = bool(RenderPlan.LEAN_ROWS) and (self.r.tight_lists or self.r.rect_lists)
             if self.r.front and RenderPlan.TIGHT_LISTS:
                 self.r.enable_tile_exact()
             self.r.Ks.copy_(torch.stack([self.window[i].camera.intrinsics for i in self.mine], dim=0))

@@ -114,7 +114,8 @@ int gsx_project_fwd(const float *means, const float *quats, const float *scales,
                     void *stream);
 /* gsx_project_fwd (rec given) that also packs the tile rectangle of every (camera, Gaussian) into rects uint32 [C,N] for
  * gsx_isect_bin_sort_rects: the reference's 3-sigma square, or the tight one under flags | GSX_PROJ_TILE_EXACT;
- * tiles_per_gauss (if asked for) counts the tiles of THAT rectangle */
+ * tiles_per_gauss (if asked for) counts the tiles of THAT rectangle.  flags | GSX_PROJ_SKIP_CULLED: a culled row gets radii = 0 and
+ * rects = 0 and nothing else (its means2d / depths / record keep whatever they held) */
 int gsx_project_fwd_rects(const float *means, const float *quats, const float *scales, const float *viewmats,
                           const float *Ks, int64_t N, int64_t C, int W, int H, float eps2d, float near_plane,
                           float far_plane, float radius_clip, int flags, int32_t *radii, float *means2d, float *depths,

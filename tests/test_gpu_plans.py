@@ -1259,3 +1259,49 @@ def test_closure_tail_inside_the_pose_backward_launch_equals_the_tail_launch(dev
     ra, rb = a.read_report().cpu(), b.read_report().cpu()
     assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
     assert float((a.r.viewmats - b.r.viewmats).abs().max()) < 5e-3
+
+
+def test_lean_rows_of_the_ba_projection_change_no_result_and_as_output_restores_the_zeros(dev):
+    """RenderPlan.lean_rows (round 5): with packed rectangles the projection of a BA plan writes radii = 0 / rects = 0 for a culled
+    (camera, Gaussian) and nothing else.  Against the plan that writes every row: render, loss and v_render bit for bit, gradients
+    to float-atomic noise - over iterations in which Gaussians LEAVE the frustum (stale rows behind them) - and as_output() shows
+    the reference's zeros in every culled row of means2d / depths / conics while the gradient records of the densification
+    iteration stay as accumulated."""
+    from gslam_amd.mapping import BundleAdjuster
+    from gslam_amd.plan import RenderPlan
+    res = []
+    for lean in (False, True):
+        m, cam, frame = _world(dev, n=150000)
+        window = [frame(i, i) for i in range(8)]
+        old = RenderPlan.LEAN_ROWS
+        RenderPlan.LEAN_ROWS = lean
+        try:
+            plan = BundleAdjuster(m, capturable=True).plan(window)
+        finally:
+            RenderPlan.LEAN_ROWS = old
+        assert plan.r.lean_rows == lean and not plan.r.front and plan.r.tight_lists
+        total, pm = plan.render_backward()                    # from identical maps: compared below
+        torch.cuda.synchronize()
+        first = (plan.r.render.clone(), plan.r.v_render.clone(), float(total), float(pm),
+                 {k: v.clone() for k, v in plan.grad_views.items()}, plan.r.radii.clone())
+        plan.step()
+        plan.step()
+        with torch.no_grad():                                 # the cameras turn: part of the map leaves every frustum
+            for f in window:
+                f.pose.dR.data[0] += 0.12
+        plan.render_backward()
+        torch.cuda.synchronize()
+        assert plan.capacity_ok()
+        vrec_before = plan.r.v_rec.clone()
+        out = plan.as_output()
+        torch.cuda.synchronize()
+        assert torch.equal(plan.r.v_rec, vrec_before)         # the densification's records survive the view
+        culled = out.radii == 0
+        assert int(culled.sum()) > 0 and int((first[5] > 0)[culled].sum()) > 0      # rows that WERE visible are among them
+        for t in (out.means2d, out.depths, out.conics):
+            assert float(t.detach()[culled].abs().max()) == 0.0
+        res.append(first)
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and torch.equal(a[5], b[5])
+    for k in a[4]:
+        assert float((a[4][k] - b[4][k]).abs().max()) < 2e-4 * float(a[4][k].abs().max()) + 1e-10, k
