@@ -751,7 +751,7 @@ class RenderPlan:
         gsx_isect_bin_sort_rects) - what the
         rasteriser composites, and so every output of the render and its backward, is unchanged; ``offsets`` / ``flat`` are then
         NOT gsplat's isect_offsets / flatten_ids (nobody outside gslam/rasterization.py reads those)"""
-        if self.tight_lists or self.rect_lists:
+        if (self.tight_lists or self.rect_lists) and max(self.tile_w, self.tile_h) < 256:      # (as _project decides)
             check(lib.gsx_isect_bin_sort_rects(_p(self.rects), _p(self.depths), self.N, self.C, self.tile_w, self.tile_h,
                                                self.capacity, _p(self.offsets), _p(self.M_dev), _p(self.status), None,
                                                _p(self.flat), _p(self.tile_order), _p(self.isect_ws), self.isect_ws.numel(), st),
