@@ -361,13 +361,23 @@ def run_headline(args, dev):
     out_graph.capture(out_stream, out_render.forward)
     torch.cuda.synchronize()
 
-    diag = set(x for x in args.diag.split(",") if x and not x.startswith("cand:"))
+    diag = set(x for x in args.diag.split(",") if x and not x.startswith("cand:") and not x.startswith("cumask:"))
     if "prio" in diag:
         lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
         print("priority range", lo, hi, file=sys.stderr)
         map_stream, track_stream = torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)
     else:
         map_stream, track_stream = torch.cuda.Stream(), torch.cuda.Stream()
+    cumask = [x for x in args.diag.split(",") if x.startswith("cumask:")]
+    if cumask:
+        # (scheduling experiment) the mapping stream restricted to the CUs of a repeating 32-bit pattern, e.g. cumask:77777777
+        import ctypes as C
+        from gslam_amd._lib import lib as _lib_, check as _check
+        pat = int(cumask[0].split(":")[1], 16)
+        words = (C.c_uint32 * 8)(*([pat] * 8))
+        ptr = C.c_void_p()
+        _check(_lib_.gsx_stream_create_masked(C.byref(ptr), words, 8), "gsx_stream_create_masked")
+        map_stream = torch.cuda.ExternalStream(ptr.value)
     closures_per_frame = N_ADAM + MAX_EVAL + 1
 
     def run(first, count):

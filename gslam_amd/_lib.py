@@ -103,6 +103,7 @@ PROTOTYPES = {
     "gsx_concat_rows": (i32, [i32, C.POINTER(vp), i64, C.POINTER(vp), i64, C.POINTER(vp), C.POINTER(i32), vp]),
     "gsx_selftest": (i32, [vp, i64, vp]),
     "gsx_stream_create": (i32, [C.POINTER(vp)]),
+    "gsx_stream_create_masked": (i32, [C.POINTER(vp), vp, i32]),
     "gsx_stream_destroy": (i32, [vp]),
     "gsx_stream_synchronize": (i32, [vp]),
     "gsx_stream_wait_stream": (i32, [vp, vp]),

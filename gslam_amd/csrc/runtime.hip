@@ -27,6 +27,17 @@ extern "C" int gsx_stream_create(void **stream_out) {
     return GSX_OK;
 }
 
+// A stream whose kernels may only use the compute units whose bit is set (hipExtStreamCreateWithCUMask; mask words are 32 CUs each).
+// For a stream of long, chip-filling launches that runs beside a chain of short dependent ones (the mapping stream beside the
+// tracker): the CUs it leaves alone are where the chain's next launch starts at once instead of waiting for a workgroup to drain.
+extern "C" int gsx_stream_create_masked(void **stream_out, const uint32_t *cu_mask, int mask_words) {
+    GSX_CHECK_ARG(stream_out != nullptr && cu_mask != nullptr && mask_words >= 1 && mask_words <= 32);
+    hipStream_t s = nullptr;
+    GSX_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask_words, cu_mask));
+    *stream_out = (void *)s;
+    return GSX_OK;
+}
+
 extern "C" int gsx_stream_destroy(void *stream) {
     if (stream == nullptr) return GSX_OK;
     GSX_HIP(hipStreamDestroy((hipStream_t)stream));

@@ -597,6 +597,8 @@ int gsx_concat_rows(int n_tensors, const void *const *a, int64_t n_a, const void
  * gslam/backend.py:260-359,465-504).  Nothing may be allocated, freed or synchronised on the capturing thread between
  * gsx_graph_begin and gsx_graph_end.  capture mode: 0 global, 1 thread-local, 2 relaxed (hipStreamCaptureMode). */
 int gsx_stream_create(void **stream_out);                    /* non-blocking stream */
+int gsx_stream_create_masked(void **stream_out, const uint32_t *cu_mask, int mask_words);   /* kernels of this stream run on the
+                                                                 CUs whose bit is set only (32 CUs per word) */
 int gsx_stream_destroy(void *stream);
 int gsx_stream_synchronize(void *stream);
 int gsx_stream_wait_stream(void *stream, void *other);       /* device-side: `stream` waits for what `other` holds now */
