@@ -19,10 +19,13 @@ constexpr int TSY = 16;          // vertical pass, 4 per active thread in the ho
 constexpr int HALO = 5;          // 11-tap window
 constexpr int INX = TSX + 2 * HALO;  // 42
 constexpr int INY = TSY + 2 * HALO;  // 26
+constexpr int STAGE_TRIPS = (INY * INX + 255) / 256;   // trips of a 256-thread workgroup over the 42 x 26 halo: 5
 
 __device__ __constant__ float c_win[11] = {1.0283800845e-03f, 7.5987581352e-03f, 3.6000772128e-02f, 1.0936068951e-01f,
                                            2.1300553771e-01f, 2.6601172486e-01f, 2.1300553771e-01f, 1.0936068951e-01f,
                                            3.6000772128e-02f, 7.5987581352e-03f, 1.0283800845e-03f};
+
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct Strides {
     int64_t b, c, h, w;
@@ -74,14 +77,31 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__
     const int t = threadIdx.x;
     const float *p1 = img1 + b * s1.b + ch0 * s1.c;
     const float *p2 = img2 + b * s2.b + ch0 * s2.c;
-    for (int i = t; i < INY * INX; i += 256) {
-        const int ly = i / INX, lx = i - ly * INX;
-        const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    // every load of the halo is issued before the first value is stored: a workgroup is a chain load -> LDS -> filter -> store whose
+    // length sets the kernel's time (56 workgroups per CU, six at a time), and the rolled loop waited for each of its five trips'
+    // loads in turn (forward 83 -> 5x us, backward 100 -> 6x us at 8 x 640 x 480: DESIGN.md 6)
+    {
+        float va[STAGE_TRIPS][NC], vc[STAGE_TRIPS][NC];
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            sx[k][ly][lx] = in ? p1[gy * s1.h + gx * s1.w + k * s1.c] : 0.f;
-            sy[k][ly][lx] = in ? p2[gy * s2.h + gx * s2.w + k * s2.c] : 0.f;
+        for (int u = 0; u < STAGE_TRIPS; ++u) {
+            const int i = t + u * 256;
+            const int ly = i / INX, lx = i - ly * INX;
+            const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+            const bool in = i < INY * INX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                va[u][k] = in ? p1[gy * s1.h + gx * s1.w + k * s1.c] : 0.f;
+                vc[u][k] = in ? p2[gy * s2.h + gx * s2.w + k * s2.c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < STAGE_TRIPS; ++u) {
+            const int i = t + u * 256;
+            if (i < INY * INX) {
+                const int ly = i / INX, lx = i - ly * INX;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) { sx[k][ly][lx] = va[u][k]; sy[k][ly][lx] = vc[u][k]; }
+            }
         }
     }
     __syncthreads();
@@ -92,43 +112,45 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__
             float a[14], c[14];
 #pragma unroll
             for (int k = 0; k < 14; ++k) { a[k] = sx[kc][ly][lx + k]; c[k] = sy[kc][ly][lx + k]; }
+            // packed fp32 (v_pk_mul / v_pk_add / v_pk_fma: two lanes of arithmetic per instruction) on the pairs (image 1, image 2):
+            // 4 instructions per tap instead of 7, the same IEEE operations on every component - bit-identical sums
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
-                float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+                f2 m = {0.f, 0.f}, e = {0.f, 0.f};
+                float e12 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 11; ++k) {
-                    const float w = c_win[k], av = a[o + k], cv = c[o + k];
-                    const float wa = w * av, wc = w * cv;
-                    m1 += wa; m2 += wc; e11 += wa * av; e22 += wc * cv; e12 += wa * cv;
+                    const float w = c_win[k];
+                    const f2 v = {a[o + k], c[o + k]}, ww = {w, w};
+                    const f2 wv = ww * v;
+                    m += wv;
+                    e = __builtin_elementwise_fma(wv, v, e);
+                    e12 = __builtin_fmaf(wv.x, v.y, e12);
                 }
-                hz[0][ly][lx + o] = m1; hz[1][ly][lx + o] = m2; hz[2][ly][lx + o] = e11; hz[3][ly][lx + o] = e22;
+                hz[0][ly][lx + o] = m.x; hz[1][ly][lx + o] = m.y; hz[2][ly][lx + o] = e.x; hz[3][ly][lx + o] = e.y;
                 hz[4][ly][lx + o] = e12;
             }
         }
         __syncthreads();
         const int lx = t & 31, ly = (t >> 5) * 2;  // two vertically adjacent outputs per thread
         const int gx = x0 + lx;
-        float acc[2][5];
+        // the two outputs of a thread as the two halves of packed accumulators: row r feeds output 0 with tap r and output 1 with
+        // tap r - 1 (a zero weight at the ends adds + 0 to a sum that is never - 0: the same bits as leaving the term out)
+        f2 pacc[5];
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int m = 0; m < 5; ++m) acc[o][m] = 0.f;
+        for (int m = 0; m < 5; ++m) pacc[m] = f2{0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 12; ++r) {
-            float v[5];
+            const f2 w = {r < 11 ? c_win[r] : 0.f, r >= 1 ? c_win[r - 1] : 0.f};
 #pragma unroll
-            for (int m = 0; m < 5; ++m) v[m] = hz[m][ly + r][lx];
-            if (r < 11) {
-                const float w = c_win[r];
-#pragma unroll
-                for (int m = 0; m < 5; ++m) acc[0][m] += w * v[m];
-            }
-            if (r >= 1) {
-                const float w = c_win[r - 1];
-#pragma unroll
-                for (int m = 0; m < 5; ++m) acc[1][m] += w * v[m];
+            for (int m = 0; m < 5; ++m) {
+                const float v = hz[m][ly + r][lx];
+                pacc[m] = __builtin_elementwise_fma(w, f2{v, v}, pacc[m]);
             }
         }
+        float acc[2][5];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) { acc[0][m] = pacc[m].x; acc[1][m] = pacc[m].y; }
         float val = 0.f;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
@@ -204,43 +226,60 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float *__restrict__
     for (int kc = 0; kc < NC; ++kc) {
         const int plane = b * CH + ch0 + kc;
         __syncthreads();                                     // sm / hz of the previous channel are no longer read
-        for (int i = t; i < INY * INX; i += 256) {
-            const int ly = i / INX, lx = i - ly * INX;
-            const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
-            float a = 0.f, c = 0.f, d = 0.f;
-            if (gx >= crop && gx < W - crop && gy >= crop && gy < H - crop) {  // dL/dmap is zero outside the crop
-                const int64_t o = ((int64_t)plane * H + gy) * W + gx;
-                a = dm_dmu1[o]; c = dm_ds1[o]; d = dm_ds12[o];
+        {
+            float va[STAGE_TRIPS], vc[STAGE_TRIPS], vd[STAGE_TRIPS];   // (all loads in flight before the first LDS store: see the forward)
+#pragma unroll
+            for (int u = 0; u < STAGE_TRIPS; ++u) {
+                const int i = t + u * 256;
+                const int ly = i / INX, lx = i - ly * INX;
+                const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+                const bool in = i < INY * INX && gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;   // dL/dmap is zero outside the crop
+                const int64_t o = ((int64_t)plane * H + (in ? gy : 0)) * W + (in ? gx : 0);
+                va[u] = in ? dm_dmu1[o] : 0.f; vc[u] = in ? dm_ds1[o] : 0.f; vd[u] = in ? dm_ds12[o] : 0.f;
             }
-            sm[0][ly][lx] = a; sm[1][ly][lx] = c; sm[2][ly][lx] = d;
+#pragma unroll
+            for (int u = 0; u < STAGE_TRIPS; ++u) {
+                const int i = t + u * 256;
+                if (i < INY * INX) {
+                    const int ly = i / INX, lx = i - ly * INX;
+                    sm[0][ly][lx] = va[u]; sm[1][ly][lx] = vc[u]; sm[2][ly][lx] = vd[u];
+                }
+            }
         }
         __syncthreads();
         if (t < INY * (TSX / 4)) {
             const int ly = t / (TSX / 4), lx = (t - ly * (TSX / 4)) * 4;
+            // maps 0 and 1 as the halves of a packed accumulator (v_pk_fma_f32), map 2 on its own: the same fused multiply-adds
+            float in0[14], in1[14], in2[14];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                float in[14];
+            for (int k = 0; k < 14; ++k) { in0[k] = sm[0][ly][lx + k]; in1[k] = sm[1][ly][lx + k]; in2[k] = sm[2][ly][lx + k]; }
 #pragma unroll
-                for (int k = 0; k < 14; ++k) in[k] = sm[m][ly][lx + k];
+            for (int o = 0; o < 4; ++o) {
+                f2 acc01 = {0.f, 0.f};
+                float acc2 = 0.f;
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 11; ++k) acc += c_win[k] * in[o + k];
-                    hz[m][ly][lx + o] = acc;
+                for (int k = 0; k < 11; ++k) {
+                    const float w = c_win[k];
+                    acc01 = __builtin_elementwise_fma(f2{w, w}, f2{in0[o + k], in1[o + k]}, acc01);
+                    acc2 = __builtin_fmaf(w, in2[o + k], acc2);
                 }
+                hz[0][ly][lx + o] = acc01.x; hz[1][ly][lx + o] = acc01.y; hz[2][ly][lx + o] = acc2;
             }
         }
         __syncthreads();
         const int lx = t & 31, ly = (t >> 5) * 2;
         const int gx = x0 + lx;
-        float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        // the thread's two outputs as the halves of packed accumulators (tap r for output 0, tap r - 1 for output 1; see the forward)
+        f2 pa[3] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
 #pragma unroll
         for (int r = 0; r < 12; ++r) {
+            const f2 w = {r < 11 ? c_win[r] : 0.f, r >= 1 ? c_win[r - 1] : 0.f};
             const float v0 = hz[0][ly + r][lx], v1 = hz[1][ly + r][lx], v2 = hz[2][ly + r][lx];
-            if (r < 11) { const float w = c_win[r]; acc[0][0] += w * v0; acc[0][1] += w * v1; acc[0][2] += w * v2; }
-            if (r >= 1) { const float w = c_win[r - 1]; acc[1][0] += w * v0; acc[1][1] += w * v1; acc[1][2] += w * v2; }
+            pa[0] = __builtin_elementwise_fma(w, f2{v0, v0}, pa[0]);
+            pa[1] = __builtin_elementwise_fma(w, f2{v1, v1}, pa[1]);
+            pa[2] = __builtin_elementwise_fma(w, f2{v2, v2}, pa[2]);
         }
+        const float acc[2][3] = {{pa[0].x, pa[1].x, pa[2].x}, {pa[0].y, pa[1].y, pa[2].y}};
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             const int gy = y0 + ly + o;
@@ -292,41 +331,58 @@ __global__ __launch_bounds__(256) void ssim_bwd_loss_kernel(gsx_loss::LossArgs A
     for (int kc = 0; kc < NC; ++kc) {
         const int plane = b * 3 + kc;
         __syncthreads();
-        for (int i = t; i < INY * INX; i += 256) {
-            const int yy = i / INX, xx = i - yy * INX;
-            const int gy = y0 + yy - HALO, gxx = x0 + xx - HALO;
-            float a = 0.f, c = 0.f, d = 0.f;
-            if (gxx >= crop && gxx < W - crop && gy >= crop && gy < H - crop) {
-                const int64_t o = ((int64_t)plane * H + gy) * W + gxx;
-                a = dm_dmu1[o]; c = dm_ds1[o]; d = dm_ds12[o];
+        {
+            float va[STAGE_TRIPS], vc[STAGE_TRIPS], vd[STAGE_TRIPS];   // (all loads in flight before the first LDS store: see the forward)
+#pragma unroll
+            for (int u = 0; u < STAGE_TRIPS; ++u) {
+                const int i = t + u * 256;
+                const int yy = i / INX, xx = i - yy * INX;
+                const int gy = y0 + yy - HALO, gxx = x0 + xx - HALO;
+                const bool in = i < INY * INX && gxx >= crop && gxx < W - crop && gy >= crop && gy < H - crop;
+                const int64_t o = ((int64_t)plane * H + (in ? gy : 0)) * W + (in ? gxx : 0);
+                va[u] = in ? dm_dmu1[o] : 0.f; vc[u] = in ? dm_ds1[o] : 0.f; vd[u] = in ? dm_ds12[o] : 0.f;
             }
-            sm[0][yy][xx] = a; sm[1][yy][xx] = c; sm[2][yy][xx] = d;
-        }
-        __syncthreads();
-        if (t < INY * (TSX / 4)) {
-            const int yy = t / (TSX / 4), xx = (t - yy * (TSX / 4)) * 4;
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                float in[14];
-#pragma unroll
-                for (int k = 0; k < 14; ++k) in[k] = sm[m][yy][xx + k];
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 11; ++k) acc += c_win[k] * in[o + k];
-                    hz[m][yy][xx + o] = acc;
+            for (int u = 0; u < STAGE_TRIPS; ++u) {
+                const int i = t + u * 256;
+                if (i < INY * INX) {
+                    const int yy = i / INX, xx = i - yy * INX;
+                    sm[0][yy][xx] = va[u]; sm[1][yy][xx] = vc[u]; sm[2][yy][xx] = vd[u];
                 }
             }
         }
         __syncthreads();
-        float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        if (t < INY * (TSX / 4)) {
+            const int yy = t / (TSX / 4), xx = (t - yy * (TSX / 4)) * 4;
+            // maps 0 and 1 as the halves of a packed accumulator (v_pk_fma_f32), map 2 on its own: the same fused multiply-adds
+            float in0[14], in1[14], in2[14];
+#pragma unroll
+            for (int k = 0; k < 14; ++k) { in0[k] = sm[0][yy][xx + k]; in1[k] = sm[1][yy][xx + k]; in2[k] = sm[2][yy][xx + k]; }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                f2 acc01 = {0.f, 0.f};
+                float acc2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    const float w = c_win[k];
+                    acc01 = __builtin_elementwise_fma(f2{w, w}, f2{in0[o + k], in1[o + k]}, acc01);
+                    acc2 = __builtin_fmaf(w, in2[o + k], acc2);
+                }
+                hz[0][yy][xx + o] = acc01.x; hz[1][yy][xx + o] = acc01.y; hz[2][yy][xx + o] = acc2;
+            }
+        }
+        __syncthreads();
+        // the thread's two outputs as the halves of packed accumulators (tap r for output 0, tap r - 1 for output 1; see the forward)
+        f2 pa[3] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
 #pragma unroll
         for (int r = 0; r < 12; ++r) {
+            const f2 w = {r < 11 ? c_win[r] : 0.f, r >= 1 ? c_win[r - 1] : 0.f};
             const float v0 = hz[0][ly + r][lx], v1 = hz[1][ly + r][lx], v2 = hz[2][ly + r][lx];
-            if (r < 11) { const float w = c_win[r]; acc[0][0] += w * v0; acc[0][1] += w * v1; acc[0][2] += w * v2; }
-            if (r >= 1) { const float w = c_win[r - 1]; acc[1][0] += w * v0; acc[1][1] += w * v1; acc[1][2] += w * v2; }
+            pa[0] = __builtin_elementwise_fma(w, f2{v0, v0}, pa[0]);
+            pa[1] = __builtin_elementwise_fma(w, f2{v1, v1}, pa[1]);
+            pa[2] = __builtin_elementwise_fma(w, f2{v2, v2}, pa[2]);
         }
+        const float acc[2][3] = {{pa[0].x, pa[1].x, pa[2].x}, {pa[0].y, pa[1].y, pa[2].y}};
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             const float x = s_xy[0][kc][ly + o][lx], y = s_xy[1][kc][ly + o][lx];
