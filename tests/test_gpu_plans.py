@@ -1220,8 +1220,7 @@ def test_closure_tail_inside_the_pose_backward_launch_equals_the_tail_launch(dev
     """gsx_front_pose_bwd_tail (round 5): the closure's tail run by the last workgroup of the pose backward launch, against
     gsx_front_pose_bwd + gsx_track_opt_tail.  One closure from the same state: loss, pose gradient (the optimiser's g), the new
     parameters and the next view matrix agree to the rounding of a different summation tree over the partial rows; the ticket
-    counters are back at zero; 30 captured closures (Adam warm-up + line search): same end point to the tolerance of the other
-    closure tests; the state machine's counters equal."""
+    counters are back at zero; ten captured closures of the Adam warm-up: same end point, the state machine's counters equal."""
     from gslam_amd.plan import TrackClosure, current_stream_ptr
     splats, _ = _track_closure(dev, 150000, 3, candidates=False)
     from gslam_amd.primitives import Camera
@@ -1250,15 +1249,18 @@ def test_closure_tail_inside_the_pose_backward_launch_equals_the_tail_launch(dev
         d = float((out[0][k] - out[1][k]).abs().max())
         assert d <= 1e-5 * float(out[0][k].abs().max()) + 1e-7, (k, d)
     assert int(b.tail_tickets.abs().sum()) == 0
+    # (ten captured closures inside the Adam warm-up: smooth steps, no discrete line-search decision that the last bits of a sum
+    # could flip - the end points agree closely; the state machine's counters agree exactly)
     for c in (a, b):
         c.load(V0, img, torch.tensor([0.02, -0.01], device=dev))
-        c.init_optimizer(4, 1e-3, 5, 25)
-        c.launch(30)
+        c.init_optimizer(12, 1e-3, 5, 25)
+        c.launch(10)
     torch.cuda.synchronize()
     assert a.r.check_capacity() and b.r.check_capacity() and int(b.tail_tickets.abs().sum()) == 0
     ra, rb = a.read_report().cpu(), b.read_report().cpu()
-    assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
-    assert float((a.r.viewmats - b.r.viewmats).abs().max()) < 5e-3
+    assert torch.equal(ra[:4], rb[:4]) and float(ra[7]) == float(rb[7]) == 10.0, (ra, rb)
+    assert abs(float(ra[4]) - float(rb[4])) <= 1e-3 * abs(float(ra[4])) + 1e-12, (ra, rb)
+    assert float((a.r.viewmats - b.r.viewmats).abs().max()) < 2e-3
 
 
 def test_lean_rows_of_the_ba_projection_change_no_result_and_as_output_restores_the_zeros(dev):
