@@ -835,7 +835,7 @@ def test_tiles_collect_their_keys_from_the_projection_rows(dev, n_gauss, scale_u
     records and pose partials to float-atomic noise, M equal - in a first closure (no cut-offs), a second one, after a pose jump
     (cut-offs of the old pose: further slabs are read from the tile's own copy of its keys) and with cut-offs far too tight; on a
     scene whose tiles outgrow the LDS sort; on piles of equal depths (the through-memory sort over the collected segment); and
-    through the captured closure: same optimiser trajectory."""
+    through the captured closure: same end point of ten Adam steps."""
     from gslam_amd.map import GaussianSplattingData
     from gslam_amd.plan import TrackClosure, current_stream_ptr
     from gslam_amd.primitives import Camera
@@ -921,16 +921,16 @@ def test_tiles_collect_their_keys_from_the_projection_rows(dev, n_gauss, scale_u
         c.load(V0.to(dev), img, torch.tensor([0.02, -0.01], device=dev))
         c.prepare()
         c.load(V0.to(dev), img, torch.tensor([0.02, -0.01], device=dev))
-        c.init_optimizer(4, 1e-3, 5, 8)
+        c.init_optimizer(12, 1e-3, 5, 8)
         c.launch(10)
     torch.cuda.synchronize()
     assert ref.r.check_capacity() and new.r.check_capacity()
     ra, rb = ref.read_report().cpu(), new.read_report().cpu()
-    # (same lists, same per-pixel arithmetic; the gradient records are summed by float atomics in another order, and ten steps
-    # of Adam + line search amplify the last bits)
-    # (the optimiser's discrete decisions - when the line search stops - may flip on those bits: compared are where the two ended up)
-    assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
-    assert float((ref.r.viewmats - new.r.viewmats).abs().max()) < 5e-3
+    # (same lists, same per-pixel arithmetic; the gradient records are summed by float atomics in another order.  Ten closures inside
+    # the Adam warm-up: smooth steps, no discrete line-search decision that the last bits of a sum could flip)
+    assert torch.equal(ra[:4], rb[:4]) and float(ra[7]) == float(rb[7]) == 10.0, (ra, rb)
+    assert abs(float(ra[4]) - float(rb[4])) <= 1e-3 * abs(float(ra[4])) + 1e-12, (ra, rb)
+    assert float((ref.r.viewmats - new.r.viewmats).abs().max()) < 2e-3
 
 
 @pytest.mark.parametrize("n_gauss,scale_up,low_opacity", [(120000, 0.5, False), (300000, 0.9, False), (100000, 1.2, True)])
@@ -1014,13 +1014,14 @@ def test_exact_tile_test_drops_only_pairs_no_pixel_can_see(dev, n_gauss, scale_u
         c.load(V0.to(dev), img, torch.tensor([0.02, -0.01], device=dev))
         c.prepare()
         c.load(V0.to(dev), img, torch.tensor([0.02, -0.01], device=dev))
-        c.init_optimizer(4, 1e-3, 5, 8)
+        c.init_optimizer(12, 1e-3, 5, 8)                       # (ten closures inside the Adam warm-up: no line-search decision to flip)
         c.launch(10)
     torch.cuda.synchronize()
     assert full.r.check_capacity() and new.r.check_capacity()
     ra, rb = full.read_report().cpu(), new.read_report().cpu()
-    assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
-    assert float((full.r.viewmats - new.r.viewmats).abs().max()) < 5e-3
+    assert torch.equal(ra[:4], rb[:4]) and float(ra[7]) == float(rb[7]) == 10.0, (ra, rb)
+    assert abs(float(ra[4]) - float(rb[4])) <= 1e-3 * abs(float(ra[4])) + 1e-12, (ra, rb)
+    assert float((full.r.viewmats - new.r.viewmats).abs().max()) < 2e-3
 
 
 @pytest.mark.parametrize("n_gauss,n_cams,W,H", [(60000, 3, 640, 480), (200000, 8, 640, 480), (30000, 2, 325, 245)])
@@ -1084,8 +1085,10 @@ def test_window_closure_on_the_tracking_machinery_equals_the_generic_path(dev, n
     torch.cuda.synchronize()
     assert ref.r.check_capacity() and new.r.check_capacity()
     ra, rb = ref.read_report().cpu(), new.read_report().cpu()
-    assert abs(float(ra[5]) - float(rb[5])) <= 1e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
-    assert float((ref.r.viewmats - new.r.viewmats).abs().max()) < 5e-3
+    # (six closures of a line search: its discrete decisions may flip on the last bits of a float-atomic sum - compared is where the
+    # two ended up, loosely; the closures themselves are compared above to 2e-6 / 3e-4)
+    assert abs(float(ra[5]) - float(rb[5])) <= 2e-2 * abs(float(ra[5])) + 1e-12, (ra, rb)
+    assert float((ref.r.viewmats - new.r.viewmats).abs().max()) < 1e-2
 
 
 def test_projection_backward_range_by_range_equals_one_launch(dev):
