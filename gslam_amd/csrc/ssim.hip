@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float *__restrict__
 // SSIM gradient added last - the same expressions in the same order as map_loss_kernel, so d loss / d render comes out bit for bit)
 // takes the planar SSIM gradient's round trip through HBM (write 12 B, read 12 B per pixel), one more pass over render + target
 // and one launch out of the BA iteration.  One partial row of the loss sums per tile (gsx_ssim_bwd_map_loss_rows).
-__global__ __launch_bounds__(256) void ssim_bwd_loss_kernel(gsx_loss::LossArgs A, int crop, const float *__restrict__ dm_dmu1,
+__global__ __launch_bounds__(256, 5) void ssim_bwd_loss_kernel(gsx_loss::LossArgs A, int crop, const float *__restrict__ dm_dmu1,
                                                             const float *__restrict__ dm_ds1,
                                                             const float *__restrict__ dm_ds12,
                                                             const float *__restrict__ scale, float scale_mul, int gx_n,
@@ -306,28 +306,33 @@ __global__ __launch_bounds__(256) void ssim_bwd_loss_kernel(gsx_loss::LossArgs A
     constexpr int NC = 3;
     __shared__ float sm[3][INY][INX + 1];
     __shared__ float hz[3][INY][TSX + 1];
-    __shared__ float s_xy[2][NC][TSY][TSX + 1];
     __shared__ float s_part[4][gsx_loss::NPART];
     const TileId tid = xcd_tile(gx_n, gy_n, gz_n);
     const int b = tid.bz;                                     // camera
     const int H = A.H, W = A.W, CH = A.CH;
     const int x0 = tid.bx * TSX, y0 = tid.by * TSY;
     const int t = threadIdx.x;
-    for (int i = t; i < TSY * TSX; i += 256) {
-        const int ly = i / TSX, lx = i - ly * TSX;
-        const int gy = y0 + ly, gx = x0 + lx;
-        const bool in = gy < H && gx < W;
-        const int64_t p = ((int64_t)b * H + gy) * W + gx;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            s_xy[0][k][ly][lx] = in ? A.render[p * CH + k] : 0.f;
-            s_xy[1][k][ly][lx] = in ? A.gt[p * 3 + k] : 0.f;
-        }
-    }
     const float sc = scale[0] * scale_mul;
     const int lx = t & 31, ly = (t >> 5) * 2;
     const int gx = x0 + lx;
+    // the colours of the thread's two output pixels in both images: registers, requested before anything else (they were a 12.7 KB
+    // LDS tile: without it five workgroups fit a CU instead of four - the kernel's time is its workgroups' chain length times the
+    // rounds it takes to run them all)
+    float px[2][NC], py[2][NC];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int gy = y0 + ly + o;
+        const bool in = gy < H && gx < W;
+        const int64_t p = ((int64_t)b * H + (in ? gy : 0)) * W + (in ? gx : 0);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const float r = A.render[p * CH + k], q = A.gt[p * 3 + k];
+            px[o][k] = in ? r : 0.f;
+            py[o][k] = in ? q : 0.f;
+        }
+    }
     float g[2][3];
+#pragma nounroll
     for (int kc = 0; kc < NC; ++kc) {
         const int plane = b * 3 + kc;
         __syncthreads();
@@ -354,21 +359,18 @@ __global__ __launch_bounds__(256) void ssim_bwd_loss_kernel(gsx_loss::LossArgs A
         __syncthreads();
         if (t < INY * (TSX / 4)) {
             const int yy = t / (TSX / 4), xx = (t - yy * (TSX / 4)) * 4;
-            // maps 0 and 1 as the halves of a packed accumulator (v_pk_fma_f32), map 2 on its own: the same fused multiply-adds
-            float in0[14], in1[14], in2[14];
 #pragma unroll
-            for (int k = 0; k < 14; ++k) { in0[k] = sm[0][yy][xx + k]; in1[k] = sm[1][yy][xx + k]; in2[k] = sm[2][yy][xx + k]; }
+            for (int m = 0; m < 3; ++m) {
+                float in[14];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                f2 acc01 = {0.f, 0.f};
-                float acc2 = 0.f;
+                for (int k = 0; k < 14; ++k) in[k] = sm[m][yy][xx + k];
 #pragma unroll
-                for (int k = 0; k < 11; ++k) {
-                    const float w = c_win[k];
-                    acc01 = __builtin_elementwise_fma(f2{w, w}, f2{in0[o + k], in1[o + k]}, acc01);
-                    acc2 = __builtin_fmaf(w, in2[o + k], acc2);
+                for (int o = 0; o < 4; ++o) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc = __builtin_fmaf(c_win[k], in[o + k], acc);
+                    hz[m][yy][xx + o] = acc;
                 }
-                hz[0][yy][xx + o] = acc01.x; hz[1][yy][xx + o] = acc01.y; hz[2][yy][xx + o] = acc2;
             }
         }
         __syncthreads();
@@ -385,7 +387,8 @@ __global__ __launch_bounds__(256) void ssim_bwd_loss_kernel(gsx_loss::LossArgs A
         const float acc[2][3] = {{pa[0].x, pa[1].x, pa[2].x}, {pa[0].y, pa[1].y, pa[2].y}};
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            const float x = s_xy[0][kc][ly + o][lx], y = s_xy[1][kc][ly + o][lx];
+            const float x = kc == 0 ? px[o][0] : (kc == 1 ? px[o][1] : px[o][2]);
+            const float y = kc == 0 ? py[o][0] : (kc == 1 ? py[o][1] : py[o][2]);
             const float v = sc * (acc[o][0] + 2.0f * x * acc[o][1] + y * acc[o][2]);
             if (kc == 0) g[o][0] = v; else if (kc == 1) g[o][1] = v; else g[o][2] = v;
         }
@@ -396,8 +399,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_loss_kernel(gsx_loss::LossArgs A
         const int gy = y0 + ly + o;
         if (gx < W && gy < H) {
             float pp[gsx_loss::NPART] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            gsx_loss::map_loss_pixel(A, b, gx, gy, s_xy[0][0][ly + o][lx], s_xy[0][1][ly + o][lx], s_xy[0][2][ly + o][lx],
-                                     s_xy[1][0][ly + o][lx], s_xy[1][1][ly + o][lx], s_xy[1][2][ly + o][lx], true, g[o], pp);
+            gsx_loss::map_loss_pixel(A, b, gx, gy, px[o][0], px[o][1], px[o][2], py[o][0], py[o][1], py[o][2], true, g[o], pp);
 #pragma unroll
             for (int k = 0; k < gsx_loss::NPART; ++k) part[k] += pp[k];
         }
